@@ -1,0 +1,156 @@
+/*
+ * ezdit.h -- C ABI of libezaudio_hip.so: the MI355X (gfx950) EzAudio denoising path.
+ *
+ * The reference (haidog-yaqub/EzAudio) is pure Python/PyTorch and has no FFI layer; its hot path
+ * sits behind plain Python callables.  This header is therefore the boundary a maintainer would
+ * bind (ctypes stub in INTEGRATION.md); each entry point names the reference interface it stands
+ * in for (paths relative to the reference tree).
+ *
+ * Conventions (surface B3):
+ *   - every pointer marked `dev` is a DEVICE pointer owned by the caller; the library never
+ *     allocates or frees persistent device memory.  Weights live in one caller-owned blob laid out
+ *     by ezdit_param_info(); all activations / tables live in one caller-owned workspace.
+ *   - every entry point that takes a stream is ASYNCHRONOUS on that stream: no device sync, no
+ *     host read of device data (a sampler step is hipGraph-capturable).
+ *   - return 0 = OK, negative = error; ezdit_last_error() gives a thread-local message.  No C++
+ *     exception crosses the ABI.
+ *   - a handle is bound to the device that was current at ezdit_create() and is NOT thread-safe:
+ *     one handle per device/stream; multi-GPU = one process + one handle per GPU.
+ *   - layouts: latents channel-major fp32 [rows, C, L] exactly as the reference passes them
+ *     (src/inference.py:67,75); context fp32 [B, Lc, Cctx]; masks uint8 (0/1).
+ */
+#ifndef EZDIT_H
+#define EZDIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EZDIT_ABI_VERSION 1
+
+typedef struct ezdit_handle ezdit_handle;
+typedef void* ezdit_stream; /* hipStream_t */
+
+/* Mirrors the `model:` section of ckpts/ezaudio-{l,xl}.yml (the keys UDiT.__init__ consumes,
+ * src/models/udit.py:11-30).  Only the shipped combination is implemented; ezdit_create returns
+ * EZDIT_E_UNSUPPORTED for anything else, mirroring the NotImplementedError sites udit.py:83,113,127. */
+typedef struct {
+    int32_t embed_dim;     /* D */
+    int32_t num_heads;     /* H, head_dim = D / H, must be 64 or 72 */
+    int32_t depth;         /* depth//2 in-blocks + mid + depth//2 out-blocks */
+    int32_t in_chans;      /* 257 = 2*out_chans + 1 (MaskDiT concat, conditioners.py:161-176) */
+    int32_t out_chans;     /* C = 128 latent channels */
+    int32_t context_dim;   /* T5 width */
+    int32_t ada_sola_rank; /* r */
+    float   ada_sola_alpha;
+    float   mlp_ratio;     /* 4.0 */
+    int32_t max_len;       /* longest latent sequence the RoPE table covers */
+} ezdit_config;
+
+enum {
+    EZDIT_OK = 0,
+    EZDIT_E_INVALID = -1,      /* bad argument / shape (reference: AssertionError class) */
+    EZDIT_E_UNSUPPORTED = -2,  /* config value outside the implemented set (NotImplementedError) */
+    EZDIT_E_STATE = -3,        /* call order: weights/workspace/context/timesteps not prepared */
+    EZDIT_E_HIP = -4           /* a HIP runtime call failed */
+};
+
+/* ---- parameter blob layout (replaces MaskDiT.load_state_dict, api/ezaudio.py:83-85) ---------- */
+enum { EZDIT_P_F32 = 0, EZDIT_P_BF16 = 1 };
+enum {
+    EZDIT_T_NONE = 0,
+    EZDIT_T_GEGLU32 = 1 /* rows re-ordered so each 64-row group = 32 value rows then their 32 gate rows */
+};
+typedef struct {
+    char    name[64];      /* our slot name, e.g. "blk3.wqkv" */
+    char    src[3][96];    /* state-dict keys concatenated along dim 0 (nsrc of them) */
+    int32_t nsrc;
+    int32_t dtype;         /* EZDIT_P_* */
+    int32_t transform;     /* EZDIT_T_* */
+    int64_t rows, cols;    /* logical shape after concatenation (trailing dims flattened) */
+    int64_t rows_pad, ld;  /* stored shape: zero padded to [rows_pad][ld] */
+    int64_t offset;        /* byte offset in the blob, 256-byte aligned */
+} ezdit_param_info_t;
+
+int         ezdit_abi_version(void);
+const char* ezdit_last_error(void);
+
+int    ezdit_create(const ezdit_config* cfg, ezdit_handle** out);
+int    ezdit_destroy(ezdit_handle* h);
+
+int    ezdit_param_count(const ezdit_handle* h);
+int    ezdit_param_info(const ezdit_handle* h, int index, ezdit_param_info_t* out);
+size_t ezdit_param_bytes(const ezdit_handle* h);
+int    ezdit_bind_weights(ezdit_handle* h, const void* dev_blob, size_t bytes);
+
+/* ---- workspace ------------------------------------------------------------------------------- */
+/* B = denoiser batch rows (2 x prompts with CFG), L = latent frames, Lc = context tokens,
+ * n_slots = number of distinct timesteps whose modulation tables are resident (sampler: n_steps). */
+size_t ezdit_workspace_bytes(const ezdit_handle* h, int B, int L, int Lc, int n_slots);
+int    ezdit_bind_workspace(ezdit_handle* h, void* dev_ws, size_t bytes, int B, int L, int Lc, int n_slots,
+                            ezdit_stream stream);
+
+/* ---- step-invariant work, hoisted (reference recomputes it every step) ----------------------- */
+/* context_embed + per-block norm_context + cross to_k/to_v + head LayerNorm(k):
+ * src/models/udit.py:94-97,295-296; blocks.py:84-85,150; utils/attention.py:128-142.
+ * ctx fp32 [B,Lc,Cctx]; mask uint8 [B,Lc], 1 = attend (T5 attention_mask, src/inference.py:42,47). */
+int ezdit_prepare_context(ezdit_handle* h, const float* dev_ctx, const uint8_t* dev_mask, ezdit_stream stream);
+
+/* timestep embedding, TimestepEmbedder, time_act, time_ada(_final), per-block AdaLN-SOLA:
+ * utils/modules.py:19-61; udit.py:305-316; blocks.py:39-45,132-133.  `timesteps` is a HOST array.
+ * per_row = 0: every batch row uses slot `cur_step` (see ezdit_set_step); sampler usage.
+ * per_row = 1: n must equal B and row b uses slot b (MaskDiT.forward with a [B] timesteps tensor). */
+int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* timesteps, int n, int per_row, ezdit_stream stream);
+int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream);
+
+/* ---- the denoiser operator: MaskDiT.forward / UDiT.forward ----------------------------------- */
+/* src/models/conditioners.py:156-183 (in_ch = C: x [x_rows,C,L], optional gt/gt_mask [x_rows,C,L];
+ * batch row b reads latent row b % x_rows, which is how the CFG pair shares one latent,
+ * src/inference.py:75) or src/models/udit.py:281-362 directly (in_ch = 2C+1: x is the assembled
+ * [B,257,L] input, as src/inference_controlnet.py:97-99 calls unet.model).
+ * cn_skips: optional n_cn device pointers to fp32 [B,L,D] ControlNet residuals in the reference's
+ * list order (popped from the end, udit.py:345-348), each already multiplied by conditioning_scale.
+ * out: fp32 [B,C,L]. */
+int ezdit_forward(ezdit_handle* h, const float* dev_x, int in_ch, int x_rows,
+                  const float* dev_gt, const uint8_t* dev_gt_mask,
+                  const float* const* cn_skips, int n_cn,
+                  float* dev_out, ezdit_stream stream);
+
+/* ---- sampler: CFG + rescale + DDIM, src/inference.py:70-100 + diffusers DDIMScheduler.step ---- */
+typedef struct {
+    float sa, sb;      /* sqrt(alpha_bar_t), sqrt(1 - alpha_bar_t) */
+    float c_x0, c_dir; /* sqrt(alpha_bar_prev), sqrt(1 - alpha_bar_prev - sigma^2) */
+    float sigma;       /* eta * sqrt(variance) */
+} ezdit_ddim_coef;
+
+/* dev_latents fp32 [P,C,L] is updated in place each step; dev_noise fp32 [n_steps,P,C,L] or NULL
+ * (eta == 0); coefs is a HOST array of n_steps entries (copied into the workspace);
+ * guidance_scale <= 0 disables CFG (B = P, src/inference.py:94-96), otherwise B = 2P with rows
+ * [0,P) conditional and [P,2P) unconditional.  gt/gt_mask as in ezdit_forward (editing). */
+int ezdit_sampler_begin(ezdit_handle* h, float* dev_latents, int P, const float* dev_noise,
+                        const ezdit_ddim_coef* coefs, int n_steps,
+                        float guidance_scale, float guidance_rescale,
+                        const float* dev_gt, const uint8_t* dev_gt_mask, ezdit_stream stream);
+/* run `n` consecutive steps from the current step counter; use_graph != 0 captures one step into a
+ * hipGraph on first use and replays it (no host work between kernels). */
+int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream);
+
+/* ---- unit-test hooks: one kernel family each, same code the forward uses ---------------------- */
+int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw,
+                    const float* dev_bias, void* dev_out, int ldo, int M, int N, int K, int splitk,
+                    ezdit_stream stream);
+int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, const void* dev_vt,
+                         const uint8_t* dev_kmask, void* dev_out, int B, int Lq, int Lk, int Lqp, int Lkp,
+                         ezdit_stream stream);
+/* copy an internal fp32/bf16 buffer (by name, e.g. "h", "u", "q", "k", "vt", "mod") for debugging. */
+int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t* bytes);
+/* number of kernel launches issued by the last ezdit_forward (host counter). */
+int ezdit_last_launch_count(const ezdit_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EZDIT_H */

@@ -1,0 +1,207 @@
+"""Mint golden vectors from the REFERENCE ITSELF (runs only in the build container).
+
+    python -m oracle.mint_golden [--only NAME] [--out tests/golden]
+
+Imports the reference's own modules from /root/reference (read-only; nothing is copied), loads
+the deterministic synthetic checkpoint of oracle/weights.py into ``MaskDiT`` via
+``load_state_dict`` (after asserting that key set and shapes agree with the real module), runs it
+in fp32 on CPU on the deterministic inputs of ``oracle.weights.make_inputs`` and stores
+inputs-by-seed + outputs under tests/golden/.  /root/reference does not exist on the GPU box, so
+tests only ever read the committed .npz files; this script is the provenance record.
+
+The reference has no tests and ships no golden vectors, so these fixtures
+are what pins oracle/dit.py and oracle/sampler.py.  The DDIM scheduler (third-party diffusers,
+absent) is NOT pinned by them: the sampler fixture drives the reference's unmodified
+``inference()`` with a scheduler object backed by oracle/ddim.py.
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+
+
+def _import_reference():
+    import torch  # noqa: F401
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for stub in ('librosa', 'soundfile'):  # unused top-level imports of src/inference.py:5,7
+        sys.modules.setdefault(stub, types.ModuleType(stub))
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.models.conditioners import MaskDiT
+        from src.inference import inference
+    return MaskDiT, inference
+
+
+def build_reference(cfg, seed):
+    import torch
+    from .weights import make_state_dict
+    MaskDiT, _ = _import_reference()
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = MaskDiT(**cfg).eval()
+    sd = make_state_dict(cfg, seed)
+    ref_sd = m.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()), (sorted(set(ref_sd) ^ set(sd))[:10])
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == sd[k].shape, (k, tuple(v.shape), sd[k].shape)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    return m, sd
+
+
+def mint_forward(name, size, L, Lc, timesteps, seed_w, seed_in, n_valid=(12, 1), with_gt=False,
+                 cn_skips=False, out_dir='tests/golden'):
+    import torch
+    from .weights import model_config, make_inputs, uniform_pm1
+    cfg = model_config(size)
+    m, _ = build_reference(cfg, seed_w)
+    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, n_valid=n_valid, seed=seed_in, with_gt=with_gt)
+    outs = {}
+    torch.set_num_threads(os.cpu_count())
+    with torch.no_grad():
+        for t in timesteps:
+            kw = {}
+            if with_gt:
+                kw = dict(gt=torch.from_numpy(inp['gt'].copy()), mae_mask_infer=torch.from_numpy(inp['gt_mask'].copy()))
+            if cn_skips:
+                # UDiT.forward(controlnet_skips=...) is reached through unet.model (inference_controlnet.py:89-99)
+                x257, _ = m(torch.from_numpy(inp['x'].copy()), torch.tensor(t), None, forward_model=False, **kw)
+                D = cfg['embed_dim']
+                skips = [torch.from_numpy((0.1 * uniform_pm1(f'in.cn{i}', 2 * L * D, seed_in)).reshape(2, L, D))
+                         for i in range(cfg['depth'] // 2)]
+                pred = m.model(x257, torch.tensor(t), torch.from_numpy(inp['ctx']),
+                               context_mask=torch.from_numpy(inp['ctx_mask']), cls_token=None,
+                               controlnet_skips=list(skips))
+            else:
+                pred, _ = m(torch.from_numpy(inp['x'].copy()), torch.tensor(t), torch.from_numpy(inp['ctx']),
+                            context_mask=torch.from_numpy(inp['ctx_mask']), cls_token=None, **kw)
+            outs[f'pred_t{t}'] = pred.numpy().astype(np.float32)
+    meta = dict(size=size, L=L, Lc=Lc, seed_w=seed_w, seed_in=seed_in, n_valid=list(n_valid),
+                with_gt=with_gt, cn_skips=cn_skips, timesteps=list(timesteps))
+    path = os.path.join(out_dir, f'dit_{name}.npz')
+    np.savez(path, meta=np.array(repr(meta)), **outs)
+    print('wrote', path, {k: (v.shape, float(v.std())) for k, v in outs.items()})
+
+
+class _FakeTok:
+    """Duck-typed tokenizer: text is a key into a table of pre-made (ids, mask)."""
+    def __init__(self, table):
+        self.table = table
+
+    def __call__(self, text, max_length=None, padding=None, truncation=None, return_tensors=None):
+        import torch
+        key = text[0] if isinstance(text, (list, tuple)) else text
+        ids, mask = self.table[key]
+        return types.SimpleNamespace(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask))
+
+
+class _FakeT5:
+    def __init__(self, emb):
+        self.emb = emb
+
+    def __call__(self, input_ids=None, attention_mask=None):
+        import torch
+        return types.SimpleNamespace(last_hidden_state=torch.from_numpy(self.emb[int(input_ids[0, 0])]))
+
+
+class _OracleScheduler:
+    """Scheduler with diffusers' call surface (set_timesteps / scale_model_input / step), backed by
+    oracle/ddim.py; `step` pops pre-drawn noise so the loop is deterministic."""
+    def __init__(self, diff, noises):
+        from .ddim import DDIMOracle
+        self.o = DDIMOracle(**diff)
+        self.noises = list(noises)
+        self.i = 0
+
+    def set_timesteps(self, n):
+        import torch
+        self.o.set_timesteps(n)
+        self.timesteps = torch.from_numpy(self.o.timesteps)
+
+    def scale_model_input(self, x, t):
+        return x
+
+    def step(self, model_output, timestep, sample, eta, generator):
+        import torch
+        z = self.noises[self.i]
+        self.i += 1
+        out = self.o.step(model_output.numpy(), int(timestep), sample.numpy(), eta, z)
+        return types.SimpleNamespace(prev_sample=torch.from_numpy(out))
+
+
+DIFF = dict(num_train_timesteps=1000, beta_schedule='scaled_linear', beta_start=0.00085, beta_end=0.012,
+            prediction_type='v_prediction', rescale_betas_zero_snr=True, timestep_spacing='trailing',
+            clip_sample=False)
+
+
+def mint_sampler(name, size, L, Lc, steps, seed_w, seed_in, guidance_scale, guidance_rescale, eta,
+                 with_gt=False, out_dir='tests/golden'):
+    """Run the reference's unmodified inference() (src/inference.py:26-107) with duck-typed fakes."""
+    import torch
+    from .weights import model_config, make_inputs, uniform_pm1
+    _, inference = _import_reference()
+    cfg = model_config(size)
+    m, _ = build_reference(cfg, seed_w)
+    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, seed=seed_in, with_gt=with_gt)
+    C = cfg['out_chans']
+    s3 = np.float32(np.sqrt(3.0))
+    init = (uniform_pm1('smp.init', C * L, seed_in) * s3).reshape(1, C, L)
+    noises = [(uniform_pm1(f'smp.z{i}', C * L, seed_in) * s3).reshape(1, C, L) for i in range(steps)]
+    tok = _FakeTok({'prompt': (np.array([[0]]), inp['ctx_mask'][0:1].astype(np.int64)),
+                    '': (np.array([[1]]), inp['ctx_mask'][1:2].astype(np.int64))})
+    t5 = _FakeT5({0: inp['ctx'][0:1], 1: inp['ctx'][1:2]})
+    sched = _OracleScheduler(DIFF, noises)
+    params = dict(text_encoder=dict(max_length=Lc), model=cfg, autoencoder=dict(scale=1.0, shift=0.0))
+    gt = torch.from_numpy(inp['gt'][0:1].copy()) if with_gt else None
+    gm = torch.from_numpy(inp['gt_mask'][0:1].copy()) if with_gt else None
+    # inference() draws the init noise itself from torch.Generator; inject ours by patching randn once
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: torch.from_numpy(init.copy())
+    try:
+        torch.set_num_threads(os.cpu_count())
+        out = inference(lambda embedding: embedding, m, gt, gm, tok, t5, params, sched,
+                        ['prompt'], None, L, guidance_scale, guidance_rescale, steps, eta, 2024, 'cpu')
+    finally:
+        torch.randn = real_randn
+    meta = dict(size=size, L=L, Lc=Lc, steps=steps, seed_w=seed_w, seed_in=seed_in, with_gt=with_gt,
+                guidance_scale=guidance_scale, guidance_rescale=guidance_rescale, eta=eta)
+    path = os.path.join(out_dir, f'sampler_{name}.npz')
+    np.savez(path, meta=np.array(repr(meta)), latent=out.numpy().astype(np.float32))
+    print('wrote', path, out.shape, float(out.std()))
+
+
+JOBS = {
+    # name: (fn, kwargs)
+    'xs':        (mint_forward, dict(size='xs', L=96, Lc=20, timesteps=[999, 499, 19], seed_w=1, seed_in=11, n_valid=(7, 1))),
+    'xs64':      (mint_forward, dict(size='xs64', L=96, Lc=20, timesteps=[979, 19], seed_w=1, seed_in=11, n_valid=(7, 1))),
+    'xs_edit':   (mint_forward, dict(size='xs', L=77, Lc=20, timesteps=[499], seed_w=1, seed_in=12, n_valid=(5, 1), with_gt=True)),
+    'xs_cn':     (mint_forward, dict(size='xs', L=96, Lc=20, timesteps=[499], seed_w=1, seed_in=13, n_valid=(5, 1), cn_skips=True)),
+    's':         (mint_forward, dict(size='s', L=500, Lc=100, timesteps=[999, 979, 499, 19], seed_w=1234, seed_in=11)),
+    's64':       (mint_forward, dict(size='s64', L=500, Lc=100, timesteps=[999, 19], seed_w=1234, seed_in=11)),
+    's_edit':    (mint_forward, dict(size='s', L=300, Lc=100, timesteps=[499], seed_w=1234, seed_in=12, with_gt=True)),
+    'l':         (mint_forward, dict(size='l', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=11)),
+    'xl':        (mint_forward, dict(size='xl', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=11)),
+    'smp_xs':    (mint_sampler, dict(size='xs', L=96, Lc=20, steps=50, seed_w=1, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
+    'smp_xs_e0': (mint_sampler, dict(size='xs', L=96, Lc=20, steps=20, seed_w=1, seed_in=22, guidance_scale=3.5, guidance_rescale=0.0, eta=0.0, with_gt=True)),
+    'smp_s':     (mint_sampler, dict(size='s', L=500, Lc=100, steps=50, seed_w=1234, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*')
+    ap.add_argument('--out', default='tests/golden')
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    for name, (fn, kw) in JOBS.items():
+        if a.only and name not in a.only:
+            continue
+        fn(name, out_dir=a.out, **kw)
+
+
+if __name__ == '__main__':
+    main()
