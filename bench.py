@@ -1,0 +1,225 @@
+"""Headline benchmark: denoising steps/sec, EzAudio-XL, 10 s latent (500 frames), CFG on.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size xl] [--prompts P]
+
+One "step" = one pass of the hot path: CFG denoiser evaluation (cond + uncond rows) + CFG combine +
+guidance rescale + DDIM update for every prompt of the batch.  Weights are random-init of
+the named architecture, inputs are synthetic T5 embeddings and seeded noise (no network here).
+N > 1: launched by torch.distributed.run, one rank per GPU; prompts are sharded (weak scaling: `--prompts`
+per GPU), there is no collective inside the step loop, and finished latents are all-gathered once over
+RCCL at the end of the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def model_section(size):
+    from ezaudio_amd.config import configs, load_yaml_with_includes
+    if size in ('xl', 'l'):
+        return load_yaml_with_includes(configs['s3_' + size]['config'])
+    raise SystemExit(f'unknown --size {size}')
+
+
+def flops_per_step(cfg, B, L, Lc):
+    """Algorithmic GEMM FLOPs of one denoiser evaluation with the step-invariant context work hoisted
+    (SURVEY.md section 8d): 2 FLOP per MAC, no padding credit."""
+    D, nblk, nskip, C = cfg['embed_dim'], cfg['depth'] + 1, cfg['depth'] // 2, cfg['out_chans']
+    macs = nblk * (18 * L * D * D + 2 * L * L * D + 2 * L * Lc * D) + nskip * 2 * L * D * D \
+        + L * D * (cfg['in_chans'] + C) + 3 * C * C * L
+    return 2.0 * macs * B
+
+
+def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
+    """Time the dominant kernel of the step (the GEGLU-in GEMM: 41 % of the step's FLOPs) with HIP events on
+    the stream it is launched on, same kernel + shape the step uses (through the ABI's unit-test hook)."""
+    D = cfg['embed_dim']
+    inner = 4 * D
+    dev = unet.device
+    A = torch.randn(M, D, device=dev).to(torch.bfloat16)
+    W = (torch.randn(2 * inner, D, device=dev) / D ** 0.5).to(torch.bfloat16)
+    bias = torch.zeros(2 * inner, device=dev)
+    out = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
+    lib = unet.lib
+    with torch.cuda.stream(stream):
+        for _ in range(3):
+            lib.ezdit_test_gemm(None, 4, A.data_ptr(), D, W.data_ptr(), D, bias.data_ptr(), out.data_ptr(), inner, M,
+                                2 * inner, D, 1, C.c_void_p(stream.cuda_stream))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            lib.ezdit_test_gemm(None, 4, A.data_ptr(), D, W.data_ptr(), D, bias.data_ptr(), out.data_ptr(), inner, M,
+                                2 * inner, D, 1, C.c_void_p(stream.cuda_stream))
+        e1.record(stream)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    fl = 2.0 * M * D * 2 * inner
+    return dict(name='k_gemm<128,128,GEGLU> (mlp.net.0.proj + GEGLU)', launches_per_step=cfg['depth'] + 1,
+                flops_per_launch=fl, avg_us=us, tflops=fl / us / 1e6, frac=fl / us / 1e6 / PEAK_BF16_TFLOPS,
+                note='back-to-back launches, includes launch gaps')
+
+
+def cpu_baseline(cfg, sd, text, text_mask, uncond, uncond_mask, L, n_eval=2):
+    """The numpy fp32 oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded
+    sample: n_eval CFG denoiser evaluations of the same workload."""
+    from oracle.dit import DiTOracle
+    o = DiTOracle(cfg, {k: v.numpy() for k, v in sd.items()}, np.float32)
+    x = np.random.default_rng(0).standard_normal((2, cfg['out_chans'], L)).astype(np.float32)
+    ctx = np.concatenate([text[:1], uncond[:1]], 0)
+    msk = np.concatenate([text_mask[:1], uncond_mask[:1]], 0)
+    o.forward(x[:, :, :64], 499, ctx, msk)  # warm up BLAS threads
+    t0 = time.perf_counter()
+    for _ in range(n_eval):
+        o.forward(x, 499, ctx, msk)
+    dt = (time.perf_counter() - t0) / n_eval
+    return dict(value=1.0 / dt, unit='steps/s', cores=os.cpu_count(), kind='port',
+                sample=f'{n_eval} CFG denoiser evaluations (B=2 rows, L={L}, Lc={ctx.shape[1]}) of the numpy fp32 oracle '
+                       f'(oracle/dit.py, multi-threaded BLAS); CFG/DDIM update excluded (negligible)',
+                seconds_per_step=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', default='xl')
+    ap.add_argument('--prompts', type=int, default=1, help='prompts per GPU (each is a cond+uncond pair)')
+    ap.add_argument('--ddim-steps', type=int, default=50)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        a.gpus = world
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from ezaudio_amd import MaskDiT
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    from ezaudio_amd.weights import random_state_dict
+
+    params = model_section(a.size)
+    cfg = params['model']
+    L = 10 * params['autoencoder']['latent_sr']          # 10 s latent = 500 frames (api/ezaudio.py:105)
+    Lc = params['text_encoder']['max_length']
+    P = a.prompts
+    sd = random_state_dict(cfg, seed=1234)
+    unet = MaskDiT(device=dev, **cfg)
+    unet.load_state_dict(sd)
+
+    # synthetic inputs, generated on CPU with seeded generators (identical on every box)
+    g = torch.Generator().manual_seed(11 + rank)
+    text = torch.randn(P, Lc, cfg['context_dim'], generator=g)
+    uncond = torch.randn(1, Lc, cfg['context_dim'], generator=g).repeat(P, 1, 1)
+    text_mask = torch.zeros(P, Lc, dtype=torch.bool)
+    for i in range(P):
+        text_mask[i, :4 + (9 * (rank * P + i)) % 37] = True      # 4..40 valid tokens
+    uncond_mask = torch.zeros(P, Lc, dtype=torch.bool)
+    uncond_mask[:, :1] = True                                      # "" -> EOS only
+    n_ddim = a.ddim_steps
+    init = torch.randn(P, cfg['out_chans'], L, generator=g)
+    noise = torch.randn(n_ddim, P, cfg['out_chans'], L, generator=g)
+
+    smp = LatentSampler(unet, DDIMScheduler(**params['diff']))
+    # API defaults of generate_audio except the step count: guidance 5, rescale 0.75, eta 1
+    smp.prepare(text, text_mask, uncond, uncond_mask, init, noise, 5.0, 0.75, n_ddim, 1.0)
+    init_dev = init.to(dev)
+    use_graph = not a.no_graph
+
+    def reset():
+        with torch.cuda.stream(smp.stream):
+            smp.latents.copy_(init_dev, non_blocking=True)
+            unet.lib.ezdit_set_step(unet._h, 0, C.c_void_p(smp.stream.cuda_stream))
+
+    def run_steps(k):
+        done = 0
+        while done < k:
+            n = min(n_ddim, k - done)
+            reset()
+            smp.run(n, use_graph=use_graph)
+            done += n
+
+    run_steps(max(a.warmup, 1))          # includes hipGraph capture
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(smp.stream)
+    run_steps(a.steps)
+    e1.record(smp.stream)
+    lat = smp.finish()
+    if dist:  # the only collective of the job: gather the finished latents (1 MB per rank)
+        out = [torch.empty_like(lat) for _ in range(world)]
+        dist.all_gather(out, lat)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(lat).all(), 'non-finite latents'
+
+    if rank == 0:
+        B = 2 * P
+        fl = flops_per_step(cfg, B, L, Lc)
+        steps_per_s = a.steps / dt                       # loop iterations per second (per GPU)
+        value = steps_per_s * P * world                  # sample-steps/s over the whole job
+        ach = fl * (a.steps / (ev_ms * 1e-3)) / 1e12     # TFLOP/s from HIP events around the timed loop
+        res = {
+            'metric': 'denoising steps/sec (EzAudio-%s, 10 s latent, CFG on)' % a.size.upper(),
+            'value': value, 'unit': 'sample-steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': dt * 1e3 / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'EzAudio-%s (ezaudio-%s.yml) %d-step DDIM sampler, 10 s latent (L=%d, Lc=%d), CFG on '
+                                   '(guidance 5, rescale 0.75, eta 1), %d prompt(s)/GPU = %d denoiser rows/GPU, random-init '
+                                   'weights, bf16 MFMA / fp32 accumulate + fp32 residual stream'
+                                   % (a.size.upper(), a.size, n_ddim, L, Lc, P, B),
+                       'prompts_per_gpu': P, 'rows_per_gpu': B, 'latent_frames': L, 'hipgraph': use_graph,
+                       'kernel_launches_per_step': unet.last_launch_count},
+            'loop_steps_per_s_per_gpu': steps_per_s,
+            'roofline': {'bound': 'mfma', 'kernel': 'whole denoising step (all kernels of the DiT forward + CFG/DDIM)',
+                         'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
+                         'flops_per_step': fl, 'event_ms_per_step': ev_ms / a.steps, 'traffic': None},
+        }
+        try:
+            res['roofline']['dominant_kernel'] = dominant_kernel_probe(unet, cfg, B * L, smp.stream)
+        except Exception as e:  # the probe must never cost the headline number
+            res['roofline']['dominant_kernel'] = {'error': repr(e)}
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, sd, text.numpy(), text_mask.numpy(), uncond.numpy(), uncond_mask.numpy(), L)
+        print(json.dumps(res))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,135 @@
+"""Public API, signature-compatible with the reference's ``api/ezaudio.py`` (EzAudio) -- the drop-in
+surface B1 of SURVEY.md section 8b.  Everything on the denoising path runs in libezaudio_hip.so; T5
+(``transformers``) and the VAE are pre/post models outside this round's scope, so
+they can be injected; when not injected, T5 is loaded the way the reference loads it.
+"""
+import random
+import sys
+import urllib.request
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .config import configs, load_yaml_with_includes
+from .denoiser import MaskDiT
+from .sampler import inference
+from .scheduler import DDIMScheduler
+
+MAX_SEED = np.iinfo(np.int32).max
+
+
+class EzAudio:
+    def __init__(self, model_name, ckpt_path=None, vae_path=None, device='cuda',
+                 autoencoder=None, tokenizer=None, text_encoder=None, state_dict=None):
+        self.device = device
+        config_name = configs[model_name]['config']
+        if ckpt_path is None and state_dict is None:
+            ckpt_path = self.download_ckpt(configs[model_name])
+        if vae_path is None and autoencoder is None:
+            vae_path = self.download_ckpt(configs['vae'])
+        (self.autoencoder, self.unet, self.tokenizer, self.text_encoder, self.noise_scheduler,
+         self.params) = self.load_models(config_name, ckpt_path, vae_path, device, autoencoder, tokenizer,
+                                         text_encoder, state_dict)
+
+    def download_ckpt(self, model_dict):
+        """api/ezaudio.py:44-65."""
+        local_path = Path(model_dict['path'])
+        url = model_dict['url']
+        local_path.parent.mkdir(parents=True, exist_ok=True)
+        if not local_path.exists() and url:
+            print(f"Downloading from {url} to {local_path}...")
+
+            def progress_bar(block_num, block_size, total_size):
+                sys.stdout.write(f"\rProgress: {block_num * block_size / total_size * 100:.2f}%")
+                sys.stdout.flush()
+            try:
+                urllib.request.urlretrieve(url, local_path, reporthook=progress_bar)
+                print(f"Downloaded checkpoint to {local_path}")
+            except Exception as e:  # the reference prints and continues; torch.load then fails
+                print(f"Error downloading checkpoint: {e}")
+        else:
+            print(f"Checkpoint already exists at {local_path}")
+        return local_path
+
+    def load_models(self, config_name, ckpt_path, vae_path, device, autoencoder=None, tokenizer=None,
+                    text_encoder=None, state_dict=None):
+        """api/ezaudio.py:68-99."""
+        params = load_yaml_with_includes(config_name)
+        if autoencoder is None:
+            raise NotImplementedError(
+                'the Oobleck VAE decoder is not built yet (SURVEY.md section 8f row 1): pass autoencoder=<callable '
+                'with the reference Autoencoder surface (embedding=z -> wav, audio=wav -> z)>')
+        if tokenizer is None or text_encoder is None:
+            from transformers import T5EncoderModel, T5Tokenizer
+            tokenizer = T5Tokenizer.from_pretrained(params['text_encoder']['model'])
+            text_encoder = T5EncoderModel.from_pretrained(params['text_encoder']['model']).to(device)
+            text_encoder.eval()
+        unet = MaskDiT(device=device, **params['model'])
+        if state_dict is None:
+            state_dict = torch.load(ckpt_path, map_location='cpu')['model']
+        unet.load_state_dict(state_dict)
+        unet.eval()
+        noise_scheduler = DDIMScheduler(**params['diff'])
+        return autoencoder, unet, tokenizer, text_encoder, noise_scheduler, params
+
+    def generate_audio(self, text, length=10, guidance_scale=5, guidance_rescale=0.75, ddim_steps=100, eta=1,
+                       random_seed=None, randomize_seed=False):
+        """api/ezaudio.py:101-130.  `text` may also be a list of prompts (batched extension): the result is then
+        an array [N, T]."""
+        neg_text = None
+        length = length * self.params['autoencoder']['latent_sr']
+        gt, gt_mask = None, None
+        if text == '':
+            guidance_scale = None
+            print('empyt input')
+        if randomize_seed:
+            random_seed = random.randint(0, MAX_SEED)
+        pred = inference(self.autoencoder, self.unet, gt, gt_mask, self.tokenizer, self.text_encoder, self.params,
+                         self.noise_scheduler, text, neg_text, length, guidance_scale, guidance_rescale, ddim_steps,
+                         eta, random_seed, self.device)
+        pred = pred.cpu().numpy()
+        pred = pred.squeeze(0).squeeze(0) if isinstance(text, str) or len(text) == 1 else pred.squeeze(1)
+        return self.params['autoencoder']['sr'], pred
+
+    def editing_audio(self, text, boundary, gt_file, mask_start, mask_length, guidance_scale=3.5, guidance_rescale=0,
+                      ddim_steps=100, eta=1, random_seed=None, randomize_seed=False):
+        """api/ezaudio.py:132-207 (crop / pad / mask bookkeeping on the host, sampling on the GPU)."""
+        import librosa
+        neg_text = None
+        if text == '':
+            guidance_scale = None
+            print('empyt input')
+        sr = self.params['autoencoder']['sr']
+        latent_sr = self.params['autoencoder']['latent_sr']
+        mask_end = mask_start + mask_length
+        gt, _ = librosa.load(gt_file, sr=sr)
+        gt = gt / (np.max(np.abs(gt)) + 1e-9)
+        audio_length = len(gt) / sr
+        mask_start = min(mask_start, audio_length)
+        if mask_end > audio_length:  # out-padding mode
+            gt = np.pad(gt, (0, round((mask_end - audio_length) * sr)), 'constant')
+            audio_length = len(gt) / sr
+        output_audio = gt.copy()
+        gt = torch.tensor(gt).unsqueeze(0).unsqueeze(1).to(self.device)
+        boundary = min((mask_end - mask_start) / 2, boundary)
+        start_idx = max(mask_start - boundary, 0)
+        end_idx = min(mask_end + boundary, audio_length)
+        mask_start -= start_idx
+        mask_end -= start_idx
+        gt = gt[:, :, round(start_idx * sr):round(end_idx * sr)]
+        gt_latent = self.autoencoder(audio=gt)
+        B, D, L = gt_latent.shape
+        gt_mask = torch.zeros(B, D, L).to(self.device)
+        gt_mask[:, :, round(mask_start * latent_sr): round(mask_end * latent_sr)] = 1
+        gt_mask = gt_mask.bool()
+        if randomize_seed:
+            random_seed = random.randint(0, MAX_SEED)
+        pred = inference(self.autoencoder, self.unet, gt_latent, gt_mask, self.tokenizer, self.text_encoder,
+                         self.params, self.noise_scheduler, text, neg_text, L, guidance_scale, guidance_rescale,
+                         ddim_steps, eta, random_seed, self.device)
+        pred = pred.cpu().numpy().squeeze(0).squeeze(0)
+        chunk_length = end_idx - start_idx
+        pred = pred[:round(chunk_length * sr)]
+        output_audio[round(start_idx * sr):round(end_idx * sr)] = pred
+        return sr, output_audio

@@ -1,0 +1,770 @@
+// C ABI of libezaudio_hip.so (include/ezdit.h): parameter layout, workspace carving, and the host-side
+// sequencing of the denoising step.  The sequencing restates UDiT.forward (src/models/udit.py:281-362),
+// DiTBlock._forward (src/models/blocks.py:120-160) and the sampler loop body (src/inference.py:70-100)
+// as a fixed chain of asynchronous kernel launches on one stream (hipGraph-capturable: no allocation, no
+// sync, no host read-back anywhere below ezdit_forward / ezdit_sampler_run).
+#include "../../include/ezdit.h"
+#include "common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return fail(EZDIT_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline long rup(long x, long a) { return (x + a - 1) / a * a; }
+
+struct Buf {  // one carved workspace region
+    size_t off = 0, bytes = 0;
+};
+
+}  // namespace
+
+struct ezdit_handle {
+    ezdit_config cfg;
+    int D, H, dh, nblk, nhalf, I, C, Cin, Cctx, r6;
+    int DQK, DV;       // padded head dims used by the attention layouts
+    int ldD, ld2D, ldI, ldPE, ldCtx;  // bf16 leading dimensions (multiples of 64)
+    float scaling;
+
+    std::vector<ezdit_param_info_t> params;
+    std::map<std::string, int> pidx;
+    size_t param_bytes = 0;
+    const char* wblob = nullptr;
+
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int B = 0, L = 0, Lc = 0, n_slots = 0, M = 0, Mp = 0, Lp = 0, Lcp = 0, Mc = 0;
+    std::map<std::string, Buf> bufs;
+    bool ctx_ready = false, ts_ready = false;
+    int n_ts = 0, per_row = 0;
+
+    // sampler
+    float* latents = nullptr;
+    const float* noise = nullptr;
+    const float* s_gt = nullptr;
+    const uint8_t* s_gt_mask = nullptr;
+    int P = 0, n_steps = 0;
+    float gscale = 0.f, grescale = 0.f;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+
+    int launches = 0;
+    int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
+
+    template <typename T>
+    const T* w(const std::string& name) const {
+        auto it = pidx.find(name);
+        if (it == pidx.end()) {
+            fprintf(stderr, "ezdit: unknown parameter slot %s\n", name.c_str());
+            abort();
+        }
+        return reinterpret_cast<const T*>(wblob + params[it->second].offset);
+    }
+    int pld(const std::string& name) const { return (int)params[pidx.at(name)].ld; }
+    template <typename T>
+    T* buf(const std::string& name) const {
+        return reinterpret_cast<T*>(ws + bufs.at(name).off);
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// parameter layout
+// ------------------------------------------------------------------------------------------------------
+void add_param(ezdit_handle* h, const std::string& name, std::vector<std::string> srcs, int dtype, long rows, long cols,
+               int transform = EZDIT_T_NONE) {
+    ezdit_param_info_t p;
+    memset(&p, 0, sizeof p);
+    snprintf(p.name, sizeof p.name, "%s", name.c_str());
+    p.nsrc = (int)srcs.size();
+    for (int i = 0; i < p.nsrc; ++i) snprintf(p.src[i], sizeof p.src[i], "%s", srcs[i].c_str());
+    p.dtype = dtype;
+    p.transform = transform;
+    p.rows = rows;
+    p.cols = cols;
+    if (dtype == EZDIT_P_BF16) {
+        p.rows_pad = rup(rows, 128);
+        p.ld = rup(cols, 64);
+    } else {
+        p.rows_pad = rows;
+        p.ld = cols;
+    }
+    p.offset = (int64_t)h->param_bytes;
+    const size_t bytes = (size_t)p.rows_pad * p.ld * (dtype == EZDIT_P_BF16 ? 2 : 4);
+    h->param_bytes += rup((long)bytes, 256);
+    h->pidx[name] = (int)h->params.size();
+    h->params.push_back(p);
+}
+
+std::string blk_prefix(const ezdit_handle* h, int b) {
+    char s[64];
+    if (b < h->nhalf) snprintf(s, sizeof s, "model.in_blocks.%d", b);
+    else if (b == h->nhalf) snprintf(s, sizeof s, "model.mid_block");
+    else snprintf(s, sizeof s, "model.out_blocks.%d", b - h->nhalf - 1);
+    return s;
+}
+std::string bn(int b, const char* k) {
+    char s[64];
+    snprintf(s, sizeof s, "blk%d.%s", b, k);
+    return s;
+}
+
+void build_params(ezdit_handle* h) {
+    const long D = h->D, C = h->C, I = h->I, dh = h->dh, r6 = h->r6;
+    const int F = EZDIT_P_F32, Bf = EZDIT_P_BF16;
+    add_param(h, "mask_embed", {"mask_embed"}, F, 1, C);
+    add_param(h, "pe.w", {"model.patch_embed.proj.weight"}, Bf, D, h->Cin);
+    add_param(h, "pe.b", {"model.patch_embed.proj.bias"}, F, 1, D);
+    add_param(h, "te.w1", {"model.time_embed.mlp.0.weight"}, F, D, 256);
+    add_param(h, "te.b1", {"model.time_embed.mlp.0.bias"}, F, 1, D);
+    add_param(h, "te.w2", {"model.time_embed.mlp.2.weight"}, F, D, D);
+    add_param(h, "te.b2", {"model.time_embed.mlp.2.bias"}, F, 1, D);
+    add_param(h, "ada.w", {"model.time_ada.weight"}, F, 6 * D, D);
+    add_param(h, "ada.b", {"model.time_ada.bias"}, F, 1, 6 * D);
+    add_param(h, "adaf.w", {"model.time_ada_final.weight"}, F, 2 * D, D);
+    add_param(h, "adaf.b", {"model.time_ada_final.bias"}, F, 1, 2 * D);
+    add_param(h, "ce.w1", {"model.context_embed.0.weight"}, Bf, D, h->Cctx);
+    add_param(h, "ce.b1", {"model.context_embed.0.bias"}, F, 1, D);
+    add_param(h, "ce.w2", {"model.context_embed.2.weight"}, Bf, D, D);
+    add_param(h, "ce.b2", {"model.context_embed.2.bias"}, F, 1, D);
+    add_param(h, "fin.nw", {"model.final_block.norm.weight"}, F, 1, D);
+    add_param(h, "fin.nb", {"model.final_block.norm.bias"}, F, 1, D);
+    add_param(h, "fin.w", {"model.final_block.linear.weight"}, Bf, C, D);
+    add_param(h, "fin.b", {"model.final_block.linear.bias"}, F, 1, C);
+    add_param(h, "fin.cw", {"model.final_block.final_layer.weight"}, F, C, C * 3);
+    add_param(h, "fin.cb", {"model.final_block.final_layer.bias"}, F, 1, C);
+    // per-block parameters, kind-major so that one kind is a constant-stride array over blocks
+    struct V { const char* name; const char* key; long n; };
+    const V vecs[] = {
+        {"n1w", "norm1.weight", D}, {"n1b", "norm1.bias", D}, {"n2w", "norm2.weight", D}, {"n2b", "norm2.bias", D},
+        {"n3w", "norm3.weight", D}, {"n3b", "norm3.bias", D}, {"ncw", "norm_context.weight", D},
+        {"ncb", "norm_context.bias", D},
+        {"a.qnw", "attn.norm_q.weight", dh}, {"a.qnb", "attn.norm_q.bias", dh}, {"a.knw", "attn.norm_k.weight", dh},
+        {"a.knb", "attn.norm_k.bias", dh}, {"c.qnw", "cross_attn.norm_q.weight", dh},
+        {"c.qnb", "cross_attn.norm_q.bias", dh}, {"c.knw", "cross_attn.norm_k.weight", dh},
+        {"c.knb", "cross_attn.norm_k.bias", dh},
+        {"bo", "attn.proj.bias", D}, {"bo2", "cross_attn.proj.bias", D}, {"b2", "mlp.net.2.bias", D},
+        {"table", "adaln.scale_shift_table", 6 * D},
+    };
+    for (const V& v : vecs)
+        for (int b = 0; b < h->nblk; ++b) add_param(h, bn(b, v.name), {blk_prefix(h, b) + "." + v.key}, F, 1, v.n);
+    for (int b = 0; b < h->nblk; ++b) {
+        const std::string p = blk_prefix(h, b);
+        add_param(h, bn(b, "b1"), {p + ".mlp.net.0.proj.bias"}, F, 1, 2 * I, EZDIT_T_GEGLU32);
+        add_param(h, bn(b, "lora_a"), {p + ".adaln.lora_a.weight"}, F, r6, D);
+        add_param(h, bn(b, "lora_b"), {p + ".adaln.lora_b.weight"}, F, 6 * D, r6);
+        add_param(h, bn(b, "wqkv"), {p + ".attn.to_q.weight", p + ".attn.to_k.weight", p + ".attn.to_v.weight"}, Bf, 3 * D, D);
+        add_param(h, bn(b, "wo"), {p + ".attn.proj.weight"}, Bf, D, D);
+        add_param(h, bn(b, "wq2"), {p + ".cross_attn.to_q.weight"}, Bf, D, D);
+        add_param(h, bn(b, "wkv2"), {p + ".cross_attn.to_k.weight", p + ".cross_attn.to_v.weight"}, Bf, 2 * D, D);
+        add_param(h, bn(b, "wo2"), {p + ".cross_attn.proj.weight"}, Bf, D, D);
+        add_param(h, bn(b, "w1"), {p + ".mlp.net.0.proj.weight"}, Bf, 2 * I, D, EZDIT_T_GEGLU32);
+        add_param(h, bn(b, "w2"), {p + ".mlp.net.2.weight"}, Bf, D, I);
+        if (b > h->nhalf) {
+            add_param(h, bn(b, "snw"), {p + ".skip_norm.weight"}, F, 1, 2 * D);
+            add_param(h, bn(b, "snb"), {p + ".skip_norm.bias"}, F, 1, 2 * D);
+            add_param(h, bn(b, "wskip"), {p + ".skip_linear.weight"}, Bf, D, 2 * D);
+            add_param(h, bn(b, "bskip"), {p + ".skip_linear.bias"}, F, 1, D);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------------
+size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<std::string, Buf>* out) {
+    size_t off = 0;
+    auto add = [&](const char* name, size_t bytes) {
+        Buf b;
+        b.off = off;
+        b.bytes = bytes;
+        if (out) (*out)[name] = b;
+        off += (size_t)rup((long)bytes, 256);
+    };
+    const long D = h->D, I = h->I, C = h->C, H = h->H;
+    const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 32), Lcp = rup(Lc, 32);
+    const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
+    const int nblk = h->nblk;
+    add("ints", 256 * sizeof(int));                       // [0] cur_step, [16..] row_slot (<= 240 rows)
+    add("rope_cos", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
+    add("rope_sin", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
+    add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
+    add("ape", Mp * h->ldPE * 2);
+    add("h", Mp * D * 4);
+    add("skips", (size_t)h->nhalf * Mp * D * 4);
+    add("u", Mp * h->ld2D * 2);
+    add("qkv", Mp * 3 * D * 4);
+    add("q", (size_t)B * H * Lp * h->DQK * 2);
+    add("k", (size_t)B * H * Lp * h->DQK * 2);
+    add("vt", (size_t)B * H * h->DV * Lp * 2);
+    add("ao", Mp * h->ldD * 2);
+    add("act", Mp * h->ldI * 2);
+    add("part", (size_t)8 * Mp * D * 4);
+    add("y", Mp * C * 4);
+    add("pred", (size_t)B * C * L * 4);
+    // context (step invariant)
+    add("kmask", rup(Mc, 256));
+    add("ctx_bf", Mcp * h->ldCtx * 2);
+    add("c1", Mcp * D * 4);
+    add("c1b", Mcp * h->ldD * 2);
+    add("c2", Mcp * D * 4);
+    add("cu", Mcp * h->ldD * 2);
+    add("ckv", Mcp * 2 * D * 4);
+    add("kc", (size_t)nblk * B * H * Lcp * h->DQK * 2);
+    add("vct", (size_t)nblk * B * H * h->DV * Lcp * 2);
+    // time path
+    const long ns = n_slots > 0 ? n_slots : 1;
+    add("ts", ns * 4);
+    add("t1", ns * D * 4);
+    add("tt", ns * D * 4);
+    add("ada", ns * 6 * D * 4);
+    add("adaf", ns * 2 * D * 4);
+    add("la", ns * h->r6 * 4);
+    add("lora", ns * nblk * 6 * D * 4);
+    add("mod", ns * nblk * 6 * D * 4);
+    add("modf", ns * 2 * D * 4);
+    return off;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------------
+struct Ctx {
+    ezdit_handle* h;
+    hipStream_t st;
+};
+
+void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const float* bias, void* out, int ldo, int M, int N,
+          int epi, int tile, int splitk = 1, long slab = 0) {
+    ezdit_handle* h = c.h;
+    GemmArgs g;
+    g.A = A;
+    g.lda = lda;
+    g.W = h->w<bf16_t>(wname);
+    g.ldw = h->pld(wname);
+    g.bias = bias;
+    g.out = out;
+    g.ldo = ldo;
+    g.slab_stride = slab;
+    g.M = M;
+    g.N = N;
+    g.K = g.ldw;
+    g.splitk = splitk;
+    g.epi = epi;
+    g.tile = tile;
+    launch_gemm(g, c.st);
+    h->launches++;
+}
+
+int pick_splitk(int M, int N, int K) {
+    const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
+    const int nk = K / 64;
+    int s = 512 / (tiles > 0 ? tiles : 1);
+    if (s > nk / 6) s = nk / 6;
+    if (s > 8) s = 8;
+    if (s < 1) s = 1;
+    return s;
+}
+
+// residual GEMM: part = A . W^T as split-K slabs (reduced by the row kernel that follows)
+int gemm_partial(Ctx& c, const bf16_t* A, int lda, const std::string& wname, int M, int N) {
+    ezdit_handle* h = c.h;
+    const int K = h->pld(wname);
+    const int s = pick_splitk(M, N, K);
+    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, 1, s, (long)h->Mp * h->D);
+    return s;
+}
+
+}  // namespace
+
+// ======================================================================================================
+extern "C" {
+
+int ezdit_abi_version(void) { return EZDIT_ABI_VERSION; }
+const char* ezdit_last_error(void) { return g_err.c_str(); }
+
+int ezdit_create(const ezdit_config* cfg, ezdit_handle** out) {
+    if (!cfg || !out) return fail(EZDIT_E_INVALID, "null argument");
+    if (cfg->embed_dim <= 0 || cfg->num_heads <= 0 || cfg->embed_dim % cfg->num_heads)
+        return fail(EZDIT_E_INVALID, "embed_dim %d not divisible by num_heads %d", cfg->embed_dim, cfg->num_heads);
+    const int dh = cfg->embed_dim / cfg->num_heads;
+    if (dh != 64 && dh != 72) return fail(EZDIT_E_UNSUPPORTED, "head_dim %d: only 64 and 72 are implemented", dh);
+    if (cfg->embed_dim > 1280 || cfg->embed_dim % 4) return fail(EZDIT_E_UNSUPPORTED, "embed_dim %d > 1280", cfg->embed_dim);
+    if (cfg->in_chans != 2 * cfg->out_chans + 1)
+        return fail(EZDIT_E_UNSUPPORTED, "in_chans %d != 2*out_chans+1 (MaskDiT concat)", cfg->in_chans);
+    if (cfg->depth < 2 || cfg->depth % 2) return fail(EZDIT_E_UNSUPPORTED, "depth %d must be even", cfg->depth);
+    if (cfg->mlp_ratio != 4.0f) return fail(EZDIT_E_UNSUPPORTED, "mlp_ratio %g", (double)cfg->mlp_ratio);
+    ezdit_handle* h = new ezdit_handle();
+    h->cfg = *cfg;
+    if (h->cfg.max_len <= 0) h->cfg.max_len = 2048;
+    h->D = cfg->embed_dim;
+    h->H = cfg->num_heads;
+    h->dh = dh;
+    h->nhalf = cfg->depth / 2;
+    h->nblk = cfg->depth + 1;
+    h->I = (int)(cfg->embed_dim * cfg->mlp_ratio);
+    h->C = cfg->out_chans;
+    h->Cin = cfg->in_chans;
+    h->Cctx = cfg->context_dim;
+    h->r6 = 6 * cfg->ada_sola_rank;
+    h->scaling = cfg->ada_sola_alpha / (float)cfg->ada_sola_rank;
+    h->DQK = dh == 64 ? 64 : 80;
+    h->DV = dh == 64 ? 64 : 96;
+    h->ldD = (int)rup(h->D, 64);
+    h->ld2D = (int)rup(2 * h->D, 64);
+    h->ldI = (int)rup(h->I, 64);
+    h->ldPE = (int)rup(h->Cin, 64);
+    h->ldCtx = (int)rup(h->Cctx, 64);
+    build_params(h);
+    *out = h;
+    return EZDIT_OK;
+}
+
+int ezdit_destroy(ezdit_handle* h) {
+    if (!h) return EZDIT_OK;
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    delete h;
+    return EZDIT_OK;
+}
+
+int ezdit_param_count(const ezdit_handle* h) { return h ? (int)h->params.size() : 0; }
+int ezdit_param_info(const ezdit_handle* h, int i, ezdit_param_info_t* out) {
+    if (!h || !out || i < 0 || i >= (int)h->params.size()) return fail(EZDIT_E_INVALID, "bad parameter index %d", i);
+    *out = h->params[i];
+    return EZDIT_OK;
+}
+size_t ezdit_param_bytes(const ezdit_handle* h) { return h ? h->param_bytes : 0; }
+
+int ezdit_bind_weights(ezdit_handle* h, const void* blob, size_t bytes) {
+    if (!h || !blob) return fail(EZDIT_E_INVALID, "null argument");
+    if (bytes < h->param_bytes) return fail(EZDIT_E_INVALID, "weight blob %zu < required %zu bytes", bytes, h->param_bytes);
+    h->wblob = reinterpret_cast<const char*>(blob);
+    h->ctx_ready = h->ts_ready = false;
+    return EZDIT_OK;
+}
+
+size_t ezdit_workspace_bytes(const ezdit_handle* h, int B, int L, int Lc, int n_slots) {
+    if (!h || B <= 0 || L <= 0 || Lc <= 0) return 0;
+    return carve(h, B, L, Lc, n_slots, nullptr);
+}
+
+int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, int Lc, int n_slots, ezdit_stream stream) {
+    if (!h || !ws) return fail(EZDIT_E_INVALID, "null argument");
+    if (B <= 0 || B > 240 || L <= 0 || Lc <= 0) return fail(EZDIT_E_INVALID, "bad shape B=%d L=%d Lc=%d", B, L, Lc);
+    if (L > h->cfg.max_len) return fail(EZDIT_E_INVALID, "L=%d exceeds max_len=%d", L, h->cfg.max_len);
+    std::map<std::string, Buf> bufs;
+    const size_t need = carve(h, B, L, Lc, n_slots, &bufs);
+    if (bytes < need) return fail(EZDIT_E_INVALID, "workspace %zu < required %zu bytes", bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    h->ws = reinterpret_cast<char*>(ws);
+    h->ws_bytes = bytes;
+    h->bufs = bufs;
+    h->B = B; h->L = L; h->Lc = Lc; h->n_slots = n_slots > 0 ? n_slots : 1;
+    h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 32); h->Lcp = (int)rup(Lc, 32);
+    h->Mc = B * Lc;
+    h->ctx_ready = h->ts_ready = false;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    // zero everything once: all padding rows / columns / keys stay zero for the lifetime of the binding
+    HIPCHK(hipMemsetAsync(ws, 0, need, st));
+    launch_rope_table(h->buf<float>("rope_cos"), h->buf<float>("rope_sin"), h->cfg.max_len, h->dh, st);
+    return EZDIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask, ezdit_stream stream) {
+    if (!h || !ctx) return fail(EZDIT_E_INVALID, "null argument");
+    if (!h->wblob || !h->ws) return fail(EZDIT_E_STATE, "bind weights and workspace first");
+    Ctx c{h, (hipStream_t)stream};
+    const int Mc = h->Mc, D = h->D;
+    uint8_t* km = h->buf<uint8_t>("kmask");
+    if (mask) HIPCHK(hipMemcpyAsync(km, mask, Mc, hipMemcpyDeviceToDevice, c.st));
+    else HIPCHK(hipMemsetAsync(km, 1, Mc, c.st));
+    // context_embed: Linear -> SiLU -> Linear  (udit.py:94-97)
+    launch_cast_bf16(ctx, h->Cctx, h->buf<bf16_t>("ctx_bf"), h->ldCtx, Mc, h->Cctx, 0, c.st);
+    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, "ce.w1", h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, 1);
+    launch_cast_bf16(h->buf<float>("c1"), D, h->buf<bf16_t>("c1b"), h->ldD, Mc, D, 1, c.st);
+    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, "ce.w2", h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, 1);
+    for (int b = 0; b < h->nblk; ++b) {
+        // norm_context (blocks.py:150) -> to_k / to_v -> head LayerNorm on k (attention.py:128-142)
+        RowArgs r;
+        memset(&r, 0, sizeof r);
+        r.h_in = h->buf<float>("c2");
+        r.mode = 0;
+        r.ln_g = h->w<float>(bn(b, "ncw"));
+        r.ln_c = h->w<float>(bn(b, "ncb"));
+        r.u = h->buf<bf16_t>("cu");
+        r.ld_u = h->ldD;
+        r.M = Mc; r.D = D; r.L = h->Lc;
+        launch_row(r, c.st);
+        gemm(c, h->buf<bf16_t>("cu"), h->ldD, bn(b, "wkv2"), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, 0);
+        HeadNormArgs hn;
+        memset(&hn, 0, sizeof hn);
+        hn.x = h->buf<float>("ckv"); hn.ldx = 2 * D;
+        hn.q_col = -1; hn.k_col = 0; hn.v_col = D;
+        hn.kn_w = h->w<float>(bn(b, "c.knw")); hn.kn_b = h->w<float>(bn(b, "c.knb"));
+        hn.k = h->buf<bf16_t>("kc") + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
+        hn.vt = h->buf<bf16_t>("vct") + (size_t)b * h->B * h->H * h->DV * h->Lcp;
+        hn.B = h->B; hn.H = h->H; hn.L = h->Lc; hn.Lp = h->Lcp; hn.dh = h->dh;
+        launch_headnorm(hn, c.st);
+    }
+    h->ctx_ready = true;
+    return EZDIT_OK;
+}
+
+int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_row, ezdit_stream stream) {
+    if (!h || !ts) return fail(EZDIT_E_INVALID, "null argument");
+    if (!h->wblob || !h->ws) return fail(EZDIT_E_STATE, "bind weights and workspace first");
+    if (n <= 0 || n > h->n_slots) return fail(EZDIT_E_INVALID, "n=%d timesteps but workspace holds %d slots", n, h->n_slots);
+    if (per_row && n != h->B) return fail(EZDIT_E_INVALID, "per_row needs n == B (%d != %d)", n, h->B);
+    hipStream_t st = (hipStream_t)stream;
+    const int D = h->D, nblk = h->nblk;
+    int* ints = h->buf<int>("ints");
+    HIPCHK(hipMemcpyAsync(h->buf<int>("ts"), ts, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    std::vector<int> rs(240, 0);
+    if (per_row) for (int b = 0; b < h->B; ++b) rs[b] = b;
+    HIPCHK(hipMemcpyAsync(ints + 16, rs.data(), 240 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));  // rs is a stack/heap temporary; prepare is not on the per-step path
+    launch_set_int(ints, 0, 0, st);
+    // TimestepEmbedder + time_act (modules.py:50-60, udit.py:313)
+    launch_linear_f32(nullptr, h->buf<int>("ts"), 1, h->w<float>("te.w1"), h->w<float>("te.b1"), h->buf<float>("t1"), n, D, 256, 1, D, st);
+    launch_linear_f32(h->buf<float>("t1"), nullptr, 0, h->w<float>("te.w2"), h->w<float>("te.b2"), h->buf<float>("tt"), n, D, D, 1, D, st);
+    launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>("ada.w"), h->w<float>("ada.b"), h->buf<float>("ada"), n, 6 * D, D, 0, 6 * D, st);
+    launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>("adaf.w"), h->w<float>("adaf.b"), h->buf<float>("adaf"), n, 2 * D, D, 0, 2 * D, st);
+    for (int b = 0; b < nblk; ++b) {
+        launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>(bn(b, "lora_a")), nullptr, h->buf<float>("la"), n, h->r6, D, 0, h->r6, st);
+        launch_linear_f32(h->buf<float>("la"), nullptr, 0, h->w<float>(bn(b, "lora_b")), nullptr,
+                          h->buf<float>("lora") + (size_t)b * 6 * D, n, 6 * D, h->r6, 0, (long)nblk * 6 * D, st);
+    }
+    ModFinalizeArgs m;
+    memset(&m, 0, sizeof m);
+    m.ada = h->buf<float>("ada");
+    m.lora = h->buf<float>("lora");
+    m.scaling = h->scaling;
+    m.table = h->w<float>(bn(0, "table"));
+    m.table_stride = nblk > 1 ? (h->w<float>(bn(1, "table")) - h->w<float>(bn(0, "table"))) : 0;
+    m.n1w = h->w<float>(bn(0, "n1w")); m.n1b = h->w<float>(bn(0, "n1b"));
+    m.n3w = h->w<float>(bn(0, "n3w")); m.n3b = h->w<float>(bn(0, "n3b"));
+    m.norm_stride = nblk > 1 ? (h->w<float>(bn(1, "n1w")) - h->w<float>(bn(0, "n1w"))) : 0;
+    m.mod = h->buf<float>("mod");
+    m.ada_final = h->buf<float>("adaf");
+    m.nfw = h->w<float>("fin.nw"); m.nfb = h->w<float>("fin.nb");
+    m.mod_final = h->buf<float>("modf");
+    m.n = n; m.nblk = nblk; m.D = D;
+    launch_mod_finalize(m, st);
+    h->ts_ready = true;
+    h->n_ts = n;
+    h->per_row = per_row;
+    return EZDIT_OK;
+}
+
+int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream) {
+    if (!h || !h->ws) return fail(EZDIT_E_STATE, "bind workspace first");
+    if (step < 0 || step >= h->n_slots) return fail(EZDIT_E_INVALID, "step %d out of range", step);
+    launch_set_int(h->buf<int>("ints"), step, 0, (hipStream_t)stream);
+    return EZDIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
+                        const float* const* cn, int n_cn, float* out, hipStream_t st) {
+    Ctx c{h, st};
+    const int D = h->D, M = h->M, nblk = h->nblk, nhalf = h->nhalf, Mp = h->Mp;
+    const int* cur = h->buf<int>("ints");
+    const int* row_slot = h->per_row ? cur + 16 : nullptr;
+    float* hA = h->buf<float>("h");
+    float* skips = h->buf<float>("skips");
+    bf16_t* u = h->buf<bf16_t>("u");
+    float* part = h->buf<float>("part");
+    const float* mod = h->buf<float>("mod");
+    const long mod_slot = (long)nblk * 6 * D;
+    h->launches = 0;
+#define STOPCHK() do { if (h->debug_stop > 0 && h->launches >= h->debug_stop) return EZDIT_OK; } while (0)
+
+    // A4 + A5: input assembly and patch embed (Conv1d k=1 == per-token Linear)
+    AssembleArgs as;
+    as.x = x; as.x_rows = x_rows; as.in_ch = in_ch;
+    as.gt = gt; as.gt_mask = gt_mask; as.mask_embed = h->w<float>("mask_embed");
+    as.out = h->buf<bf16_t>("ape"); as.ldo = h->ldPE;
+    as.B = h->B; as.C = h->C; as.L = h->L;
+    STOPCHK();
+    launch_assemble(as, st);
+    h->launches++;
+    STOPCHK();
+    gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, 1);
+
+    auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
+                   long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
+                   int ld_u) {
+        RowArgs r;
+        memset(&r, 0, sizeof r);
+        r.h_in = h_in; r.h_out = h_out;
+        r.part = part; r.nsplit = nsplit; r.part_stride = (long)Mp * D; r.ld_part = D;
+        r.bias = bias; r.gate = gate; r.gate_slot_stride = gate_stride; r.mode = mode;
+        r.ln_g = lg; r.ln_c = lc; r.ln_slot_stride = ln_stride;
+        r.skip = skip; r.cn = cnp;
+        r.u = u; r.ld_u = ld_u;
+        r.M = M; r.D = D; r.L = h->L;
+        r.cur_step = cur; r.row_slot = row_slot;
+        launch_row(r, st);
+        h->launches++;
+    };
+    auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
+
+    // LN1 of block 0 on the patch embedding
+    STOPCHK();
+    row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
+    const float* hcur = hA;
+
+    for (int b = 0; b < nblk; ++b) {
+        const bool is_in = b < nhalf, is_out = b > nhalf;
+        if (is_out) {
+            // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
+            STOPCHK();
+            const int s = gemm_partial(c, u, h->ld2D, bn(b, "wskip"), M, D);
+            STOPCHK();
+            row(2, nullptr, hA, s, h->w<float>(bn(b, "bskip")), nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
+            hcur = hA;
+        }
+        // ---- self attention (blocks.py:136-141) ----
+        STOPCHK();
+        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32, 0);
+        HeadNormArgs hn;
+        memset(&hn, 0, sizeof hn);
+        hn.x = h->buf<float>("qkv"); hn.ldx = 3 * D;
+        hn.q_col = 0; hn.k_col = D; hn.v_col = 2 * D;
+        hn.qn_w = h->w<float>(bn(b, "a.qnw")); hn.qn_b = h->w<float>(bn(b, "a.qnb"));
+        hn.kn_w = h->w<float>(bn(b, "a.knw")); hn.kn_b = h->w<float>(bn(b, "a.knb"));
+        hn.rope_cos = h->buf<float>("rope_cos"); hn.rope_sin = h->buf<float>("rope_sin");
+        hn.q = h->buf<bf16_t>("q"); hn.k = h->buf<bf16_t>("k"); hn.vt = h->buf<bf16_t>("vt");
+        hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
+        STOPCHK();
+        launch_headnorm(hn, st);
+        h->launches += 2;
+        AttnArgs at;
+        at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
+        at.out = h->buf<bf16_t>("ao"); at.ldo = h->ldD;
+        at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
+        STOPCHK();
+        launch_attention(at, st);
+        h->launches++;
+        STOPCHK();
+        int s = gemm_partial(c, at.out, h->ldD, bn(b, "wo"), M, D);
+        // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
+        STOPCHK();
+        row(1, hcur, hA, s, h->w<float>(bn(b, "bo")), modv(b, 2), mod_slot, h->w<float>(bn(b, "n2w")), h->w<float>(bn(b, "n2b")), 0,
+            nullptr, nullptr, h->ldD);
+        hcur = hA;
+        // ---- cross attention (blocks.py:147-151) ----
+        STOPCHK();
+        gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, 1);
+        memset(&hn, 0, sizeof hn);
+        hn.x = h->buf<float>("qkv"); hn.ldx = D;
+        hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
+        hn.qn_w = h->w<float>(bn(b, "c.qnw")); hn.qn_b = h->w<float>(bn(b, "c.qnb"));
+        hn.q = h->buf<bf16_t>("q");
+        hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
+        STOPCHK();
+        launch_headnorm(hn, st);
+        h->launches++;
+        at.q = hn.q;
+        at.k = h->buf<bf16_t>("kc") + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
+        at.vt = h->buf<bf16_t>("vct") + (size_t)b * h->B * h->H * h->DV * h->Lcp;
+        at.kmask = h->buf<uint8_t>("kmask");
+        at.Lk = h->Lc; at.Lkp = h->Lcp;
+        STOPCHK();
+        launch_attention(at, st);
+        h->launches++;
+        STOPCHK();
+        s = gemm_partial(c, at.out, h->ldD, bn(b, "wo2"), M, D);
+        STOPCHK();
+        row(1, hA, hA, s, h->w<float>(bn(b, "bo2")), nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+        // ---- GEGLU MLP (blocks.py:154-156) ----
+        STOPCHK();
+        gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU, 0);
+        STOPCHK();
+        s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
+        // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
+        const float* b2 = h->w<float>(bn(b, "b2"));
+        if (b == nblk - 1) {
+            const float* mf = h->buf<float>("modf");
+            STOPCHK();
+            row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, mf, mf + D, 2L * D, nullptr, nullptr, h->ldD);
+        } else if (b + 1 > nhalf) {
+            const int j = b + 1 - nhalf - 1;  // out block index of the consumer
+            const float* skip = skips + (size_t)(nhalf - 1 - j) * Mp * D;
+            const float* cnp = (cn && n_cn > 0) ? cn[n_cn - 1 - j] : nullptr;
+            STOPCHK();
+            row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, h->w<float>(bn(b + 1, "snw")), h->w<float>(bn(b + 1, "snb")), 0, skip, cnp,
+                h->ld2D);
+        } else {
+            float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
+            STOPCHK();
+            row(1, hA, dst, s, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
+            hcur = dst;
+        }
+    }
+    // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
+    STOPCHK();
+    gemm(c, u, h->ldD, "fin.w", h->w<float>("fin.b"), h->buf<float>("y"), h->C, M, h->C, EPI_F32, 1);
+    FinalConvArgs fc;
+    fc.y = h->buf<float>("y"); fc.ldy = h->C;
+    fc.w = h->w<float>("fin.cw"); fc.b = h->w<float>("fin.cb");
+    fc.out = out; fc.B = h->B; fc.C = h->C; fc.L = h->L;
+    STOPCHK();
+    launch_final_conv(fc, st);
+    h->launches++;
+    return EZDIT_OK;
+}
+
+int ezdit_forward(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
+                  const float* const* cn_skips, int n_cn, float* out, ezdit_stream stream) {
+    if (!h || !x || !out) return fail(EZDIT_E_INVALID, "null argument");
+    if (!h->wblob || !h->ws) return fail(EZDIT_E_STATE, "bind weights and workspace first");
+    if (!h->ctx_ready) return fail(EZDIT_E_STATE, "ezdit_prepare_context has not run for this workspace");
+    if (!h->ts_ready) return fail(EZDIT_E_STATE, "ezdit_prepare_timesteps has not run for this workspace");
+    if (in_ch != h->C && in_ch != h->Cin) return fail(EZDIT_E_INVALID, "in_ch %d: expected %d or %d", in_ch, h->C, h->Cin);
+    if (in_ch == h->C && (x_rows <= 0 || h->B % x_rows)) return fail(EZDIT_E_INVALID, "x_rows %d does not divide B %d", x_rows, h->B);
+    if ((gt == nullptr) != (gt_mask == nullptr)) return fail(EZDIT_E_INVALID, "gt and gt_mask must be given together");
+    if (n_cn != 0 && n_cn != h->nhalf) return fail(EZDIT_E_INVALID, "n_cn %d: expected 0 or %d", n_cn, h->nhalf);
+    return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, cn_skips, n_cn, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noise, const ezdit_ddim_coef* coefs, int n_steps,
+                        float guidance_scale, float guidance_rescale, const float* gt, const uint8_t* gt_mask,
+                        ezdit_stream stream) {
+    if (!h || !latents || !coefs) return fail(EZDIT_E_INVALID, "null argument");
+    if (!h->ws || !h->wblob) return fail(EZDIT_E_STATE, "bind weights and workspace first");
+    if (n_steps <= 0 || n_steps > h->n_slots) return fail(EZDIT_E_INVALID, "n_steps %d > workspace slots %d", n_steps, h->n_slots);
+    const int needB = guidance_scale > 0.f ? 2 * P : P;
+    if (P <= 0 || needB != h->B) return fail(EZDIT_E_INVALID, "P=%d with guidance %g needs B=%d, workspace has B=%d", P, (double)guidance_scale, needB, h->B);
+    if ((gt == nullptr) != (gt_mask == nullptr)) return fail(EZDIT_E_INVALID, "gt and gt_mask must be given together");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> cf((size_t)n_steps * 8, 0.f);
+    for (int i = 0; i < n_steps; ++i) {
+        cf[i * 8 + 0] = coefs[i].sa; cf[i * 8 + 1] = coefs[i].sb; cf[i * 8 + 2] = coefs[i].c_x0;
+        cf[i * 8 + 3] = coefs[i].c_dir; cf[i * 8 + 4] = coefs[i].sigma;
+    }
+    HIPCHK(hipMemcpyAsync(h->buf<float>("coef"), cf.data(), cf.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    launch_set_int(h->buf<int>("ints"), 0, 0, st);
+    h->latents = latents; h->noise = noise; h->P = P; h->n_steps = n_steps;
+    h->gscale = guidance_scale; h->grescale = guidance_rescale;
+    h->s_gt = gt; h->s_gt_mask = gt_mask;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    return EZDIT_OK;
+}
+
+static int sampler_step(ezdit_handle* h, hipStream_t st) {
+    float* pred = h->buf<float>("pred");
+    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, pred, st);
+    if (rc) return rc;
+    CfgDdimArgs a;
+    a.pred = pred; a.latents = h->latents; a.noise = h->noise;
+    a.coef = h->buf<float>("coef"); a.cur_step = h->buf<int>("ints");
+    a.guidance_scale = h->gscale; a.guidance_rescale = h->grescale;
+    a.P = h->P; a.n = h->C * h->L;
+    launch_cfg_ddim(a, st);
+    launch_set_int(h->buf<int>("ints"), 1, 1, st);
+    h->launches += 2;
+    return EZDIT_OK;
+}
+
+int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream) {
+    if (!h || !h->latents) return fail(EZDIT_E_STATE, "ezdit_sampler_begin first");
+    if (!h->ctx_ready || !h->ts_ready) return fail(EZDIT_E_STATE, "prepare context and timesteps first");
+    if (h->per_row) return fail(EZDIT_E_STATE, "sampler needs ezdit_prepare_timesteps(per_row = 0)");
+    hipStream_t st = (hipStream_t)stream;
+    if (!use_graph) {
+        for (int i = 0; i < n; ++i) {
+            int rc = sampler_step(h, st);
+            if (rc) return rc;
+        }
+        return EZDIT_OK;
+    }
+    if (!h->graph_exec) {
+        if (st == nullptr) return fail(EZDIT_E_INVALID, "graph capture needs a non-default stream");
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int rc = sampler_step(h, st);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(EZDIT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        h->graph = g;
+        HIPCHK(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
+    }
+    for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(h->graph_exec, st));
+    return EZDIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
+                    int ldo, int M, int N, int K, int splitk, ezdit_stream stream) {
+    (void)h;
+    if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
+    g.slab_stride = (long)rup(M, 128) * ldo;
+    g.epi = variant / 2; g.tile = variant % 2;   // variant = epi * 2 + tile
+    if (g.epi == EPI_GEGLU && g.tile != 0) return fail(EZDIT_E_INVALID, "GEGLU epilogue uses the 128x128 tile");
+    if (g.epi != EPI_PARTIAL) g.splitk = 1;
+    launch_gemm(g, (hipStream_t)stream);
+    return EZDIT_OK;
+}
+
+int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const void* vt, const uint8_t* kmask, void* out, int B,
+                         int Lq, int Lk, int Lqp, int Lkp, ezdit_stream stream) {
+    if (!h) return fail(EZDIT_E_INVALID, "null handle");
+    AttnArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
+    a.out = (bf16_t*)out; a.ldo = h->ldD;
+    a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
+    launch_attention(a, (hipStream_t)stream);
+    return EZDIT_OK;
+}
+
+int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** ptr, size_t* bytes) {
+    if (!h || !h->ws || !name) return fail(EZDIT_E_STATE, "bind workspace first");
+    auto it = h->bufs.find(name);
+    if (it == h->bufs.end()) return fail(EZDIT_E_INVALID, "no workspace buffer named %s", name);
+    if (ptr) *ptr = h->ws + it->second.off;
+    if (bytes) *bytes = it->second.bytes;
+    return EZDIT_OK;
+}
+
+int ezdit_last_launch_count(const ezdit_handle* h) { return h ? h->launches : 0; }
+int ezdit_debug_stop_after(ezdit_handle* h, int n) {
+    if (!h) return fail(EZDIT_E_INVALID, "null handle");
+    h->debug_stop = n;
+    return EZDIT_OK;
+}
+
+}  // extern "C"

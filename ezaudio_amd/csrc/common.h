@@ -1,0 +1,139 @@
+// Shared device helpers and host launcher declarations for libezaudio_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t bf16_t;  // storage type
+
+#define EZ_WAVE 64
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+    // round-to-nearest-even, NaN preserved
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers (one per kernel family); all asynchronous on `st`
+// ------------------------------------------------------------------------------------------
+enum GemmEpi {
+    EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
+    EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
+    EPI_GEGLU = 2     // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 32/32
+};
+
+struct GemmArgs {
+    const bf16_t* A; int lda;   // [M][lda] bf16, row-major, K contiguous, zero padded to K_pad
+    const bf16_t* W; int ldw;   // [N_pad][ldw] bf16 (nn.Linear layout: out x in)
+    const float* bias;          // nullable; EPI_GEGLU: bias in the interleaved row order
+    void* out; int ldo;
+    long slab_stride;           // EPI_PARTIAL: elements between split-K slabs
+    int M, N, K;                // K multiple of 64 (padded); N = valid output columns
+    int splitk;                 // >= 1 (EPI_PARTIAL only)
+    int epi;
+    int tile;                   // 0: 128x128, 1: 128x64
+};
+void launch_gemm(const GemmArgs& a, hipStream_t st);
+
+struct AttnArgs {
+    const bf16_t* q;    // [B][H][Lqp][DQK]
+    const bf16_t* k;    // [B][H][Lkp][DQK]
+    const bf16_t* vt;   // [B][H][DV][Lkp]
+    const uint8_t* kmask;  // nullable [B][Lk], 1 = attend
+    bf16_t* out; int ldo;  // [B*Lq][ldo], head h occupies cols [h*dh, (h+1)*dh)
+    int B, H, Lq, Lk, Lqp, Lkp, dh;
+};
+void launch_attention(const AttnArgs& a, hipStream_t st);
+
+struct RowArgs {
+    // h_new = (mode SET) sum_s part_s + bias | (RES) h_in + gate * (sum_s part_s + bias) | (COPY) h_in
+    const float* h_in; float* h_out;  // h_out nullable (not stored)
+    const float* part; int nsplit; long part_stride; int ld_part;
+    const float* bias;
+    const float* gate; long gate_slot_stride;  // gate nullable -> 1; per-slot vector when stride != 0
+    int mode;  // 0 COPY, 1 RES, 2 SET
+    // LN output: u = LN(x) * g + c (per-slot or static vectors), bf16, zero padded to ld_u
+    const float* ln_g; const float* ln_c; long ln_slot_stride;
+    const float* skip; const float* cn;  // concat mode: x = [h_new | skip (+ cn)], LN over 2D with ln_g/ln_c of length 2D
+    bf16_t* u; int ld_u;
+    int M, D, L;           // rows, width, rows per batch element
+    const int* cur_step; const int* row_slot;
+};
+void launch_row(const RowArgs& a, hipStream_t st);
+
+struct HeadNormArgs {
+    const float* x; int ldx;  // fp32 [M][ldx]; q cols [0,D), k cols [D,2D), v cols [2D,3D) (as selected)
+    int q_col, k_col, v_col;  // starting column of each part, -1 = absent
+    const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // [dh]
+    const float* rope_cos; const float* rope_sin;  // [max_len][dh/2] or null (no RoPE)
+    bf16_t* q; bf16_t* k; bf16_t* vt;  // [B][H][Lp][DQK], [B][H][Lp][DQK], [B][H][DV][Lp]
+    int B, H, L, Lp, dh;
+};
+void launch_headnorm(const HeadNormArgs& a, hipStream_t st);
+
+struct AssembleArgs {
+    const float* x; int x_rows; int in_ch;  // in_ch = C: build [x | gt' | m]; in_ch = 2C+1: x is already assembled
+    const float* gt; const uint8_t* gt_mask; const float* mask_embed;
+    bf16_t* out; int ldo;  // [B*L][ldo], zero padded
+    int B, C, L;
+};
+void launch_assemble(const AssembleArgs& a, hipStream_t st);
+
+struct FinalConvArgs {
+    const float* y; int ldy;  // fp32 [B*L][ldy], token-major, C valid cols
+    const float* w; const float* b;  // [C][C][3], [C]
+    float* out;               // [B][C][L]
+    int B, C, L;
+};
+void launch_final_conv(const FinalConvArgs& a, hipStream_t st);
+
+// y[n][N] = act(x[n][K] . W[N][K]^T + b) in fp32; act: 0 none, 1 silu.  x_mode 1: x is the sinusoidal
+// embedding of timesteps ts[n] (K = 256), computed on the fly.
+void launch_linear_f32(const float* x, const int* ts, int x_mode, const float* W, const float* b, float* y,
+                       int n, int N, int K, int act, long y_stride, hipStream_t st);
+
+struct ModFinalizeArgs {
+    const float* ada;       // [n][6D]  time_ada(tt)
+    const float* lora;      // [n][nblk][6D]  lora_b(lora_a(tt)) (unscaled)
+    float scaling;          // alpha / r
+    const float* table;     // nblk pointers are not contiguous -> passed as base + stride
+    long table_stride;      // elements between blocks' scale_shift_table
+    const float* n1w; const float* n1b; const float* n3w; const float* n3b; long norm_stride;
+    float* mod;             // [n][nblk][6][D]: g1,c1,a1,g3,c3,a3
+    const float* ada_final; // [n][2D]
+    const float* nfw; const float* nfb;
+    float* mod_final;       // [n][2][D]: gF,cF
+    int n, nblk, D;
+};
+void launch_mod_finalize(const ModFinalizeArgs& a, hipStream_t st);
+
+void launch_rope_table(float* cosT, float* sinT, int max_len, int dh, hipStream_t st);
+
+struct CfgDdimArgs {
+    const float* pred;   // [B][C][L]; rows [0,P) cond, [P,2P) uncond (or B = P without CFG)
+    float* latents;      // [P][C][L] in/out
+    const float* noise;  // [n_steps][P][C][L] or null
+    const float* coef;   // [n_steps][8] (sa, sb, c_x0, c_dir, sigma, 0,0,0)
+    const int* cur_step;
+    float guidance_scale, guidance_rescale;  // guidance_scale <= 0: no CFG
+    int P, n;            // n = C*L elements per sample
+};
+void launch_cfg_ddim(const CfgDdimArgs& a, hipStream_t st);
+void launch_set_int(int* p, int v, int add, hipStream_t st);  // *p = add ? *p + v : v
+void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu

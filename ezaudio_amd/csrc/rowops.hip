@@ -1,0 +1,487 @@
+// Row-wise, HBM/L2-bound kernels of the denoising step (everything that is not a GEMM or attention).
+//   k_row          residual / split-K reduce + LayerNorm (+FiLM) -> bf16 GEMM operand   blocks.py:124-156
+//   k_headnorm     per-head LayerNorm(q,k) + RoPE -> attention layouts                  attention.py:137-142, rotary.py:6-18
+//   k_vtranspose   V -> V^T (keys contiguous) for the P.V MFMA
+//   k_assemble     MaskDiT input assembly [x | gt' | m] -> token-major bf16             conditioners.py:151-176
+//   k_final_conv   unpatchify + Conv1d(C,C,3,pad 1)                                     blocks.py:209-210
+//   k_linear_f32   tiny fp32 linears of the time path                                   modules.py:19-61, udit.py:305-316
+//   k_mod_finalize AdaLN-SOLA combine, folded with the LayerNorm affine                  blocks.py:39-45,132-139
+//   k_cfg_ddim     CFG + rescale + DDIM v-prediction update                             inference.py:12-23,88-100
+// All are pure streaming kernels: 16-byte vector accesses, one wave per row, no LDS except block reductions.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXJ = 5;  // float4 chunks per lane: D <= 5*256 = 1280
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, float d) {
+    uint2 v;
+    v.x = pack_bf2(a, b);
+    v.y = pack_bf2(c, d);
+    *reinterpret_cast<uint2*>(p) = v;
+}
+
+__global__ __launch_bounds__(256) void k_row(RowArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const int D = a.D;
+    const int nc = D >> 2;
+    const int b = row / a.L;
+    const int slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[b] : 0);
+    const float* gate = a.gate ? a.gate + (long)slot * a.gate_slot_stride : nullptr;
+
+    float4 x[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c = lane + 64 * j;
+        x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nc) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.mode != 2) v = ld4(a.h_in + (long)row * D + c * 4);
+            if (a.mode != 0) {
+                float4 s = a.bias ? ld4(a.bias + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sp = 0; sp < a.nsplit; ++sp) {
+                    const float4 p = ld4(a.part + sp * a.part_stride + (long)row * a.ld_part + c * 4);
+                    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+                }
+                if (a.mode == 1) {
+                    float4 g = gate ? ld4(gate + c * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+                    v.x += g.x * s.x; v.y += g.y * s.y; v.z += g.z * s.z; v.w += g.w * s.w;
+                } else {
+                    v = s;
+                }
+            }
+            x[j] = v;
+            if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)row * D + c * 4) = v;
+        }
+    }
+    if (!a.u) return;
+
+    const float* lg = a.ln_g + (long)slot * a.ln_slot_stride;
+    const float* lc = a.ln_c + (long)slot * a.ln_slot_stride;
+    bf16_t* urow = a.u + (long)row * a.ld_u;
+
+    if (!a.skip) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) s += x[j].x + x[j].y + x[j].z + x[j].w;  // invalid chunks are zero
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            if (lane + 64 * j < nc) {
+                const float dx = x[j].x - mean, dy = x[j].y - mean, dz = x[j].z - mean, dw = x[j].w - mean;
+                q += dx * dx + dy * dy + dz * dz + dw * dw;
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nc) {
+                const float4 g = ld4(lg + c * 4), cc = ld4(lc + c * 4);
+                st_bf4(urow + c * 4, (x[j].x - mean) * rstd * g.x + cc.x, (x[j].y - mean) * rstd * g.y + cc.y,
+                       (x[j].z - mean) * rstd * g.z + cc.z, (x[j].w - mean) * rstd * g.w + cc.w);
+            }
+        }
+        for (int i = D + lane; i < a.ld_u; i += 64) urow[i] = 0;
+    } else {
+        // LayerNorm over the concatenation [h_new | skip (+ controlnet residual)], width 2D  (blocks.py:124-127)
+        float4 y[MAXJ];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            y[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nc) {
+                float4 v = ld4(a.skip + (long)row * D + c * 4);
+                if (a.cn) {
+                    const float4 w = ld4(a.cn + (long)row * D + c * 4);
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                y[j] = v;
+            }
+            s += x[j].x + x[j].y + x[j].z + x[j].w + y[j].x + y[j].y + y[j].z + y[j].w;
+        }
+        const float inv = 1.f / (float)(2 * D);
+        const float mean = wave_sum(s) * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j)
+            if (lane + 64 * j < nc) {
+                float d;
+                d = x[j].x - mean; q += d * d; d = x[j].y - mean; q += d * d;
+                d = x[j].z - mean; q += d * d; d = x[j].w - mean; q += d * d;
+                d = y[j].x - mean; q += d * d; d = y[j].y - mean; q += d * d;
+                d = y[j].z - mean; q += d * d; d = y[j].w - mean; q += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nc) {
+                float4 g = ld4(lg + c * 4), cc = ld4(lc + c * 4);
+                st_bf4(urow + c * 4, (x[j].x - mean) * rstd * g.x + cc.x, (x[j].y - mean) * rstd * g.y + cc.y,
+                       (x[j].z - mean) * rstd * g.z + cc.z, (x[j].w - mean) * rstd * g.w + cc.w);
+                g = ld4(lg + D + c * 4); cc = ld4(lc + D + c * 4);
+                st_bf4(urow + D + c * 4, (y[j].x - mean) * rstd * g.x + cc.x, (y[j].y - mean) * rstd * g.y + cc.y,
+                       (y[j].z - mean) * rstd * g.z + cc.z, (y[j].w - mean) * rstd * g.w + cc.w);
+            }
+        }
+        for (int i = 2 * D + lane; i < a.ld_u; i += 64) urow[i] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int DH, int DQK>
+__device__ __forceinline__ void headnorm_one(const float* __restrict__ src, const float* __restrict__ w,
+                                             const float* __restrict__ bb, const float* __restrict__ cs,
+                                             const float* __restrict__ sn, bf16_t* __restrict__ dst) {
+    float v[DH];
+#pragma unroll
+    for (int i = 0; i < DH / 4; ++i) {
+        const float4 t = ld4(src + 4 * i);
+        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH; ++i) s += v[i];
+    const float mean = s * (1.f / DH);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < DH; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(q * (1.f / DH) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < DH; ++i) v[i] = (v[i] - mean) * rstd * w[i] + bb[i];
+    if (cs) {
+#pragma unroll
+        for (int i = 0; i < DH / 2; ++i) {
+            const float c = cs[i], sv = sn[i];
+            const float x1 = v[i], x2 = v[i + DH / 2];
+            v[i] = x1 * c - x2 * sv;            // x*cos + rotate_half(x)*sin, rotate_half = [-x2 | x1]
+            v[i + DH / 2] = x2 * c + x1 * sv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DQK / 8; ++i) {
+        uint4 o;
+        uint32_t* op = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i0 = 8 * i + 2 * e;
+            op[e] = pack_bf2(i0 < DH ? v[i0 < DH ? i0 : 0] : 0.f, i0 + 1 < DH ? v[i0 + 1 < DH ? i0 + 1 : 0] : 0.f);
+        }
+        *reinterpret_cast<uint4*>(dst + 8 * i) = o;
+    }
+}
+
+template <int DH, int DQK>
+__global__ __launch_bounds__(256) void k_headnorm(HeadNormArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int M = a.B * a.L;
+    if (idx >= M * a.H) return;
+    const int m = idx / a.H, h = idx % a.H;
+    const int b = m / a.L, l = m % a.L;
+    const float* cs = a.rope_cos ? a.rope_cos + (long)l * (DH / 2) : nullptr;
+    const float* sn = a.rope_sin ? a.rope_sin + (long)l * (DH / 2) : nullptr;
+    const long dsto = (((long)b * a.H + h) * a.Lp + l) * DQK;
+    if (a.q_col >= 0)
+        headnorm_one<DH, DQK>(a.x + (long)m * a.ldx + a.q_col + h * DH, a.qn_w, a.qn_b, cs, sn, a.q + dsto);
+    if (a.k_col >= 0)
+        headnorm_one<DH, DQK>(a.x + (long)m * a.ldx + a.k_col + h * DH, a.kn_w, a.kn_b, cs, sn, a.k + dsto);
+}
+
+__global__ __launch_bounds__(256) void k_vtranspose(HeadNormArgs a, int DV) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int l8n = a.Lp >> 3;
+    const int total = a.B * a.H * a.dh * l8n;
+    if (idx >= total) return;
+    const int d = idx % a.dh;
+    const int l8 = (idx / a.dh) % l8n;
+    const int bh = idx / (a.dh * l8n);
+    const int b = bh / a.H, h = bh % a.H;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int l = l8 * 8 + e;
+        v[e] = l < a.L ? a.x[((long)b * a.L + l) * a.ldx + a.v_col + h * a.dh + d] : 0.f;
+    }
+    uint4 o;
+    o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(a.vt + ((long)bh * DV + d) * a.Lp + l8 * 8) = o;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble(AssembleArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.L * a.ldo;
+    if (idx >= total) return;
+    const int c = (int)(idx % a.ldo);
+    const int m = (int)(idx / a.ldo);
+    const int b = m / a.L, l = m % a.L;
+    const int C = a.C;
+    float v = 0.f;
+    if (a.in_ch == C) {
+        const int xb = b % a.x_rows;
+        if (c < C) {
+            v = a.x[((long)xb * C + c) * a.L + l];
+        } else if (c < 2 * C) {
+            const int cc = c - C;
+            if (a.gt && !a.gt_mask[((long)xb * C + cc) * a.L + l]) v = a.gt[((long)xb * C + cc) * a.L + l];
+            else v = a.mask_embed[cc];
+        } else if (c == 2 * C) {
+            v = a.gt ? (a.gt_mask[((long)xb * C) * a.L + l] ? 1.f : 0.f) : 1.f;
+        }
+    } else if (c < a.in_ch) {
+        v = a.x[((long)b * a.in_ch + c) * a.L + l];
+    }
+    a.out[idx] = f2bf(v);
+}
+
+// out[b][co][l] = bias[co] + sum_{ci,k} w[co][ci][k] * y[b][l+k-1][ci]
+__global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
+    constexpr int TL = 32;
+    extern __shared__ float sy[];  // [(TL+2)][C+1]
+    const int C = a.C;
+    const int ltiles = (a.L + TL - 1) / TL;
+    const int b = blockIdx.x / ltiles;
+    const int l0 = (blockIdx.x % ltiles) * TL;
+    for (int i = threadIdx.x; i < (TL + 2) * C; i += 256) {
+        const int r = i / C, ci = i % C;
+        const int l = l0 + r - 1;
+        sy[r * (C + 1) + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
+    }
+    __syncthreads();
+    const int ll = threadIdx.x & 31;
+    const int cg = threadIdx.x >> 5;  // 8 groups
+    const int l = l0 + ll;
+    for (int co = cg; co < C; co += 8) {
+        float acc = a.b[co];
+        const float* wr = a.w + (long)co * C * 3;
+        for (int ci = 0; ci < C; ++ci) {
+            acc += wr[ci * 3 + 0] * sy[(ll + 0) * (C + 1) + ci];
+            acc += wr[ci * 3 + 1] * sy[(ll + 1) * (C + 1) + ci];
+            acc += wr[ci * 3 + 2] * sy[(ll + 2) * (C + 1) + ci];
+        }
+        if (l < a.L) a.out[((long)b * C + co) * a.L + l] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// y[s][j] = act(x[s][:] . W[j][:] + b[j]); one wave per output feature j, all n slots.
+__global__ __launch_bounds__(256) void k_linear_f32(const float* __restrict__ x, const int* __restrict__ ts, int x_mode,
+                                                    const float* __restrict__ W, const float* __restrict__ bias,
+                                                    float* __restrict__ y, int n, int N, int K, int act, long y_stride) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= N) return;
+    const float* wr = W + (long)j * K;
+    const float bj = bias ? bias[j] : 0.f;
+    for (int s = 0; s < n; ++s) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            float xv;
+            if (x_mode == 1) {  // timestep_embedding(t, 256): [cos(t f) | sin(t f)], f_k = exp(-ln(1e4) k / 128)
+                const int half = K >> 1;
+                const int kk = k < half ? k : k - half;
+                const float f = expf(-9.210340371976184f * (float)kk / (float)half);
+                const float arg = (float)ts[s] * f;
+                xv = k < half ? cosf(arg) : sinf(arg);
+            } else {
+                xv = x[(long)s * K + k];
+            }
+            acc += xv * wr[k];
+        }
+        acc = wave_sum(acc) + bj;
+        if (act == 1) acc = acc / (1.f + expf(-acc));
+        if (lane == 0) y[(long)s * y_stride + j] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mod_finalize(ModFinalizeArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int D = a.D;
+    const long per_slot = (long)(a.nblk + 1) * D;  // nblk block entries + 1 final entry
+    if (idx >= per_slot * a.n) return;
+    const int s = (int)(idx / per_slot);
+    const int r = (int)(idx % per_slot);
+    const int blk = r / D, d = r % D;
+    if (blk < a.nblk) {
+        float six[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            six[i] = a.ada[(long)s * 6 * D + i * D + d] +
+                     a.scaling * a.lora[((long)s * a.nblk + blk) * 6 * D + i * D + d] +
+                     a.table[(long)blk * a.table_stride + i * D + d];
+        // chunk order (blocks.py:132-133): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        const float w1 = a.n1w[(long)blk * a.norm_stride + d], b1 = a.n1b[(long)blk * a.norm_stride + d];
+        const float w3 = a.n3w[(long)blk * a.norm_stride + d], b3 = a.n3b[(long)blk * a.norm_stride + d];
+        float* o = a.mod + (((long)s * a.nblk + blk) * 6) * D + d;
+        o[0 * D] = w1 * (1.f + six[1]);
+        o[1 * D] = b1 * (1.f + six[1]) + six[0];
+        o[2 * D] = 1.f - six[2];
+        o[3 * D] = w3 * (1.f + six[4]);
+        o[4 * D] = b3 * (1.f + six[4]) + six[3];
+        o[5 * D] = 1.f - six[5];
+    } else {
+        const float shift = a.ada_final[(long)s * 2 * D + d];   // blocks.py:203-204: shift first
+        const float scale = a.ada_final[(long)s * 2 * D + D + d];
+        float* o = a.mod_final + (long)s * 2 * D + d;
+        o[0] = a.nfw[d] * (1.f + scale);
+        o[D] = a.nfb[d] * (1.f + scale) + shift;
+    }
+}
+
+__global__ void k_rope_table(float* cosT, float* sinT, int max_len, int dh) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int half = dh / 2;
+    if (idx >= max_len * half) return;
+    const int p = idx / half, i = idx % half;
+    // rotary.py:42: inv_freq = 1 / (10000 ** (arange(0, dim, 2) / dim)); angles p * inv_freq in fp32
+    const float inv_freq = 1.0f / powf(10000.0f, (float)(2 * i) / (float)dh);
+    const float ang = (float)p * inv_freq;
+    cosT[idx] = cosf(ang);
+    sinT[idx] = sinf(ang);
+}
+
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void k_cfg_ddim(CfgDdimArgs a) {
+    __shared__ float red[16];
+    const int p = blockIdx.x;
+    const int n = a.n;
+    const int step = *a.cur_step;
+    const float* cf = a.coef + step * 8;
+    const float sa = cf[0], sb = cf[1], cx0 = cf[2], cdir = cf[3], sigma = cf[4];
+    const bool cfg = a.guidance_scale > 0.f;
+    const float* pc = a.pred + (long)p * n;
+    const float* pu = cfg ? a.pred + (long)(a.P + p) * n : nullptr;
+    float* lat = a.latents + (long)p * n;
+    const float* z = a.noise ? a.noise + ((long)step * a.P + p) * n : nullptr;
+    const float gs = a.guidance_scale;
+    float ratio = 1.f;
+    const bool rescale = cfg && a.guidance_rescale > 0.f;
+    if (rescale) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float c = pc[i], u = pu[i];
+            s1 += c;
+            s2 += u + gs * (c - u);
+        }
+        const float m1 = block_sum(s1, red) / (float)n;
+        const float m2 = block_sum(s2, red) / (float)n;
+        float q1 = 0.f, q2 = 0.f;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const float c = pc[i], u = pu[i];
+            const float g = u + gs * (c - u);
+            q1 += (c - m1) * (c - m1);
+            q2 += (g - m2) * (g - m2);
+        }
+        const float v1 = block_sum(q1, red) / (float)(n - 1);  // torch.std default: unbiased
+        const float v2 = block_sum(q2, red) / (float)(n - 1);
+        ratio = sqrtf(v1) / sqrtf(v2);
+    }
+    const float phi = a.guidance_rescale;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = pc[i];
+        if (cfg) {
+            const float u = pu[i];
+            v = u + gs * (v - u);
+            if (rescale) v = phi * (v * ratio) + (1.f - phi) * v;
+        }
+        const float x = lat[i];
+        const float x0 = sa * x - sb * v;
+        const float eps = sa * v + sb * x;
+        float prev = cx0 * x0 + cdir * eps;
+        if (z) prev += sigma * z[i];
+        lat[i] = prev;
+    }
+}
+
+__global__ void k_set_int(int* p, int v, int add) { *p = add ? *p + v : v; }
+
+// out bf16 [M][ldo] = act(x fp32 [M][ldx]) for cols < N, zero for N <= col < ldo
+__global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, int ldx, bf16_t* __restrict__ out,
+                                                   int ldo, int M, int N, int act) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * ldo) return;
+    const int c = (int)(idx % ldo);
+    const int m = (int)(idx / ldo);
+    float v = 0.f;
+    if (c < N) {
+        v = x[(long)m * ldx + c];
+        if (act == 1) v = v / (1.f + expf(-v));
+    }
+    out[idx] = f2bf(v);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+void launch_row(const RowArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_row, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
+}
+
+void launch_headnorm(const HeadNormArgs& a, hipStream_t st) {
+    const int M = a.B * a.L;
+    if (a.q_col >= 0 || a.k_col >= 0) {
+        const int nthr = M * a.H;
+        if (a.dh == 64) hipLaunchKernelGGL((k_headnorm<64, 64>), dim3((nthr + 255) / 256), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_headnorm<72, 80>), dim3((nthr + 255) / 256), dim3(256), 0, st, a);
+    }
+    if (a.v_col >= 0) {
+        const int DV = a.dh == 64 ? 64 : 96;
+        const int total = a.B * a.H * a.dh * (a.Lp / 8);
+        hipLaunchKernelGGL(k_vtranspose, dim3((total + 255) / 256), dim3(256), 0, st, a, DV);
+    }
+}
+
+void launch_assemble(const AssembleArgs& a, hipStream_t st) {
+    const long total = (long)a.B * a.L * a.ldo;
+    hipLaunchKernelGGL(k_assemble, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+}
+
+void launch_final_conv(const FinalConvArgs& a, hipStream_t st) {
+    const int ltiles = (a.L + 31) / 32;
+    const size_t sh = (size_t)34 * (a.C + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_final_conv, dim3(a.B * ltiles), dim3(256), sh, st, a);
+}
+
+void launch_linear_f32(const float* x, const int* ts, int x_mode, const float* W, const float* b, float* y,
+                       int n, int N, int K, int act, long y_stride, hipStream_t st) {
+    hipLaunchKernelGGL(k_linear_f32, dim3((N + 3) / 4), dim3(256), 0, st, x, ts, x_mode, W, b, y, n, N, K, act, y_stride);
+}
+
+void launch_mod_finalize(const ModFinalizeArgs& a, hipStream_t st) {
+    const long total = (long)(a.nblk + 1) * a.D * a.n;
+    hipLaunchKernelGGL(k_mod_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+}
+
+void launch_rope_table(float* cosT, float* sinT, int max_len, int dh, hipStream_t st) {
+    const int total = max_len * (dh / 2);
+    hipLaunchKernelGGL(k_rope_table, dim3((total + 255) / 256), dim3(256), 0, st, cosT, sinT, max_len, dh);
+}
+
+void launch_cfg_ddim(const CfgDdimArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_cfg_ddim, dim3(a.P), dim3(1024), 0, st, a);
+}
+
+void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st) {
+    const long total = (long)M * ldo;
+    hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, out, ldo, M, N, act);
+}
+
+void launch_set_int(int* p, int v, int add, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, p, v, add);
+}

@@ -1,0 +1,106 @@
+"""DDIM scheduler with the call surface the reference uses from `diffusers.DDIMScheduler`
+(api/ezaudio.py:11,92-97; src/inference.py:64,70-71,98-100): constructor kwargs = the `diff:` section
+of the yml, `set_timesteps`, `timesteps`, `scale_model_input`, `step(...).prev_sample`, `add_noise`,
+`config.num_train_timesteps`.
+
+diffusers is not vendored by the reference and not installable here, so this is a from-scratch host-side
+implementation of the published algorithm (scaled_linear betas, zero-terminal-SNR rescale, trailing
+spacing, v-prediction step).  Scalar tables are built with torch float32 CPU ops exactly as diffusers
+builds them, and `ddim_coefficients` exports the per-step scalars the fused HIP kernel consumes.
+"""
+import types
+
+import numpy as np
+import torch
+
+
+def _rescale_zero_terminal_snr(betas):
+    alphas = 1.0 - betas
+    abar_sqrt = torch.cumprod(alphas, dim=0).sqrt()
+    a0, aT = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+    abar_sqrt = abar_sqrt - aT
+    abar_sqrt = abar_sqrt * (a0 / (a0 - aT))
+    abar = abar_sqrt ** 2
+    alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+    return 1 - alphas
+
+
+class DDIMScheduler:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule='linear',
+                 prediction_type='epsilon', rescale_betas_zero_snr=False, timestep_spacing='leading',
+                 clip_sample=True, set_alpha_to_one=True, **unused):
+        if beta_schedule != 'scaled_linear':
+            raise NotImplementedError(f'beta_schedule={beta_schedule!r}')
+        if prediction_type != 'v_prediction':
+            raise NotImplementedError(f'prediction_type={prediction_type!r}')
+        if timestep_spacing != 'trailing':
+            raise NotImplementedError(f'timestep_spacing={timestep_spacing!r}')
+        if clip_sample:
+            raise NotImplementedError('clip_sample=True')
+        self.config = types.SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start,
+                                            beta_end=beta_end, beta_schedule=beta_schedule,
+                                            prediction_type=prediction_type,
+                                            rescale_betas_zero_snr=rescale_betas_zero_snr,
+                                            timestep_spacing=timestep_spacing, clip_sample=clip_sample)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        if rescale_betas_zero_snr:
+            betas = _rescale_zero_terminal_snr(betas)
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps / num_inference_steps
+        ts = np.round(np.arange(self.config.num_train_timesteps, 0, -ratio)).astype(np.int64) - 1
+        self.timesteps = torch.from_numpy(ts)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def _scalars(self, timestep):
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        return a_t, a_prev
+
+    def ddim_coefficients(self, eta):
+        """[(sa, sb, c_x0, c_dir, sigma)] per step, float32, for ezdit_sampler_begin."""
+        out = []
+        for t in self.timesteps:
+            a_t, a_prev = self._scalars(t)
+            b_t = 1 - a_t
+            variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
+            sigma = eta * variance ** 0.5
+            c_dir = (1 - a_prev - sigma ** 2) ** 0.5
+            out.append(tuple(float(v) for v in (a_t ** 0.5, b_t ** 0.5, a_prev ** 0.5, c_dir, sigma)))
+        return out
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None, variance_noise=None, **unused):
+        a_t, a_prev = self._scalars(timestep)
+        b_t = 1 - a_t
+        x0 = (a_t ** 0.5) * sample - (b_t ** 0.5) * model_output
+        eps = (a_t ** 0.5) * model_output + (b_t ** 0.5) * sample
+        variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
+        sigma = eta * variance ** 0.5
+        prev = a_prev ** 0.5 * x0 + (1 - a_prev - sigma ** 2) ** 0.5 * eps
+        if eta > 0:
+            if variance_noise is None:
+                variance_noise = torch.randn(model_output.shape, generator=generator, device=model_output.device,
+                                             dtype=model_output.dtype)
+            prev = prev + sigma * variance_noise
+        return types.SimpleNamespace(prev_sample=prev)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        timesteps = timesteps.to(original_samples.device)
+        sa = ac[timesteps] ** 0.5
+        sb = (1 - ac[timesteps]) ** 0.5
+        while sa.dim() < original_samples.dim():
+            sa, sb = sa.unsqueeze(-1), sb.unsqueeze(-1)
+        return sa * original_samples + sb * noise

@@ -149,6 +149,8 @@ int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, 
 int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t* bytes);
 /* number of kernel launches issued by the last ezdit_forward (host counter). */
 int ezdit_last_launch_count(const ezdit_handle* h);
+/* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
+int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
 
 #ifdef __cplusplus
 }

@@ -127,7 +127,7 @@ class DiTOracle:
         return x257, mae_mask
 
     # --- A11/A13: Attention.forward, attention.py:122-149 -------------------------------------------
-    def attention(self, pfx, x, context=None, key_mask=None, rope=None):
+    def attention(self, pfx, x, context=None, key_mask=None, rope=None, tap=None):
         H = self.H
         ctx = x if context is None else context
         q = split_heads(linear(x, self.p(f'{pfx}.to_q.weight')), H)
@@ -141,6 +141,9 @@ class DiTOracle:
             q = apply_rope(q.astype(np.float32), cos, sin).astype(self.dtype) if self.dtype == np.float32 else apply_rope(q, cos, sin)
             k = apply_rope(k.astype(np.float32), cos, sin).astype(self.dtype) if self.dtype == np.float32 else apply_rope(k, cos, sin)
         o = merge_heads(sdpa(q, k, v, key_mask))
+        if tap is not None:
+            kind = 'x' if context is not None else 's'
+            tap(kind + 'q', q); tap(kind + 'k', k); tap(kind + 'v', v); tap(kind + 'o', o)
         return linear(o, self.p(f'{pfx}.proj.weight'), self.p(f'{pfx}.proj.bias'))
 
     # --- A8: AdaLN.forward (ada_sola_bias), blocks.py:39-45 -----------------------------------------
@@ -152,28 +155,43 @@ class DiTOracle:
         return self.p(f'{pfx}.adaln.scale_shift_table')[None] + ta
 
     # --- A14: FeedForward / GEGLU, modules.py:263-277,341-374 --------------------------------------
-    def mlp(self, pfx, x):
+    def mlp(self, pfx, x, tap=None):
         h = linear(x, self.p(f'{pfx}.mlp.net.0.proj.weight'), self.p(f'{pfx}.mlp.net.0.proj.bias'))
         inner = h.shape[-1] // 2
         val, gate = h[..., :inner], h[..., inner:]  # chunk(2): first half value, second half gate
+        if tap is not None:
+            tap('act', val * gelu_erf(gate))
         return linear(val * gelu_erf(gate), self.p(f'{pfx}.mlp.net.2.weight'), self.p(f'{pfx}.mlp.net.2.bias'))
 
     # --- A16: DiTBlock._forward, blocks.py:120-160 --------------------------------------------------
     def block(self, pfx, x, time_token, time_ada, skip, context, ctx_mask, rope):
+        tp = self.taps if (self.taps is not None and self.taps.get('_fine')) else None
+
+        def tap(name, v):
+            if tp is not None:
+                tp[f'{pfx}:{name}'] = np.array(v, copy=True)
         if skip is not None:  # blocks.py:124-128
             cat = np.concatenate([x, skip], axis=-1)
             cat = layer_norm(cat, self.p(f'{pfx}.skip_norm.weight'), self.p(f'{pfx}.skip_norm.bias'))
+            tap('ucat', cat)
             x = linear(cat, self.p(f'{pfx}.skip_linear.weight'), self.p(f'{pfx}.skip_linear.bias'))
+            tap('h_skip', x)
         ta = self.adaln(pfx, time_token, time_ada)
+        tap('ada6', ta)
         shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = [ta[:, i:i + 1, :] for i in range(6)]
         xn = film_modulate(layer_norm(x, self.p(f'{pfx}.norm1.weight'), self.p(f'{pfx}.norm1.bias')), shift_msa, scale_msa)
-        x = x + (1 - gate_msa) * self.attention(f'{pfx}.attn', xn, rope=rope)  # blocks.py:139: (1 - gate)
+        tap('u1', xn)
+        x = x + (1 - gate_msa) * self.attention(f'{pfx}.attn', xn, rope=rope, tap=tap)  # blocks.py:139: (1 - gate)
+        tap('h_attn', x)
         cn = layer_norm(context, self.p(f'{pfx}.norm_context.weight'), self.p(f'{pfx}.norm_context.bias'))
-        x = x + self.attention(f'{pfx}.cross_attn',
-                               layer_norm(x, self.p(f'{pfx}.norm2.weight'), self.p(f'{pfx}.norm2.bias')),
-                               context=cn, key_mask=ctx_mask)  # blocks.py:147-151: no gate
+        u2 = layer_norm(x, self.p(f'{pfx}.norm2.weight'), self.p(f'{pfx}.norm2.bias'))
+        tap('u2', u2)
+        x = x + self.attention(f'{pfx}.cross_attn', u2, context=cn, key_mask=ctx_mask, tap=tap)  # blocks.py:147-151: no gate
+        tap('h_cross', x)
         xn = film_modulate(layer_norm(x, self.p(f'{pfx}.norm3.weight'), self.p(f'{pfx}.norm3.bias')), shift_mlp, scale_mlp)
-        x = x + (1 - gate_mlp) * self.mlp(pfx, xn)
+        tap('u3', xn)
+        x = x + (1 - gate_mlp) * self.mlp(pfx, xn, tap=tap)
+        tap('h_out', x)
         return x
 
     # --- A6: context path, udit.py:94-97,295-296 ----------------------------------------------------

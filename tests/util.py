@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import ast
+import os
+
+import numpy as np
+
+from oracle.weights import make_inputs, make_state_dict, model_config, uniform_pm1
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    meta = ast.literal_eval(str(g['meta']))
+    return g, meta
+
+
+def golden_case(name):
+    """(cfg, state_dict, inputs, extra kwargs for forward, golden arrays, meta) of a dit_* fixture."""
+    g, meta = load_golden('dit_' + name)
+    cfg = model_config(meta['size'])
+    sd = make_state_dict(cfg, meta['seed_w'])
+    inp = make_inputs(cfg, B=2, L=meta['L'], Lc=meta['Lc'], n_valid=tuple(meta['n_valid']), seed=meta['seed_in'],
+                      with_gt=meta['with_gt'])
+    kw = {}
+    if meta['with_gt']:
+        kw = dict(gt=inp['gt'], mae_mask_infer=inp['gt_mask'])
+    if meta['cn_skips']:
+        D, L = cfg['embed_dim'], meta['L']
+        kw['controlnet_skips'] = [(0.1 * uniform_pm1(f'in.cn{i}', 2 * L * D, meta['seed_in'])).reshape(2, L, D)
+                                  for i in range(cfg['depth'] // 2)]
+    return cfg, sd, inp, kw, g, meta
+
+
+def sampler_case(name):
+    g, meta = load_golden('sampler_' + name)
+    cfg = model_config(meta['size'])
+    sd = make_state_dict(cfg, meta['seed_w'])
+    L, Lc, steps = meta['L'], meta['Lc'], meta['steps']
+    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, seed=meta['seed_in'], with_gt=meta['with_gt'])
+    C = cfg['out_chans']
+    s3 = np.float32(np.sqrt(3.0))
+    init = (uniform_pm1('smp.init', C * L, meta['seed_in']) * s3).reshape(1, C, L)
+    noises = [(uniform_pm1(f'smp.z{i}', C * L, meta['seed_in']) * s3).reshape(1, C, L) for i in range(steps)]
+    return cfg, sd, inp, init, noises, g, meta
+
+
+DIFF = dict(num_train_timesteps=1000, beta_schedule='scaled_linear', beta_start=0.00085, beta_end=0.012,
+            prediction_type='v_prediction', rescale_betas_zero_snr=True, timestep_spacing='trailing',
+            clip_sample=False)
