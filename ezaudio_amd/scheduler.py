@@ -14,6 +14,20 @@ import numpy as np
 import torch
 
 
+def _linspace_f32(start, end, steps):
+    """torch.linspace(..., dtype=float32) by its scalar definition (step = (end-start)/(steps-1); first half counted
+    up from start, second half down from end).  torch's own CPU kernel evaluates this with SIMD-width-dependent
+    rounding, i.e. the last bit of beta depends on the host's vector ISA; the zero-terminal-SNR schedule then lands
+    either side of 0 in `1 - alpha_prev - sigma^2` at t = 999 (see `ddim_coefficients`).  A fixed scalar evaluation
+    makes the schedule identical on every machine."""
+    start, end = np.float32(start), np.float32(end)
+    step = np.float32((end - start) / np.float32(steps - 1))
+    idx = np.arange(steps)
+    up = (start + step * idx.astype(np.float32)).astype(np.float32)
+    down = (end - step * (steps - 1 - idx).astype(np.float32)).astype(np.float32)
+    return torch.from_numpy(np.where(idx < steps // 2, up, down).astype(np.float32))
+
+
 def _rescale_zero_terminal_snr(betas):
     alphas = 1.0 - betas
     abar_sqrt = torch.cumprod(alphas, dim=0).sqrt()
@@ -42,7 +56,7 @@ class DDIMScheduler:
                                             prediction_type=prediction_type,
                                             rescale_betas_zero_snr=rescale_betas_zero_snr,
                                             timestep_spacing=timestep_spacing, clip_sample=clip_sample)
-        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        betas = _linspace_f32(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps) ** 2
         if rescale_betas_zero_snr:
             betas = _rescale_zero_terminal_snr(betas)
         self.betas = betas
@@ -77,7 +91,11 @@ class DDIMScheduler:
             b_t = 1 - a_t
             variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
             sigma = eta * variance ** 0.5
-            c_dir = (1 - a_prev - sigma ** 2) ** 0.5
+            # With zero terminal SNR and eta = 1 the radicand is 0 in exact arithmetic at t = 999 (alpha_bar_t = 0 =>
+            # sigma^2 = 1 - alpha_bar_prev) and +-6e-8 in fp32: the reference (diffusers) takes sqrt of whichever sign
+            # the host's rounding produced (NaN for e.g. 25 steps).  Clamp at 0: identical whenever the reference is
+            # finite, finite where it is not.
+            c_dir = torch.clamp(1 - a_prev - sigma ** 2, min=0.0) ** 0.5
             out.append(tuple(float(v) for v in (a_t ** 0.5, b_t ** 0.5, a_prev ** 0.5, c_dir, sigma)))
         return out
 
@@ -88,7 +106,7 @@ class DDIMScheduler:
         eps = (a_t ** 0.5) * model_output + (b_t ** 0.5) * sample
         variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
         sigma = eta * variance ** 0.5
-        prev = a_prev ** 0.5 * x0 + (1 - a_prev - sigma ** 2) ** 0.5 * eps
+        prev = a_prev ** 0.5 * x0 + torch.clamp(1 - a_prev - sigma ** 2, min=0.0) ** 0.5 * eps
         if eta > 0:
             if variance_noise is None:
                 variance_noise = torch.randn(model_output.shape, generator=generator, device=model_output.device,

@@ -221,7 +221,10 @@ class DiTOracle:
         x = x257.transpose(0, 2, 1) @ w.T + self.p('model.patch_embed.proj.bias')
         c = self.context_embed(ctx)
         tt, ada, ada_final = self.time_path(t, B)
-        rope = rope_tables(L, self.sd[f'model.mid_block.attn.rotary.inv_freq'])
+        inv_freq = self.sd.get('model.mid_block.attn.rotary.inv_freq')
+        if inv_freq is None:  # a buffer, not a parameter: rebuild it as rotary.py:42 does
+            inv_freq = (1.0 / (10000.0 ** (np.arange(0, self.dh, 2, dtype=np.float32) / np.float32(self.dh)))).astype(np.float32)
+        rope = rope_tables(L, inv_freq)
         if self.dtype != np.float32:
             rope = (rope[0].astype(self.dtype), rope[1].astype(self.dtype))
         ctx_mask = None if ctx_mask is None else np.asarray(ctx_mask, dtype=bool)
