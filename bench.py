@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
+GEGLU_VARIANT = 0 * 4 + 2   # ezdit_test_gemm: tile config 0 (what the step uses), GEGLU epilogue
 
 
 def model_section(size):
@@ -54,12 +55,12 @@ def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
     lib = unet.lib
     with torch.cuda.stream(stream):
         for _ in range(3):
-            lib.ezdit_test_gemm(None, 4, A.data_ptr(), D, W.data_ptr(), D, bias.data_ptr(), out.data_ptr(), inner, M,
+            lib.ezdit_test_gemm(None, GEGLU_VARIANT, A.data_ptr(), D, W.data_ptr(), D, bias.data_ptr(), out.data_ptr(), inner, M,
                                 2 * inner, D, 1, C.c_void_p(stream.cuda_stream))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(iters):
-            lib.ezdit_test_gemm(None, 4, A.data_ptr(), D, W.data_ptr(), D, bias.data_ptr(), out.data_ptr(), inner, M,
+            lib.ezdit_test_gemm(None, GEGLU_VARIANT, A.data_ptr(), D, W.data_ptr(), D, bias.data_ptr(), out.data_ptr(), inner, M,
                                 2 * inner, D, 1, C.c_void_p(stream.cuda_stream))
         e1.record(stream)
     e1.synchronize()

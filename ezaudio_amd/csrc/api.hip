@@ -206,13 +206,14 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         off += (size_t)rup((long)bytes, 256);
     };
     const long D = h->D, I = h->I, C = h->C, H = h->H;
-    const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 32), Lcp = rup(Lc, 32);
+    const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 64), Lcp = rup(Lc, 64);  // attention stages 64-key tiles
     const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
     const int nblk = h->nblk;
     add("ints", 256 * sizeof(int));                       // [0] cur_step, [16..] row_slot (<= 240 rows)
     add("rope_cos", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("rope_sin", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
+    add("cfgpart", (size_t)B * 64 * 4 * 4);
     add("ape", Mp * h->ldPE * 2);
     add("h", Mp * D * 4);
     add("skips", (size_t)h->nhalf * Mp * D * 4);
@@ -276,16 +277,24 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.splitk = splitk;
     g.epi = epi;
     g.tile = tile;
+    g.debug = 0;
     launch_gemm(g, c.st);
     h->launches++;
+}
+
+// Tile / split-K heuristics from tests/bench_kernels.py on MI355X (profiles/): with M ~ 1000 rows the 128x64 tile at
+// 3 workgroups per CU wins everywhere (occupancy beats ring depth); from M ~ 4000 the 128x128 8-wave tile is ahead.
+int tile_for(int M, bool partial) {
+    if (M <= 2048) return partial ? 5 : 6;
+    return partial ? 5 : 7;
 }
 
 int pick_splitk(int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = K / 64;
-    int s = 512 / (tiles > 0 ? tiles : 1);
-    if (s > nk / 6) s = nk / 6;
-    if (s > 8) s = 8;
+    if (tiles >= 256) return 1;
+    int s = nk >= 36 ? 4 : 2;
+    if (s > nk) s = nk;
     if (s < 1) s = 1;
     return s;
 }
@@ -295,7 +304,7 @@ int gemm_partial(Ctx& c, const bf16_t* A, int lda, const std::string& wname, int
     ezdit_handle* h = c.h;
     const int K = h->pld(wname);
     const int s = pick_splitk(M, N, K);
-    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, 1, s, (long)h->Mp * h->D);
+    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, tile_for(M, true), s, (long)h->Mp * h->D);
     return s;
 }
 
@@ -385,7 +394,7 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     h->ws_bytes = bytes;
     h->bufs = bufs;
     h->B = B; h->L = L; h->Lc = Lc; h->n_slots = n_slots > 0 ? n_slots : 1;
-    h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 32); h->Lcp = (int)rup(Lc, 32);
+    h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 64); h->Lcp = (int)rup(Lc, 64);
     h->Mc = B * Lc;
     h->ctx_ready = h->ts_ready = false;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -407,9 +416,9 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
     else HIPCHK(hipMemsetAsync(km, 1, Mc, c.st));
     // context_embed: Linear -> SiLU -> Linear  (udit.py:94-97)
     launch_cast_bf16(ctx, h->Cctx, h->buf<bf16_t>("ctx_bf"), h->ldCtx, Mc, h->Cctx, 0, c.st);
-    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, "ce.w1", h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, 1);
+    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, "ce.w1", h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, tile_for(Mc, false));
     launch_cast_bf16(h->buf<float>("c1"), D, h->buf<bf16_t>("c1b"), h->ldD, Mc, D, 1, c.st);
-    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, "ce.w2", h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, 1);
+    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, "ce.w2", h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, tile_for(Mc, false));
     for (int b = 0; b < h->nblk; ++b) {
         // norm_context (blocks.py:150) -> to_k / to_v -> head LayerNorm on k (attention.py:128-142)
         RowArgs r;
@@ -422,7 +431,7 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
         r.ld_u = h->ldD;
         r.M = Mc; r.D = D; r.L = h->Lc;
         launch_row(r, c.st);
-        gemm(c, h->buf<bf16_t>("cu"), h->ldD, bn(b, "wkv2"), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, 0);
+        gemm(c, h->buf<bf16_t>("cu"), h->ldD, bn(b, "wkv2"), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, tile_for(Mc, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("ckv"); hn.ldx = 2 * D;
@@ -516,7 +525,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     launch_assemble(as, st);
     h->launches++;
     STOPCHK();
-    gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, 1);
+    gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, tile_for(M, false));
 
     auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
                    long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
@@ -553,7 +562,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         }
         // ---- self attention (blocks.py:136-141) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32, 0);
+        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32, tile_for(M, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = 3 * D;
@@ -582,7 +591,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hcur = hA;
         // ---- cross attention (blocks.py:147-151) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, 1);
+        gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, tile_for(M, false));
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = D;
         hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
@@ -606,7 +615,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         row(1, hA, hA, s, h->w<float>(bn(b, "bo2")), nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU, 0);
+        gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU, tile_for(M, false));
         STOPCHK();
         s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
@@ -631,7 +640,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     }
     // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
     STOPCHK();
-    gemm(c, u, h->ldD, "fin.w", h->w<float>("fin.b"), h->buf<float>("y"), h->C, M, h->C, EPI_F32, 1);
+    gemm(c, u, h->ldD, "fin.w", h->w<float>("fin.b"), h->buf<float>("y"), h->C, M, h->C, EPI_F32, tile_for(M, false));
     FinalConvArgs fc;
     fc.y = h->buf<float>("y"); fc.ldy = h->C;
     fc.w = h->w<float>("fin.cw"); fc.b = h->w<float>("fin.cb");
@@ -691,7 +700,7 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
     a.coef = h->buf<float>("coef"); a.cur_step = h->buf<int>("ints");
     a.guidance_scale = h->gscale; a.guidance_rescale = h->grescale;
     a.P = h->P; a.n = h->C * h->L;
-    launch_cfg_ddim(a, st);
+    launch_cfg_ddim(a, h->buf<float>("cfgpart"), st);
     launch_set_int(h->buf<int>("ints"), 1, 1, st);
     h->launches += 2;
     return EZDIT_OK;
@@ -733,8 +742,11 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.epi = variant / 2; g.tile = variant % 2;   // variant = epi * 2 + tile
-    if (g.epi == EPI_GEGLU && g.tile != 0) return fail(EZDIT_E_INVALID, "GEGLU epilogue uses the 128x128 tile");
+    g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
+    g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
+    if (g.epi > EPI_GEGLU || g.tile > 11) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
+    if (g.epi == EPI_GEGLU && (g.tile == 1 || g.tile == 3 || g.tile == 5))
+        return fail(EZDIT_E_INVALID, "GEGLU epilogue needs a tile config with >= 2 column fragments per wave");
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     launch_gemm(g, (hipStream_t)stream);
     return EZDIT_OK;

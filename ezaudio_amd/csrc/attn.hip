@@ -3,7 +3,10 @@
 // key mask of cross-attention is built at attention.py:30-37,131-135.)
 //
 // gfx950 design (v_mfma_f32_32x32x16_bf16 everywhere, fp32 softmax state):
-//   * one wave owns 32 query rows; 4 waves per workgroup (128 query rows), waves are independent.
+//   * workgroup = 64 query rows of one (batch, head); 4 waves = 2 query sub-blocks (32 rows) x 2 key halves.
+//     K and V^T are staged through LDS in 64-key tiles; wave (qs, kh) works on the 32 keys [32*kh, 32*kh+32) of
+//     every tile and the two key halves are merged once at the end (log-sum-exp merge through LDS).  With
+//     L = 500 this gives B*H*8 = 256 workgroups for one CFG pair: one per CU, all four SIMDs busy.
 //   * scores are computed TRANSPOSED: S^T[key, q] = K . Q^T, so in the 32x32 C layout a lane owns ONE query
 //     column (q = lane & 31) and 16 of the 32 keys of the tile.  The softmax row reductions are then
 //     in-lane plus a single exchange with lane ^ 32 -- no LDS, no 5-step butterflies.
@@ -11,11 +14,13 @@
 //     factor (per q) is lane-local for the accumulators, and P^T (B operand: lane = q, 8 keys per lane) is
 //     exactly the S^T registers converted to bf16 -- P never leaves registers.  The MFMA contraction order
 //     over keys is permuted accordingly (k-slot (hi, j) <-> key 16*step + 8*(j>>2) + 4*hi + (j&3)); the
-//     producer stores V TRANSPOSED ([dh][keys], keys contiguous) so the matching A fragment is two 8-byte loads.
+//     producer stores V TRANSPOSED ([dh][keys], keys contiguous) so the matching A fragment is two 8-byte reads.
+//   * staging is register-prefetched (issue the global loads of tile t+1, compute tile t out of LDS, then
+//     write the registers to the other LDS buffer): one barrier per tile, HBM/L2 latency hidden behind the
+//     MFMAs + softmax of a whole tile.  LDS row strides are padded (K: +16 B, V^T: +8 B) so that the
+//     ds_read_b128 / ds_read_b64 fragment reads are bank-conflict free.
 //   * head_dim 72 (EzAudio-XL) is zero padded to 80 for the QK^T contraction (5 k-steps of 16) and to 96
 //     output rows (3 tiles of 32) for P.V; head_dim 64 needs no padding.
-//   * L = 500 keys: K/V of one head are 80 KB each and L2/L1 resident, so fragments are read straight
-//     from global memory (no LDS staging, no barriers).
 #include "common.h"
 
 namespace {
@@ -33,22 +38,79 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     constexpr int DV = HeadGeom<DH>::DV;
     constexpr int NKS = DQK / 16;  // k-steps of the QK^T contraction
     constexpr int NDT = DV / 32;   // 32-row tiles of O^T
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    constexpr int KSTR = DQK * 2 + 16;   // LDS row stride of a K row (bytes)
+    constexpr int VSTR = 64 * 2 + 8;     // LDS row stride of a V^T row (64 keys)
+    constexpr int KBYTES = 64 * KSTR, VBYTES = DV * VSTR;
+    constexpr int BUF = KBYTES + VBYTES;
+    constexpr int KCH = 64 * DQK * 2 / 16;   // 16-byte chunks of a K tile (contiguous in global memory)
+    constexpr int VCH = DV * 8;              // 16-byte chunks of a V^T tile (8 per row)
+    constexpr int KPT = (KCH + 255) / 256, VPT = (VCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int qs = wave & 1, kh = wave >> 1;
     const int r32 = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
-    if (q0 >= a.Lq) return;
+    const int q0 = blockIdx.x * 64 + qs * 32;
     const long bh = (long)b * a.H + h;
 
     const bf16_t* Q = a.q + (bh * a.Lqp + q0 + r32) * DQK + 8 * hi;
-    const bf16_t* K = a.k + (bh * a.Lkp + r32) * DQK + 8 * hi;
-    const bf16_t* VT = a.vt + (bh * DV + r32) * (long)a.Lkp + 4 * hi;
+    const char* Kg = reinterpret_cast<const char*>(a.k + bh * a.Lkp * DQK);
+    const bf16_t* VTg = a.vt + bh * DV * (long)a.Lkp;
     const uint8_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
 
     bf16x8 qf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + 16 * ks);
+
+    // staging registers: NAMED scalars, not an array (hipcc demotes a register array that is live across the tile loop
+    // to scratch); every thread issues all its loads unconditionally (chunk index clamped), only LDS writes are predicated
+    uint4 k0 = {}, k1 = {}, k2 = {}, v0 = {}, v1 = {}, v2 = {};
+    auto kchunk = [&](int i, int key0) -> uint4 {
+        int c = tid + 256 * i;
+        c = c < KCH ? c : KCH - 1;
+        return *reinterpret_cast<const uint4*>(Kg + (long)key0 * DQK * 2 + c * 16);
+    };
+    auto vchunk = [&](int i, int key0) -> uint4 {
+        int c = tid + 256 * i;
+        c = c < VCH ? c : VCH - 1;
+        return *reinterpret_cast<const uint4*>(VTg + (long)(c >> 3) * a.Lkp + key0 + (c & 7) * 8);
+    };
+    auto kstore = [&](int i, char* kb, const uint4& val) {
+        const int c = tid + 256 * i;
+        if (c < KCH) *reinterpret_cast<uint4*>(kb + (c / (DQK / 8)) * KSTR + (c % (DQK / 8)) * 16) = val;
+    };
+    auto vstore = [&](int i, char* vb, const uint4& val) {
+        const int c = tid + 256 * i;
+        if (c < VCH) {
+            char* dst = vb + (c >> 3) * VSTR + (c & 7) * 16;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
+            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(val.z, val.w);
+        }
+    };
+#define LOAD_TILE(t)                                   \
+    do {                                               \
+        const int key0_ = (t) * 64;                    \
+        k0 = kchunk(0, key0_);                         \
+        k1 = kchunk(1, key0_);                         \
+        if constexpr (KPT > 2) k2 = kchunk(2, key0_);  \
+        v0 = vchunk(0, key0_);                         \
+        v1 = vchunk(1, key0_);                         \
+        if constexpr (VPT > 2) v2 = vchunk(2, key0_);  \
+    } while (0)
+#define WRITE_TILE(buf)                                \
+    do {                                               \
+        char* kb_ = smem + (buf) * BUF;                \
+        char* vb_ = kb_ + KBYTES;                      \
+        kstore(0, kb_, k0);                            \
+        kstore(1, kb_, k1);                            \
+        if constexpr (KPT > 2) kstore(2, kb_, k2);     \
+        vstore(0, vb_, v0);                            \
+        vstore(1, vb_, v1);                            \
+        if constexpr (VPT > 2) vstore(2, vb_, v2);     \
+    } while (0)
 
     f32x16 o[NDT];
 #pragma unroll
@@ -56,87 +118,145 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m = -1e30f, lsum = 0.f;
+    constexpr float RESCALE_THR = 4.0f;  // log2 units: P <= 16
     const float c = 1.4426950408889634f * rsqrtf((float)DH);  // log2(e) / sqrt(dh)
 
-    const int ntiles = (a.Lk + 31) / 32;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        const int key0 = kt * 32;
-        f32x16 s;
+    const int ntiles = (a.Lk + 63) / 64;
+    LOAD_TILE(0);
+    WRITE_TILE(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) LOAD_TILE(t + 1);
+        const char* kb = smem + (t & 1) * BUF;
+        const char* vb = kb + KBYTES;
+        const int key0 = t * 64 + kh * 32;
+        if (key0 < a.Lk) {  // wave-uniform: the whole 32-key sub-tile may lie beyond Lk
+            // validity of this wave's 32 keys as one bit mask (bit j <-> key0 + j), built BEFORE the MFMAs
+            const int kidx = key0 + r32;
+            bool kv = kidx < a.Lk;
+            if (km) kv = kv && (km[kidx < a.Lk ? kidx : 0] != 0);
+            const uint32_t tmask = (uint32_t)__ballot(kv) >> (4 * hi);  // lanes 0..31 fill bits 0..31
+            f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(K + (long)key0 * DQK + 16 * ks);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
-        }
-        // lane holds S^T[key0 + (r&3) + 8*(r>>2) + 4*hi][q0 + r32]
-        float tmax = -1e30f;
-        bool valid[16];
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kh * 32 + r32) * KSTR + (2 * ks + hi) * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // The last MFMA writes a12..a15 in its final pass.  hipcc 7.2 was observed to place the accumulator
+            // reads only ~4 wait states behind it when a uniform branch separated them (stale s[14], s[15]): pin an
+            // explicit 20-state gap that depends on the accumulator.
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(s));
+            // lane holds S^T[key0 + (r&3) + 8*(r>>2) + 4*hi][q0 + r32]
+            float tmax = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            bool v = key < a.Lk;
-            if (km) v = v && (km[key < a.Lk ? key : 0] != 0);
-            valid[r] = v;
-            s[r] = v ? s[r] * c : -1e30f;
-            tmax = fmaxf(tmax, s[r]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mnew);
-        m = mnew;
-        float psum = 0.f;
-        float p[16];
+            for (int r = 0; r < 16; ++r) {
+                const bool v = (tmask >> ((r & 3) + 8 * (r >> 2))) & 1u;
+                s[r] = v ? s[r] * c : -1e30f;
+                tmax = fmaxf(tmax, s[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            // deferred rescale: keep the old reference max while the tile max exceeds it by < 2^-? ... THR (log2 units);
+            // P is then bounded by 2^THR instead of 1, which fp32 sums / bf16 P absorb; the accumulators are touched
+            // only when some row really needs a new reference (wave-uniform branch).
+            if (!__all(tmax <= m + RESCALE_THR)) {
+                const float mnew = fmaxf(m, tmax);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                m = mnew;
+                lsum *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = valid[r] ? exp2f(s[r] - mnew) : 0.f;
-            psum += p[r];
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        lsum = lsum * alpha + psum;
+                for (int tt = 0; tt < NDT; ++tt)
 #pragma unroll
-        for (int t = 0; t < NDT; ++t)
+                    for (int r = 0; r < 16; ++r) o[tt][r] *= alpha;
+            }
+            float psum = 0.f;
+            float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                const bool v = (tmask >> ((r & 3) + 8 * (r >> 2))) & 1u;
+                p[r] = v ? __builtin_amdgcn_exp2f(s[r] - m) : 0.f;
+                psum += p[r];
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            lsum += psum;
 #pragma unroll
-        for (int step = 0; step < 2; ++step) {
-            union { bf16x8 v; uint32_t u[4]; } pf;
+            for (int step = 0; step < 2; ++step) {
+                union { bf16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf2(p[8 * step + 2 * e], p[8 * step + 2 * e + 1]);
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf2(p[8 * step + 2 * e], p[8 * step + 2 * e + 1]);
 #pragma unroll
-            for (int t = 0; t < NDT; ++t) {
-                // A fragment: V^T[32t + r32][key0 + 16*step + 4*hi + {0..3}] and [... + 8 + {0..3}]
-                const bf16_t* vp = VT + (long)(32 * t) * a.Lkp + key0 + 16 * step;
-                union { bf16x8 v; uint2 h2[2]; } vf;
-                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
-                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 8);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[t], 0, 0, 0);
+                for (int tt = 0; tt < NDT; ++tt) {
+                    // A fragment: V^T[32tt + r32][keys 32kh + 16step + 4hi + {0..3}] and [... + 8 + {0..3}]
+                    const char* vp = vb + (32 * tt + r32) * VSTR + (32 * kh + 16 * step + 4 * hi) * 2;
+                    union { bf16x8 v; uint2 h2[2]; } vf;
+                    vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
+                    vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
+                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[tt], 0, 0, 0);
+                }
             }
         }
+        // keep the O^T accumulators resident in AGPRs across iterations (otherwise hipcc round-trips all 16*NDT of them
+        // through VGPRs every tile because the conditional rescale is VALU work)
+#pragma unroll
+        for (int tt = 0; tt < NDT; ++tt) asm volatile("" : "+a"(o[tt]));
+        if (t + 1 < ntiles) WRITE_TILE((t + 1) & 1);
+        __syncthreads();
     }
+
+    // ---- merge the two key halves: (m, l, O) of kh = 1 -> LDS -> kh = 0 ----
+#pragma unroll
+    for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[tt]));
+    float* xo = reinterpret_cast<float*>(smem);                       // [qs][NDT][16][64]
+    float* xml = reinterpret_cast<float*>(smem) + 2 * NDT * 16 * 64;  // [qs][2][32]
+    static_assert(2 * BUF >= (2 * NDT * 16 * 64 + 2 * 2 * 32) * 4, "exchange area must fit the staging buffers");
+    if (kh == 1) {
+#pragma unroll
+        for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xo[((qs * NDT + tt) * 16 + r) * 64 + lane] = o[tt][r];
+        if (hi == 0) {
+            xml[(qs * 2 + 0) * 32 + r32] = m;
+            xml[(qs * 2 + 1) * 32 + r32] = lsum;
+        }
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m2 = xml[(qs * 2 + 0) * 32 + r32], l2 = xml[(qs * 2 + 1) * 32 + r32];
+    const float mm = fmaxf(m, m2);
+    const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
+    const float inv = 1.f / (lsum * a1 + l2 * a2);
+    const float w1 = a1 * inv, w2 = a2 * inv;
+
     // lane holds O^T[d = 32t + (r&3) + 8*(r>>2) + 4*hi][q = q0 + r32]
     const int qrow = q0 + r32;
     if (qrow >= a.Lq) return;
-    const float inv = 1.f / lsum;
     bf16_t* orow = a.out + ((long)b * a.Lq + qrow) * a.ldo + h * DH;
 #pragma unroll
-    for (int t = 0; t < NDT; ++t)
+    for (int tt = 0; tt < NDT; ++tt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int d = 32 * t + 8 * g + 4 * hi;
+            const int d = 32 * tt + 8 * g + 4 * hi;
             if (d < DH) {
+                float v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v4[e] = o[tt][4 * g + e] * w1 + xo[((qs * NDT + tt) * 16 + 4 * g + e) * 64 + lane] * w2;
                 uint2 v;
-                v.x = pack_bf2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv);
-                v.y = pack_bf2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+                v.x = pack_bf2(v4[0], v4[1]);
+                v.y = pack_bf2(v4[2], v4[3]);
                 *reinterpret_cast<uint2*>(orow + d) = v;
             }
         }
 }
 
+#undef LOAD_TILE
+#undef WRITE_TILE
+
 }  // namespace
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
-    dim3 grid((a.Lq + 127) / 128, a.H, a.B);
+    dim3 grid((a.Lq + 63) / 64, a.H, a.B);
     if (a.dh == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_attn<72>), grid, dim3(256), 0, st, a);
 }

@@ -11,16 +11,15 @@ typedef uint16_t bf16_t;  // storage type
 
 #define EZ_WAVE 64
 
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    // round-to-nearest-even, NaN preserved
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// native conversions: one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserving) instead of a branchy bit trick
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -47,7 +46,8 @@ struct GemmArgs {
     int M, N, K;                // K multiple of 64 (padded); N = valid output columns
     int splitk;                 // >= 1 (EPI_PARTIAL only)
     int epi;
-    int tile;                   // 0: 128x128, 1: 128x64
+    int tile;                   // tile / pipeline configuration, see gemm.hip
+    int debug;                  // 0 normal; 1 = stage only (no LDS reads / MFMA); 2 = compute only (no global loads)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 
@@ -134,6 +134,6 @@ struct CfgDdimArgs {
     float guidance_scale, guidance_rescale;  // guidance_scale <= 0: no CFG
     int P, n;            // n = C*L elements per sample
 };
-void launch_cfg_ddim(const CfgDdimArgs& a, hipStream_t st);
+void launch_cfg_ddim(const CfgDdimArgs& a, float* partial /* [P][64][4] scratch */, hipStream_t st);
 void launch_set_int(int* p, int v, int add, hipStream_t st);  // *p = add ? *p + v : v
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu

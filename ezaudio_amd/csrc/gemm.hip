@@ -4,13 +4,16 @@
 // src/models/utils/modules.py:263-277,341-374; src/models/blocks.py:124-128) as one kernel family.
 //
 // gfx950 design:
-//   * v_mfma_f32_32x32x16_bf16, 4 waves (2x2) per workgroup, wave tile (BM/2)x(BN/2), fp32 accumulate
+//   * v_mfma_f32_32x32x16_bf16, WM x WN waves per workgroup, wave tile (BM/WM)x(BN/WN), fp32 accumulate
 //   * BK = 64: one LDS row = 128 B = 8 chunks of 16 B.  Tiles are staged with global_load_lds (16 B per
 //     lane, no VGPR round trip).  The LDS image is lane-linear, so the bank swizzle is applied to the
 //     SOURCE address: chunk c of row r is fetched into slot c ^ ((r>>1)&7), and fragment reads apply the
 //     same involution.  With 128-B rows two consecutive rows span the 64 banks, hence (r>>1): the 16 lanes
 //     of a ds_read_b128 group (rows distinct mod 16) then hit 16 distinct 16-B slots -> conflict free.
-//   * double-buffered LDS, one barrier per K tile: tile t+1 streams in while tile t feeds the MFMAs
+//   * NS-deep LDS ring (NS = 4 for the 128-wide tiles), ONE raw s_barrier per K tile and COUNTED vmcnt waits:
+//     three K tiles of LDS-DMA stay in flight across the barriers, so the ~1 us HBM/L2 latency of a weight tile
+//     is covered by three tiles of MFMA work instead of one (a 2-deep ring measured 300-400 TF on these shapes:
+//     latency bound, one workgroup per CU)
 //   * workgroup -> tile map is XCD aware: the 8 workgroups that the dispatcher puts on one XCD
 //     (block b -> XCD b % 8) walk the M tiles of ONE weight panel, so each weight tile is pulled from
 //     HBM into exactly one L2.
@@ -22,19 +25,19 @@ namespace {
 
 constexpr int BK = 64;
 
-template <int ROWS>
+template <int ROWS, int NT>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int max_row, int k0,
                                            char* lds, int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; ++i) {
-        const int q = i * 256 + tid;
+    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+        const int q = i * NT + tid;
         const int row = q >> 3;
         const int c = q & 7;
         int grow = row0 + row;
         grow = grow < max_row ? grow : max_row;
         const int gc = c ^ ((row >> 1) & 7);
         const bf16_t* src = G + (long)grow * ld + k0 + gc * 8;
-        char* dst = lds + (i * 256 + (tid & ~63)) * 16;
+        char* dst = lds + (i * NT + (tid & ~63)) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
@@ -46,17 +49,33 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* lds, int row, int chunk) 
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
-    constexpr int TM = BM / 2, TN = BN / 2;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else static_assert(N == 0, "unsupported vmcnt");
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // stage s: [A tile | B tile] at smem + s * STAGE_BYTES
+    // NS = ring depth; prefetch distance NS - 1 tiles
+    constexpr int LPT = (BM + BN) * 8 / NT;          // LDS-DMA instructions per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware tile map
     const int tilesM = (a.M + BM - 1) / BM;
@@ -72,6 +91,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
     const int z = blockIdx.z;
     const int kb = nk * z / a.splitk;
     const int ke = nk * (z + 1) / a.splitk;
+    const int nt = ke - kb;
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -81,102 +101,177 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // stage s: [A tile | B tile] at smem + s * STAGE_BYTES
+    auto stage = [&](int t) {  // K tile t (relative) -> ring slot t % NS
+        char* dst = smem + (t % NS) * STAGE_BYTES;
+        stage_tile<BM, NT>(a.A, a.lda, row0, a.M - 1, (kb + t) * BK, dst, tid);
+        stage_tile<BN, NT>(a.W, a.ldw, col0, 0x7fffffff, (kb + t) * BK, dst + A_BYTES, tid);
+    };
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nt) stage(t);
 
-    if (kb < ke) {
-        stage_tile<BM>(a.A, a.lda, row0, a.M - 1, kb * BK, smem, tid);
-        stage_tile<BN>(a.W, a.ldw, col0, 0x7fffffff, kb * BK, smem + A_BYTES, tid);
-    }
     const int r32 = lane & 31, hi = lane >> 5;
-    int cur = 0;
-    for (int kt = kb; kt < ke; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < ke) {
-            char* nxt = smem + (cur ^ 1) * STAGE_BYTES;
-            stage_tile<BM>(a.A, a.lda, row0, a.M - 1, (kt + 1) * BK, nxt, tid);
-            stage_tile<BN>(a.W, a.ldw, col0, 0x7fffffff, (kt + 1) * BK, nxt + A_BYTES, tid);
-        }
-        const char* cA = smem + cur * STAGE_BYTES;
+    for (int t = 0; t < nt; ++t) {
+        // tile t has landed once at most (tiles still allowed in flight) * LPT loads are outstanding
+        const int younger = nt - 1 - t;  // tiles issued after t (capped by the prefetch distance NS - 2 here)
+        if (NS >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
+        else if (NS >= 3 && younger >= 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
+        if (t + NS - 1 < nt) stage(t + NS - 1);  // overwrites the slot of tile t-1
+        const char* cA = smem + (t % NS) * STAGE_BYTES;
         const char* cB = cA + A_BYTES;
+        {
+            // fragment double buffering: the ds_reads of k-step ks+1 are issued before the MFMAs of k-step ks
+            bf16x8 af[2][FM], bfr[2][FN];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[FM], bfr[FN];
+            for (int i = 0; i < FM; ++i) af[0][i] = lds_frag(cA, wm * TM + i * 32 + r32, hi);
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = lds_frag(cA, wm * TM + i * 32 + r32, 2 * ks + hi);
+            for (int j = 0; j < FN; ++j) bfr[0][j] = lds_frag(cB, wn * TN + j * 32 + r32, hi);
+            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = lds_frag(cB, wn * TN + j * 32 + r32, 2 * ks + hi);
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < 3) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+                    for (int i = 0; i < FM; ++i) af[(ks + 1) & 1][i] = lds_frag(cA, wm * TM + i * 32 + r32, 2 * (ks + 1) + hi);
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FN; ++j) bfr[(ks + 1) & 1][j] = lds_frag(cB, wn * TN + j * 32 + r32, 2 * (ks + 1) + hi);
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+                // pin the order: next k-step's LDS reads first, then this k-step's MFMAs (hides the ds_read latency)
+                if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);
+            }
         }
-        cur ^= 1;
+        // keep the accumulators resident in AGPRs across the back edge: without this hipcc copies all of them to VGPRs
+        // and back around every barrier (64+ v_accvgpr moves per K tile, and the copy-out waits for the MFMAs to drain)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
     }
 
-    // ---- epilogue: C layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // ---- epilogue.  The MFMAs compute the TRANSPOSED tile (W fragment as the A operand), so in the 32x32 C layout a
+    // lane owns ONE output row (m = lane & 31) and, per register group g, FOUR CONSECUTIVE output columns
+    // n = 32j + 8g + 4*(lane>>5) + {0..3}: every store is 16 bytes (fp32) or 8 bytes (bf16) per lane instead of 4.
+    const int row_in = lane & 31;
     if constexpr (EPI == EPI_GEGLU) {
         static_assert(FN % 2 == 0, "GEGLU epilogue pairs value/gate fragments");
         bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) {
+            const int row = row0 + wm * TM + i * 32 + row_in;
 #pragma unroll
-            for (int j = 0; j < FN; j += 2) {
-                const int cv = col0 + wn * TN + j * 32 + r32;  // interleaved column of the value
-                const int cg = cv + 32;
-                const int oc = (col0 + wn * TN + j * 32) / 2 + r32;  // output (inner) index
-                if (cv >= a.N) continue;
-                const float bv = a.bias ? a.bias[cv] : 0.f;
-                const float bg = a.bias ? a.bias[cg] : 0.f;
+            for (int j = 0; j < FN; j += 2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < a.M) {
-                        const float v = acc[i][j][r] + bv;
-                        const float g = acc[i][j + 1][r] + bg;
-                        out[(long)row * a.ldo + oc] = f2bf(v * gelu_erf(g));
+                for (int g = 0; g < 4; ++g) {
+                    const int cv = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;  // interleaved column of the value
+                    const int oc = (col0 + wn * TN + j * 32) / 2 + 8 * g + 4 * hi;  // output (inner) index
+                    if (row < a.M && cv < a.N) {
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+                        if (a.bias) {
+                            bv = *reinterpret_cast<const float4*>(a.bias + cv);
+                            bg = *reinterpret_cast<const float4*>(a.bias + cv + 32);
+                        }
+                        const float v0 = acc[i][j][4 * g + 0] + bv.x, g0 = acc[i][j + 1][4 * g + 0] + bg.x;
+                        const float v1 = acc[i][j][4 * g + 1] + bv.y, g1 = acc[i][j + 1][4 * g + 1] + bg.y;
+                        const float v2 = acc[i][j][4 * g + 2] + bv.z, g2 = acc[i][j + 1][4 * g + 2] + bg.z;
+                        const float v3 = acc[i][j][4 * g + 3] + bv.w, g3 = acc[i][j + 1][4 * g + 3] + bg.w;
+                        uint2 o;
+                        o.x = pack_bf2(v0 * gelu_erf(g0), v1 * gelu_erf(g1));
+                        o.y = pack_bf2(v2 * gelu_erf(g2), v3 * gelu_erf(g3));
+                        *reinterpret_cast<uint2*>(out + (long)row * a.ldo + oc) = o;
                     }
                 }
-            }
+        }
     } else {
         float* out = reinterpret_cast<float*>(a.out);
         if constexpr (EPI == EPI_PARTIAL) out += (long)z * a.slab_stride;
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i) {
+            const int row = row0 + wm * TM + i * 32 + row_in;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int col = col0 + wn * TN + j * 32 + r32;
-                if (col >= a.N) continue;
-                float bias = 0.f;
-                if constexpr (EPI == EPI_F32) bias = a.bias ? a.bias[col] : 0.f;
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < a.M) out[(long)row * a.ldo + col] = acc[i][j][r] + bias;
+                for (int g = 0; g < 4; ++g) {
+                    const int col = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;
+                    if (row < a.M && col < a.N) {  // N is a multiple of 4 for every caller
+                        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                        if constexpr (EPI == EPI_F32) {
+                            if (a.bias) {
+                                const float4 b = *reinterpret_cast<const float4*>(a.bias + col);
+                                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                            }
+                        }
+                        *reinterpret_cast<float4*>(out + (long)row * a.ldo + col) = v;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int WM, int WN, int NS, int EPI>
 void launch_t(const GemmArgs& a, hipStream_t st) {
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     dim3 grid(8 * tilesM * ((tilesN + 7) / 8), 1, a.splitk);
-    hipLaunchKernelGGL((k_gemm<BM, BN, EPI>), grid, dim3(256), 0, st, a);
+    constexpr int SMEM = NS * (BM + BN) * 128;
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in attribute once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
+}
+
+// tile / pipeline configurations (GemmArgs.tile); GEGLU needs an even number of 32-column fragments per wave
+//   id  tile     waves  ring  LDS     note
+//   0   128x128  2x2    4     128 KB
+//   1   128x64   2x2    3      72 KB
+//   2   128x128  2x2    2      64 KB  2 workgroups / CU
+//   3   128x64   2x2    4      96 KB
+//   4   128x128  2x2    3      96 KB
+//   5   128x64   2x2    2      48 KB  3 workgroups / CU
+//   6   128x64   4x1    2      48 KB  GEGLU-capable 128x64
+//   7   128x128  4x2    2      64 KB  8 waves
+//   8   256x128  4x2    2      96 KB  8 waves, wave tile 64x64
+//   9   128x128  4x2    3      96 KB  8 waves
+//   10  256x128  4x2    3     144 KB  8 waves
+//   11  256x256  4x2    2     128 KB  8 waves, wave tile 64x128
+template <int EPI>
+void launch_e(const GemmArgs& a, hipStream_t st) {
+    switch (a.tile) {
+        case 0: launch_t<128, 128, 2, 2, 4, EPI>(a, st); return;
+        case 2: launch_t<128, 128, 2, 2, 2, EPI>(a, st); return;
+        case 4: launch_t<128, 128, 2, 2, 3, EPI>(a, st); return;
+        case 6: launch_t<128, 64, 4, 1, 2, EPI>(a, st); return;
+        case 7: launch_t<128, 128, 4, 2, 2, EPI>(a, st); return;
+        case 8: launch_t<256, 128, 4, 2, 2, EPI>(a, st); return;
+        case 9: launch_t<128, 128, 4, 2, 3, EPI>(a, st); return;
+        case 10: launch_t<256, 128, 4, 2, 3, EPI>(a, st); return;
+        case 11: launch_t<256, 256, 4, 2, 2, EPI>(a, st); return;
+        default: break;
+    }
+    if constexpr (EPI != EPI_GEGLU) {
+        switch (a.tile) {
+            case 1: launch_t<128, 64, 2, 2, 3, EPI>(a, st); return;
+            case 3: launch_t<128, 64, 2, 2, 4, EPI>(a, st); return;
+            case 5: launch_t<128, 64, 2, 2, 2, EPI>(a, st); return;
+            default: break;
+        }
+    }
+    launch_t<128, 64, 4, 1, 2, EPI>(a, st);
 }
 
 }  // namespace
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
-    if (a.epi == EPI_GEGLU) {
-        launch_t<128, 128, EPI_GEGLU>(a, st);
-    } else if (a.epi == EPI_PARTIAL) {
-        if (a.tile == 0) launch_t<128, 128, EPI_PARTIAL>(a, st);
-        else launch_t<128, 64, EPI_PARTIAL>(a, st);
-    } else {
-        if (a.tile == 0) launch_t<128, 128, EPI_F32>(a, st);
-        else launch_t<128, 64, EPI_F32>(a, st);
-    }
+    if (a.epi == EPI_GEGLU) launch_e<EPI_GEGLU>(a, st);
+    else if (a.epi == EPI_PARTIAL) launch_e<EPI_PARTIAL>(a, st);
+    else launch_e<EPI_F32>(a, st);
 }

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int MAXJ = 5;  // float4 chunks per lane: D <= 5*256 = 1280
+constexpr int RJ = 2;  // float4 chunks per thread of the 256-thread row kernel: D <= 2048
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, float d) {
@@ -22,20 +22,31 @@ __device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, flo
     *reinterpret_cast<uint2*>(p) = v;
 }
 
+__device__ __forceinline__ float block_sum4(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float t = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return t;
+}
+
+// one 256-thread workgroup per row: <= 2 float4 chunks per thread (D <= 2048), 4 waves per row keep enough loads
+// in flight to stream h + the split-K slabs (a one-wave-per-row version measured 13 us for 25 MB: latency bound)
 __global__ __launch_bounds__(256) void k_row(RowArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.M) return;
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x;
     const int D = a.D;
     const int nc = D >> 2;
     const int b = row / a.L;
     const int slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[b] : 0);
     const float* gate = a.gate ? a.gate + (long)slot * a.gate_slot_stride : nullptr;
 
-    float4 x[MAXJ];
+    float4 x[RJ];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int c = lane + 64 * j;
+    for (int j = 0; j < RJ; ++j) {
+        const int c = tid + 256 * j;
         x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nc) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -66,33 +77,33 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
     if (!a.skip) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) s += x[j].x + x[j].y + x[j].z + x[j].w;  // invalid chunks are zero
-        const float mean = wave_sum(s) / (float)D;
+        for (int j = 0; j < RJ; ++j) s += x[j].x + x[j].y + x[j].z + x[j].w;  // invalid chunks are zero
+        const float mean = block_sum4(s, red) / (float)D;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (lane + 64 * j < nc) {
+        for (int j = 0; j < RJ; ++j)
+            if (tid + 256 * j < nc) {
                 const float dx = x[j].x - mean, dy = x[j].y - mean, dz = x[j].z - mean, dw = x[j].w - mean;
                 q += dx * dx + dy * dy + dz * dz + dw * dw;
             }
-        const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-5f);
+        const float rstd = rsqrtf(block_sum4(q, red) / (float)D + 1e-5f);
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
+        for (int j = 0; j < RJ; ++j) {
+            const int c = tid + 256 * j;
             if (c < nc) {
                 const float4 g = ld4(lg + c * 4), cc = ld4(lc + c * 4);
                 st_bf4(urow + c * 4, (x[j].x - mean) * rstd * g.x + cc.x, (x[j].y - mean) * rstd * g.y + cc.y,
                        (x[j].z - mean) * rstd * g.z + cc.z, (x[j].w - mean) * rstd * g.w + cc.w);
             }
         }
-        for (int i = D + lane; i < a.ld_u; i += 64) urow[i] = 0;
+        for (int i = D + tid; i < a.ld_u; i += 256) urow[i] = 0;
     } else {
         // LayerNorm over the concatenation [h_new | skip (+ controlnet residual)], width 2D  (blocks.py:124-127)
-        float4 y[MAXJ];
+        float4 y[RJ];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
+        for (int j = 0; j < RJ; ++j) {
+            const int c = tid + 256 * j;
             y[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < nc) {
                 float4 v = ld4(a.skip + (long)row * D + c * 4);
@@ -105,21 +116,21 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
             s += x[j].x + x[j].y + x[j].z + x[j].w + y[j].x + y[j].y + y[j].z + y[j].w;
         }
         const float inv = 1.f / (float)(2 * D);
-        const float mean = wave_sum(s) * inv;
+        const float mean = block_sum4(s, red) * inv;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (lane + 64 * j < nc) {
+        for (int j = 0; j < RJ; ++j)
+            if (tid + 256 * j < nc) {
                 float d;
                 d = x[j].x - mean; q += d * d; d = x[j].y - mean; q += d * d;
                 d = x[j].z - mean; q += d * d; d = x[j].w - mean; q += d * d;
                 d = y[j].x - mean; q += d * d; d = y[j].y - mean; q += d * d;
                 d = y[j].z - mean; q += d * d; d = y[j].w - mean; q += d * d;
             }
-        const float rstd = rsqrtf(wave_sum(q) * inv + 1e-5f);
+        const float rstd = rsqrtf(block_sum4(q, red) * inv + 1e-5f);
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = lane + 64 * j;
+        for (int j = 0; j < RJ; ++j) {
+            const int c = tid + 256 * j;
             if (c < nc) {
                 float4 g = ld4(lg + c * 4), cc = ld4(lc + c * 4);
                 st_bf4(urow + c * 4, (x[j].x - mean) * rstd * g.x + cc.x, (x[j].y - mean) * rstd * g.y + cc.y,
@@ -129,67 +140,66 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
                        (y[j].z - mean) * rstd * g.z + cc.z, (y[j].w - mean) * rstd * g.w + cc.w);
             }
         }
-        for (int i = 2 * D + lane; i < a.ld_u; i += 64) urow[i] = 0;
+        for (int i = 2 * D + tid; i < a.ld_u; i += 256) urow[i] = 0;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 4 lanes per (row, head, q|k): each lane owns DH/4 contiguous channels; the LayerNorm reductions are two
+// xor-shuffles, and the RoPE partner channel (i +- DH/2, rotary.py:6-8 half split) lives in lane ^ 2 at the same
+// local index.  Consecutive 4-lane groups walk the heads of one row: fully coalesced fp32 reads.
 template <int DH, int DQK>
-__device__ __forceinline__ void headnorm_one(const float* __restrict__ src, const float* __restrict__ w,
-                                             const float* __restrict__ bb, const float* __restrict__ cs,
-                                             const float* __restrict__ sn, bf16_t* __restrict__ dst) {
-    float v[DH];
+__global__ __launch_bounds__(256) void k_headnorm(HeadNormArgs a) {
+    constexpr int E = DH / 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int sub = idx & 3;
+    const int g = idx >> 2;
+    const int nparts = (a.q_col >= 0 ? 1 : 0) + (a.k_col >= 0 ? 1 : 0);
+    const int M = a.B * a.L;
+    if (g >= M * a.H * nparts) return;
+    const int h = g % a.H;
+    const int part = (g / a.H) % nparts;
+    const int m = g / (a.H * nparts);
+    const bool is_q = (a.q_col >= 0) && part == 0;
+    const int col = is_q ? a.q_col : a.k_col;
+    const float* w = is_q ? a.qn_w : a.kn_w;
+    const float* bb = is_q ? a.qn_b : a.kn_b;
+    bf16_t* dstbase = is_q ? a.q : a.k;
+    const int b = m / a.L, l = m % a.L;
+    const float* src = a.x + (long)m * a.ldx + col + h * DH + sub * E;
+    float v[E];
 #pragma unroll
-    for (int i = 0; i < DH / 4; ++i) {
-        const float4 t = ld4(src + 4 * i);
-        v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+    for (int i = 0; i < E / 2; ++i) {
+        const float2 t = *reinterpret_cast<const float2*>(src + 2 * i);
+        v[2 * i] = t.x; v[2 * i + 1] = t.y;
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < DH; ++i) s += v[i];
+    for (int i = 0; i < E; ++i) s += v[i];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
     const float mean = s * (1.f / DH);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < DH; ++i) { const float d = v[i] - mean; q += d * d; }
+    for (int i = 0; i < E; ++i) { const float d = v[i] - mean; q += d * d; }
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
     const float rstd = rsqrtf(q * (1.f / DH) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < DH; ++i) v[i] = (v[i] - mean) * rstd * w[i] + bb[i];
-    if (cs) {
+    for (int i = 0; i < E; ++i) v[i] = (v[i] - mean) * rstd * w[sub * E + i] + bb[sub * E + i];
+    if (a.rope_cos) {
+        const float* cs = a.rope_cos + (long)l * (DH / 2) + (sub & 1) * E;
+        const float* sn = a.rope_sin + (long)l * (DH / 2) + (sub & 1) * E;
+        const float sign = (sub & 2) ? 1.f : -1.f;  // first half: x1*c - x2*s ; second half: x2*c + x1*s
 #pragma unroll
-        for (int i = 0; i < DH / 2; ++i) {
-            const float c = cs[i], sv = sn[i];
-            const float x1 = v[i], x2 = v[i + DH / 2];
-            v[i] = x1 * c - x2 * sv;            // x*cos + rotate_half(x)*sin, rotate_half = [-x2 | x1]
-            v[i + DH / 2] = x2 * c + x1 * sv;
+        for (int i = 0; i < E; ++i) {
+            const float other = __shfl_xor(v[i], 2, 64);
+            v[i] = v[i] * cs[i] + sign * other * sn[i];
         }
     }
+    bf16_t* dst = dstbase + (((long)b * a.H + h) * a.Lp + l) * DQK + sub * E;
 #pragma unroll
-    for (int i = 0; i < DQK / 8; ++i) {
-        uint4 o;
-        uint32_t* op = reinterpret_cast<uint32_t*>(&o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i0 = 8 * i + 2 * e;
-            op[e] = pack_bf2(i0 < DH ? v[i0 < DH ? i0 : 0] : 0.f, i0 + 1 < DH ? v[i0 + 1 < DH ? i0 + 1 : 0] : 0.f);
-        }
-        *reinterpret_cast<uint4*>(dst + 8 * i) = o;
-    }
-}
-
-template <int DH, int DQK>
-__global__ __launch_bounds__(256) void k_headnorm(HeadNormArgs a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int M = a.B * a.L;
-    if (idx >= M * a.H) return;
-    const int m = idx / a.H, h = idx % a.H;
-    const int b = m / a.L, l = m % a.L;
-    const float* cs = a.rope_cos ? a.rope_cos + (long)l * (DH / 2) : nullptr;
-    const float* sn = a.rope_sin ? a.rope_sin + (long)l * (DH / 2) : nullptr;
-    const long dsto = (((long)b * a.H + h) * a.Lp + l) * DQK;
-    if (a.q_col >= 0)
-        headnorm_one<DH, DQK>(a.x + (long)m * a.ldx + a.q_col + h * DH, a.qn_w, a.qn_b, cs, sn, a.q + dsto);
-    if (a.k_col >= 0)
-        headnorm_one<DH, DQK>(a.x + (long)m * a.ldx + a.k_col + h * DH, a.kn_w, a.kn_b, cs, sn, a.k + dsto);
+    for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
 }
 
 __global__ __launch_bounds__(256) void k_vtranspose(HeadNormArgs a, int DV) {
@@ -239,9 +249,10 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs a) {
     a.out[idx] = f2bf(v);
 }
 
-// out[b][co][l] = bias[co] + sum_{ci,k} w[co][ci][k] * y[b][l+k-1][ci]
+// out[b][co][l] = bias[co] + sum_{ci,k} w[co][ci][k] * y[b][l+k-1][ci]      (fp32 FMA: this is the model output)
+// workgroup = 8 frames x all C channels of one batch element (B*L/8 workgroups); thread = 1 frame x C/32 channels
 __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
-    constexpr int TL = 32;
+    constexpr int TL = 8;
     extern __shared__ float sy[];  // [(TL+2)][C+1]
     const int C = a.C;
     const int ltiles = (a.L + TL - 1) / TL;
@@ -253,10 +264,10 @@ __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
         sy[r * (C + 1) + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
     }
     __syncthreads();
-    const int ll = threadIdx.x & 31;
-    const int cg = threadIdx.x >> 5;  // 8 groups
+    const int ll = threadIdx.x & 7;
+    const int cg = threadIdx.x >> 3;  // 32 groups
     const int l = l0 + ll;
-    for (int co = cg; co < C; co += 8) {
+    for (int co = cg; co < C; co += 32) {
         float acc = a.b[co];
         const float* wr = a.w + (long)co * C * 3;
         for (int ci = 0; ci < C; ++ci) {
@@ -346,54 +357,57 @@ __global__ void k_rope_table(float* cosT, float* sinT, int max_len, int dh) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[w] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int i = 0; i < nw; ++i) t += red[i];
-    return t;
+// CFG + guidance rescale + DDIM update in two grid-wide passes (a single workgroup per sample measured 118 us):
+//   k_cfg_stats : per (sample, chunk) partial sums  S(c), S(c^2), S(g), S(g^2)   with g = u + s (c - u)
+//   k_cfg_apply : every workgroup re-reduces the NB partials in double (deterministic, no atomics), forms
+//                 std(c)/std(g) with torch.std's unbiased normalisation, and updates its chunk of the latent.
+constexpr int CFG_NB = 64;
+
+__global__ __launch_bounds__(256) void k_cfg_stats(CfgDdimArgs a, float* partial) {
+    __shared__ float red[4];
+    const int p = blockIdx.y, blk = blockIdx.x;
+    const int n = a.n;
+    const float* pc = a.pred + (long)p * n;
+    const float* pu = a.pred + (long)(a.P + p) * n;
+    const float gs = a.guidance_scale;
+    float s1 = 0.f, q1 = 0.f, s2 = 0.f, q2 = 0.f;
+    for (int i = blk * 256 + threadIdx.x; i < n; i += CFG_NB * 256) {
+        const float c = pc[i], u = pu[i];
+        const float g = u + gs * (c - u);
+        s1 += c; q1 += c * c; s2 += g; q2 += g * g;
+    }
+    s1 = block_sum4(s1, red); q1 = block_sum4(q1, red); s2 = block_sum4(s2, red); q2 = block_sum4(q2, red);
+    if (threadIdx.x == 0) {
+        float* o = partial + ((long)p * CFG_NB + blk) * 4;
+        o[0] = s1; o[1] = q1; o[2] = s2; o[3] = q2;
+    }
 }
 
-__global__ __launch_bounds__(1024) void k_cfg_ddim(CfgDdimArgs a) {
-    __shared__ float red[16];
-    const int p = blockIdx.x;
+__global__ __launch_bounds__(256) void k_cfg_apply(CfgDdimArgs a, const float* partial) {
+    const int p = blockIdx.y, blk = blockIdx.x;
     const int n = a.n;
     const int step = *a.cur_step;
     const float* cf = a.coef + step * 8;
     const float sa = cf[0], sb = cf[1], cx0 = cf[2], cdir = cf[3], sigma = cf[4];
     const bool cfg = a.guidance_scale > 0.f;
+    const bool rescale = cfg && a.guidance_rescale > 0.f;
+    float ratio = 1.f;
+    if (rescale) {
+        double s1 = 0, q1 = 0, s2 = 0, q2 = 0;
+        for (int i = 0; i < CFG_NB; ++i) {
+            const float* o = partial + ((long)p * CFG_NB + i) * 4;
+            s1 += o[0]; q1 += o[1]; s2 += o[2]; q2 += o[3];
+        }
+        const double v1 = (q1 - s1 * s1 / n) / (n - 1);  // torch.std default: unbiased
+        const double v2 = (q2 - s2 * s2 / n) / (n - 1);
+        ratio = (float)(sqrt(v1) / sqrt(v2));
+    }
     const float* pc = a.pred + (long)p * n;
     const float* pu = cfg ? a.pred + (long)(a.P + p) * n : nullptr;
     float* lat = a.latents + (long)p * n;
     const float* z = a.noise ? a.noise + ((long)step * a.P + p) * n : nullptr;
-    const float gs = a.guidance_scale;
-    float ratio = 1.f;
-    const bool rescale = cfg && a.guidance_rescale > 0.f;
-    if (rescale) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float c = pc[i], u = pu[i];
-            s1 += c;
-            s2 += u + gs * (c - u);
-        }
-        const float m1 = block_sum(s1, red) / (float)n;
-        const float m2 = block_sum(s2, red) / (float)n;
-        float q1 = 0.f, q2 = 0.f;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const float c = pc[i], u = pu[i];
-            const float g = u + gs * (c - u);
-            q1 += (c - m1) * (c - m1);
-            q2 += (g - m2) * (g - m2);
-        }
-        const float v1 = block_sum(q1, red) / (float)(n - 1);  // torch.std default: unbiased
-        const float v2 = block_sum(q2, red) / (float)(n - 1);
-        ratio = sqrtf(v1) / sqrtf(v2);
-    }
-    const float phi = a.guidance_rescale;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float gs = a.guidance_scale, phi = a.guidance_rescale;
+    for (int i = blk * 256 + threadIdx.x; i < n; i += CFG_NB * 256) {
         float v = pc[i];
         if (cfg) {
             const float u = pu[i];
@@ -430,13 +444,13 @@ __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, 
 
 // ---------------------------------------------------------------------------------------------------
 void launch_row(const RowArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_row, dim3((a.M + 3) / 4), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_row, dim3(a.M), dim3(256), 0, st, a);
 }
 
 void launch_headnorm(const HeadNormArgs& a, hipStream_t st) {
     const int M = a.B * a.L;
     if (a.q_col >= 0 || a.k_col >= 0) {
-        const int nthr = M * a.H;
+        const int nthr = M * a.H * 4 * ((a.q_col >= 0 ? 1 : 0) + (a.k_col >= 0 ? 1 : 0));
         if (a.dh == 64) hipLaunchKernelGGL((k_headnorm<64, 64>), dim3((nthr + 255) / 256), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_headnorm<72, 80>), dim3((nthr + 255) / 256), dim3(256), 0, st, a);
     }
@@ -453,8 +467,8 @@ void launch_assemble(const AssembleArgs& a, hipStream_t st) {
 }
 
 void launch_final_conv(const FinalConvArgs& a, hipStream_t st) {
-    const int ltiles = (a.L + 31) / 32;
-    const size_t sh = (size_t)34 * (a.C + 1) * sizeof(float);
+    const int ltiles = (a.L + 7) / 8;
+    const size_t sh = (size_t)10 * (a.C + 1) * sizeof(float);
     hipLaunchKernelGGL(k_final_conv, dim3(a.B * ltiles), dim3(256), sh, st, a);
 }
 
@@ -473,8 +487,10 @@ void launch_rope_table(float* cosT, float* sinT, int max_len, int dh, hipStream_
     hipLaunchKernelGGL(k_rope_table, dim3((total + 255) / 256), dim3(256), 0, st, cosT, sinT, max_len, dh);
 }
 
-void launch_cfg_ddim(const CfgDdimArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_cfg_ddim, dim3(a.P), dim3(1024), 0, st, a);
+void launch_cfg_ddim(const CfgDdimArgs& a, float* partial, hipStream_t st) {
+    if (a.guidance_scale > 0.f && a.guidance_rescale > 0.f)
+        hipLaunchKernelGGL(k_cfg_stats, dim3(CFG_NB, a.P), dim3(256), 0, st, a, partial);
+    hipLaunchKernelGGL(k_cfg_apply, dim3(CFG_NB, a.P), dim3(256), 0, st, a, partial);
 }
 
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st) {

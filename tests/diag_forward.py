@@ -32,7 +32,7 @@ def main(size='xs', L=96, Lc=20, t=499):
     B, D, H = 2, cfg['embed_dim'], cfg['num_heads']
     dh = D // H
     M = B * L
-    Lp = (L + 31) // 32 * 32
+    Lp = (L + 63) // 64 * 64
     DQK = 64 if dh == 64 else 80
     DV = 64 if dh == 64 else 96
     ldD = (D + 63) // 64 * 64
@@ -93,7 +93,7 @@ def main(size='xs', L=96, Lc=20, t=499):
     run(11)
     q2 = b16('q', (B, H, Lp, DQK))[:, :, :L, :dh]
     rows.append(('cross q', rel(q2, T[f'{pfx}:xq'])))
-    Lcp = (Lc + 31) // 32 * 32
+    Lcp = (Lc + 63) // 64 * 64
     kc = b16('kc', (cfg['depth'] + 1, B, H, Lcp, DQK))[0, :, :, :Lc, :dh]
     vct = b16('vct', (cfg['depth'] + 1, B, H, DV, Lcp))[0, :, :, :dh, :Lc]
     rows.append(('cross k (ctx path)', rel(kc, T[f'{pfx}:xk'])))

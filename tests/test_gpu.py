@@ -50,13 +50,26 @@ def t_(a, dev='cuda:0'):
 # ---------------------------------------------------------------------------------------------------
 # kernel level
 # ---------------------------------------------------------------------------------------------------
+# variant = tile_config * 4 + epilogue; epilogue 0 = fp32 (+bias), 1 = split-K partial slabs, 2 = GEGLU
+# tile_config: 0 128x128 ring 4 | 1 128x64 ring 3 | 2 128x128 ring 2 | 3 128x64 ring 4 | 4 128x128 ring 3 | 5 128x64 ring 2
 @pytest.mark.parametrize('M,N,K,variant,splitk', [
-    (1000, 1152, 1152, 0, 1),   # EPI_F32, 128x128
-    (1000, 1152, 1152, 1, 1),   # EPI_F32, 128x64
-    (200, 300, 192, 1, 1),      # ragged M and N
-    (1000, 1152, 4608, 3, 4),   # EPI_PARTIAL 128x64 split-K 4 (MLP-out shape)
-    (1000, 1152, 1152, 2, 3),   # EPI_PARTIAL 128x128 split-K 3
-    (130, 128, 64, 1, 1),       # single K tile
+    (1000, 1152, 1152, 0 * 4 + 0, 1),
+    (1000, 1152, 1152, 1 * 4 + 0, 1),
+    (1000, 3456, 1152, 2 * 4 + 0, 1),
+    (1000, 1152, 1152, 3 * 4 + 0, 1),
+    (1000, 1152, 1152, 4 * 4 + 0, 1),
+    (1000, 1152, 1152, 5 * 4 + 0, 1),
+    (200, 300, 192, 1 * 4 + 0, 1),      # ragged M and N
+    (1000, 1152, 4608, 1 * 4 + 1, 4),   # split-K 4 (MLP-out shape)
+    (1000, 1152, 1152, 0 * 4 + 1, 3),   # split-K 3: 6 K tiles per slice
+    (1000, 1152, 1152, 3 * 4 + 1, 9),   # 2 K tiles per slice: shorter than the ring
+    (130, 128, 64, 1 * 4 + 0, 1),       # single K tile
+    (130, 128, 128, 0 * 4 + 0, 1),      # two K tiles
+    (300, 256, 192, 4 * 4 + 1, 2),      # uneven split: 1 + 2 tiles
+    (1000, 1152, 1152, 6 * 4 + 0, 1),   # 128x64, waves 4x1
+    (1000, 1152, 1152, 7 * 4 + 1, 2),   # 128x128, 8 waves
+    (1000, 1152, 1152, 8 * 4 + 0, 1),   # 256x128, 8 waves
+    (1000, 1152, 1152, 9 * 4 + 1, 3),   # 128x128, 8 waves, ring 3
 ])
 def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     g = torch.Generator().manual_seed(M + N + K)
@@ -68,7 +81,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     ref = A.float().double() @ W[:N].float().double().T
     Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
     Mp = (M + 127) // 128 * 128
-    epi = variant // 2
+    epi = variant % 4
     if epi == 0:
         out = torch.full((M, N), float('nan'), device=dev)
         rc = lib.ezdit_test_gemm(None, variant, Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), out.data_ptr(), N, M, N, K, 1, None)
@@ -86,7 +99,8 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-def test_gemm_geglu_epilogue(lib, dev):
+@pytest.mark.parametrize('tile', [2, 6, 8])
+def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 512
     g = torch.Generator().manual_seed(7)
     A = torch.randn(M, D, generator=g).to(torch.bfloat16)
@@ -99,14 +113,14 @@ def test_gemm_geglu_epilogue(lib, dev):
     ref = val * torch.nn.functional.gelu(gate)
     out = torch.zeros(M, inner, dtype=torch.bfloat16, device=dev)
     Ad, Wd, bd = A.to(dev), Wi.to(dev), bi.to(dev)   # keep the device tensors alive across the launch
-    rc = lib.ezdit_test_gemm(None, 4, Ad.data_ptr(), D, Wd.data_ptr(), D, bd.data_ptr(), out.data_ptr(),
+    rc = lib.ezdit_test_gemm(None, tile * 4 + 2, Ad.data_ptr(), D, Wd.data_ptr(), D, bd.data_ptr(), out.data_ptr(),
                              inner, M, 2 * inner, D, 1, None)
     assert rc == 0
     torch.cuda.synchronize()
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < 4e-3  # one bf16 rounding of the output
 
 
-@pytest.mark.parametrize('size,Lq,Lk,masked', [('xs', 96, 96, False), ('xs64', 96, 96, False), ('xs', 500, 100, True),
+@pytest.mark.parametrize('size,Lq,Lk,masked', [('xs', 96, 96, False), ('xs64', 96, 96, False), ('xs', 500, 100, True), ('xs', 64, 20, True),
                                                ('xs64', 500, 100, True), ('xs', 500, 500, False), ('xs64', 77, 500, False)])
 def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked):
     m = get_model(size, 1)
@@ -115,7 +129,7 @@ def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked):
     dh = D // H
     DQK, DV = (64, 64) if dh == 64 else (80, 96)
     B = 2
-    Lqp, Lkp = (Lq + 31) // 32 * 32, (Lk + 31) // 32 * 32
+    Lqp, Lkp = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
     g = torch.Generator().manual_seed(Lq * 7 + Lk)
     q = torch.randn(B, H, Lq, dh, generator=g).to(torch.bfloat16)
     k = torch.randn(B, H, Lk, dh, generator=g).to(torch.bfloat16)
