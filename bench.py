@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
-GEGLU_VARIANT = 0 * 4 + 2   # ezdit_test_gemm: tile config 0 (what the step uses), GEGLU epilogue
+GEGLU_VARIANT = 12 * 4 + 2  # ezdit_test_gemm: tile config 12 (128x288, 12 waves: what the step uses at M <= 2048), GEGLU epilogue
 
 
 def model_section(size):
@@ -49,7 +49,7 @@ def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
     inner = 4 * D
     dev = unet.device
     A = torch.randn(M, D, device=dev).to(torch.bfloat16)
-    W = (torch.randn(2 * inner, D, device=dev) / D ** 0.5).to(torch.bfloat16)
+    W = (torch.randn(2 * inner + 288, D, device=dev) / D ** 0.5).to(torch.bfloat16)
     bias = torch.zeros(2 * inner, device=dev)
     out = torch.empty(M, inner, dtype=torch.bfloat16, device=dev)
     lib = unet.lib
@@ -66,7 +66,7 @@ def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     fl = 2.0 * M * D * 2 * inner
-    return dict(name='k_gemm<128,128,GEGLU> (mlp.net.0.proj + GEGLU)', launches_per_step=cfg['depth'] + 1,
+    return dict(name='k_gemm<128,288,4x3 waves,GEGLU> (mlp.net.0.proj + GEGLU epilogue)', launches_per_step=cfg['depth'] + 1,
                 flops_per_launch=fl, avg_us=us, tflops=fl / us / 1e6, frac=fl / us / 1e6 / PEAK_BF16_TFLOPS,
                 note='back-to-back launches, includes launch gaps')
 
@@ -114,8 +114,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        from ezaudio_amd.dist import init_from_env
+        init_from_env('nccl', dev)
 
     from ezaudio_amd import MaskDiT
     from ezaudio_amd.sampler import LatentSampler
@@ -174,9 +174,10 @@ def main():
     run_steps(a.steps)
     e1.record(smp.stream)
     lat = smp.finish()
-    if dist:  # the only collective of the job: gather the finished latents (1 MB per rank)
-        out = [torch.empty_like(lat) for _ in range(world)]
-        dist.all_gather(out, lat)
+    if dist:  # the only collective of the job: gather the finished latents (256 KB per sample)
+        from ezaudio_amd.dist import gather_samples
+        all_lat = gather_samples(lat, P * world)
+        assert all_lat.shape[0] == P * world
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -31,7 +31,7 @@ class EzditDdimCoef(C.Structure):
 
 
 P_F32, P_BF16 = 0, 1
-T_NONE, T_GEGLU32 = 0, 1
+T_NONE, T_GEGLU8 = 0, 1
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 PROTOTYPES = {
@@ -74,6 +74,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime: import it FIRST so that this library binds to the runtime instance torch
+    # initialises (loading us first was observed to leave the library with "no ROCm-capable device")
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EzditError(f'{LIB_PATH} is missing: the HIP extension has not been built '
                          f'(python -m ezaudio_amd.build). There is no CPU fallback.')

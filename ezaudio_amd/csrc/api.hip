@@ -72,6 +72,7 @@ struct ezdit_handle {
     hipGraph_t graph = nullptr;
 
     int launches = 0;
+    int geglu_tile = -1;  // tuning override (tests/bench)
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
 
     template <typename T>
@@ -174,7 +175,7 @@ void build_params(ezdit_handle* h) {
         for (int b = 0; b < h->nblk; ++b) add_param(h, bn(b, v.name), {blk_prefix(h, b) + "." + v.key}, F, 1, v.n);
     for (int b = 0; b < h->nblk; ++b) {
         const std::string p = blk_prefix(h, b);
-        add_param(h, bn(b, "b1"), {p + ".mlp.net.0.proj.bias"}, F, 1, 2 * I, EZDIT_T_GEGLU32);
+        add_param(h, bn(b, "b1"), {p + ".mlp.net.0.proj.bias"}, F, 1, 2 * I, EZDIT_T_GEGLU8);
         add_param(h, bn(b, "lora_a"), {p + ".adaln.lora_a.weight"}, F, r6, D);
         add_param(h, bn(b, "lora_b"), {p + ".adaln.lora_b.weight"}, F, 6 * D, r6);
         add_param(h, bn(b, "wqkv"), {p + ".attn.to_q.weight", p + ".attn.to_k.weight", p + ".attn.to_v.weight"}, Bf, 3 * D, D);
@@ -182,7 +183,7 @@ void build_params(ezdit_handle* h) {
         add_param(h, bn(b, "wq2"), {p + ".cross_attn.to_q.weight"}, Bf, D, D);
         add_param(h, bn(b, "wkv2"), {p + ".cross_attn.to_k.weight", p + ".cross_attn.to_v.weight"}, Bf, 2 * D, D);
         add_param(h, bn(b, "wo2"), {p + ".cross_attn.proj.weight"}, Bf, D, D);
-        add_param(h, bn(b, "w1"), {p + ".mlp.net.0.proj.weight"}, Bf, 2 * I, D, EZDIT_T_GEGLU32);
+        add_param(h, bn(b, "w1"), {p + ".mlp.net.0.proj.weight"}, Bf, 2 * I, D, EZDIT_T_GEGLU8);
         add_param(h, bn(b, "w2"), {p + ".mlp.net.2.weight"}, Bf, D, I);
         if (b > h->nhalf) {
             add_param(h, bn(b, "snw"), {p + ".skip_norm.weight"}, F, 1, 2 * D);
@@ -267,6 +268,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.lda = lda;
     g.W = h->w<bf16_t>(wname);
     g.ldw = h->pld(wname);
+    g.wrows = (int)h->params[h->pidx.at(wname)].rows_pad;
     g.bias = bias;
     g.out = out;
     g.ldo = ldo;
@@ -293,7 +295,7 @@ int pick_splitk(int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = K / 64;
     if (tiles >= 256) return 1;
-    int s = nk >= 36 ? 4 : 2;
+    int s = nk >= 72 ? 4 : nk >= 36 ? 2 : 1;   // fewer slabs = less traffic for the row kernel that reduces them
     if (s > nk) s = nk;
     if (s < 1) s = 1;
     return s;
@@ -615,7 +617,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         row(1, hA, hA, s, h->w<float>(bn(b, "bo2")), nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU, tile_for(M, false));
+        gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU,
+             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 12 : 2));
         STOPCHK();
         s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
@@ -739,14 +742,12 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     (void)h;
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
-    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.bias = bias; g.out = out; g.ldo = ldo;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
-    if (g.epi > EPI_GEGLU || g.tile > 11) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
-    if (g.epi == EPI_GEGLU && (g.tile == 1 || g.tile == 3 || g.tile == 5))
-        return fail(EZDIT_E_INVALID, "GEGLU epilogue needs a tile config with >= 2 column fragments per wave");
+    if (g.epi > EPI_GEGLU || g.tile > 13) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     launch_gemm(g, (hipStream_t)stream);
     return EZDIT_OK;

@@ -34,13 +34,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
-    EPI_GEGLU = 2     // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 32/32
+    EPI_GEGLU = 2     // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
 };
 
 struct GemmArgs {
     const bf16_t* A; int lda;   // [M][lda] bf16, row-major, K contiguous, zero padded to K_pad
-    const bf16_t* W; int ldw;   // [N_pad][ldw] bf16 (nn.Linear layout: out x in)
-    const float* bias;          // nullable; EPI_GEGLU: bias in the interleaved row order
+    const bf16_t* W; int ldw;   // [wrows][ldw] bf16 (nn.Linear layout: out x in), rows >= N zero padded
+    int wrows;                  // allocated rows of W (tile loads clamp to wrows - 1)
+    const float* bias;          // nullable; EPI_GEGLU: bias in the same interleaved order
     void* out; int ldo;
     long slab_stride;           // EPI_PARTIAL: elements between split-K slabs
     int M, N, K;                // K multiple of 64 (padded); N = valid output columns

@@ -25,35 +25,56 @@ namespace {
 
 constexpr int BK = 64;
 
+// Per-thread byte offsets of the 16-byte chunks this thread stages for one operand tile (K offset excluded): computed
+// ONCE per workgroup.  Chunk q of the tile = (row q>>3, 16-byte slot q&7); the slot is filled from global chunk
+// slot ^ ((row>>1)&7) (source-side swizzle, see header).  In the K loop a load is then  uniform base (SGPR) + this 32-bit
+// offset (VGPR): no per-load VALU address arithmetic.
 template <int ROWS, int NT>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, int ld, int row0, int max_row, int k0,
-                                           char* lds, int tid) {
+__device__ __forceinline__ void stage_offsets(uint32_t (&off)[(ROWS * 8 + NT - 1) / NT], int ld, int row0, int max_row, int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / NT; ++i) {
+    for (int i = 0; i < (ROWS * 8 + NT - 1) / NT; ++i) {
         const int q = i * NT + tid;
         const int row = q >> 3;
         const int c = q & 7;
         int grow = row0 + row;
         grow = grow < max_row ? grow : max_row;
         const int gc = c ^ ((row >> 1) & 7);
-        const bf16_t* src = G + (long)grow * ld + k0 + gc * 8;
-        char* dst = lds + (i * NT + (tid & ~63)) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        off[i] = (uint32_t)(grow * ld + gc * 8) * 2u;
     }
 }
 
-__device__ __forceinline__ bf16x8 lds_frag(const char* lds, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_tile(const char* __restrict__ gbase /* uniform, K offset applied */,
+                                           const uint32_t (&off)[(ROWS * 8 + NT - 1) / NT], char* lds_wave /* uniform */, int tid) {
+#pragma unroll
+    for (int i = 0; i < (ROWS * 8 + NT - 1) / NT; ++i) {
+        if ((ROWS * 8) % NT != 0 && i * NT + tid >= ROWS * 8) break;  // ragged last pass (768-thread configs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off[i]),
+                                         (__attribute__((address_space(3))) void*)(lds_wave + i * NT * 16), 16, 0, 0);
+    }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
+// fp32-rounding class and far below the bf16 rounding of the result): ~14 VALU instead of ~40 for erff -- the GEGLU
+// epilogue evaluates it 16x per lane and the kernel is instruction-issue bound.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = 1.0f - p * t * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -101,41 +122,69 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- loop-invariant addressing ----
+    uint32_t aoff[(BM * 8 + NT - 1) / NT], boff[(BN * 8 + NT - 1) / NT];
+    stage_offsets<BM, NT>(aoff, a.lda, row0, a.M - 1, tid);
+    stage_offsets<BN, NT>(boff, a.ldw, col0, a.wrows - 1, tid);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably wave-uniform -> SGPR
+    const char* gA = reinterpret_cast<const char*>(a.A) + (long)kb * BK * 2;
+    const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
     auto stage = [&](int t) {  // K tile t (relative) -> ring slot t % NS
-        char* dst = smem + (t % NS) * STAGE_BYTES;
-        stage_tile<BM, NT>(a.A, a.lda, row0, a.M - 1, (kb + t) * BK, dst, tid);
-        stage_tile<BN, NT>(a.W, a.ldw, col0, 0x7fffffff, (kb + t) * BK, dst + A_BYTES, tid);
+        char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
+        stage_tile<BM, NT>(gA + t * (BK * 2), aoff, dst, tid);
+        stage_tile<BN, NT>(gW + t * (BK * 2), boff, dst + A_BYTES, tid);
     };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nt) stage(t);
 
     const int r32 = lane & 31, hi = lane >> 5;
+    // fragment read offsets: row r32 of a 32-row fragment, k-step ks -> 16-byte slot (2ks + hi) ^ ((r32>>1)&7).  Fragment
+    // bases are multiples of 32 rows, so one set of four per-lane offsets serves every A and W fragment (the rest of the
+    // address is wave-uniform and folds into the ds_read immediate).
+    uint32_t foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = r32 * 128 + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4);
+    const int a_base = wm * TM * 128, b_base = A_BYTES + wn * TN * 128;
+
     for (int t = 0; t < nt; ++t) {
         // tile t has landed once at most (tiles still allowed in flight) * LPT loads are outstanding
         const int younger = nt - 1 - t;  // tiles issued after t (capped by the prefetch distance NS - 2 here)
-        if (NS >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
-        else if (NS >= 3 && younger >= 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
+        if constexpr (((BM + BN) * 8) % NT != 0) {
+            // ragged staging (768-thread configs): waves below the remainder issue one more LDS-DMA per tile
+            constexpr int REM_WAVES = (((BM * 8) % NT) + ((BN * 8) % NT)) / 64;
+            static_assert(((BM * 8) % NT == 0) || ((BN * 8) % NT == 0), "at most one ragged operand");
+            constexpr int LO = (BM * 8) / NT + (BN * 8) / NT;
+            if (NS >= 3 && younger >= 1) {
+                if (wave_u < REM_WAVES) wait_vmcnt<LO + 1>(); else wait_vmcnt<LO>();
+            } else {
+                wait_vmcnt<0>();
+            }
+        } else {
+            if (NS >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
+            else if (NS >= 3 && younger >= 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
         if (t + NS - 1 < nt) stage(t + NS - 1);  // overwrites the slot of tile t-1
-        const char* cA = smem + (t % NS) * STAGE_BYTES;
-        const char* cB = cA + A_BYTES;
+        const char* cT = smem + (t % NS) * STAGE_BYTES;
         {
             // fragment double buffering: the ds_reads of k-step ks+1 are issued before the MFMAs of k-step ks
             bf16x8 af[2][FM], bfr[2][FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[0][i] = lds_frag(cA, wm * TM + i * 32 + r32, hi);
+            for (int i = 0; i < FM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + a_base + i * 4096);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[0][j] = lds_frag(cB, wn * TN + j * 32 + r32, hi);
+            for (int j = 0; j < FN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + b_base + j * 4096);
             __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 if (ks < 3) {
 #pragma unroll
-                    for (int i = 0; i < FM; ++i) af[(ks + 1) & 1][i] = lds_frag(cA, wm * TM + i * 32 + r32, 2 * (ks + 1) + hi);
+                    for (int i = 0; i < FM; ++i)
+                        af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + a_base + i * 4096);
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) bfr[(ks + 1) & 1][j] = lds_frag(cB, wn * TN + j * 32 + r32, 2 * (ks + 1) + hi);
+                    for (int j = 0; j < FN; ++j)
+                        bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + b_base + j * 4096);
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
@@ -160,27 +209,28 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     // n = 32j + 8g + 4*(lane>>5) + {0..3}: every store is 16 bytes (fp32) or 8 bytes (bf16) per lane instead of 4.
     const int row_in = lane & 31;
     if constexpr (EPI == EPI_GEGLU) {
-        static_assert(FN % 2 == 0, "GEGLU epilogue pairs value/gate fragments");
+        // W rows are interleaved in groups of 8 (8 value rows, then their 8 gate rows): in the C layout above the
+        // value of inner index c sits in register group g (even) and its gate in group g + 1 of the SAME lane.
         bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int row = row0 + wm * TM + i * 32 + row_in;
 #pragma unroll
-            for (int j = 0; j < FN; j += 2)
+            for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int cv = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;  // interleaved column of the value
-                    const int oc = (col0 + wn * TN + j * 32) / 2 + 8 * g + 4 * hi;  // output (inner) index
+                for (int g = 0; g < 4; g += 2) {
+                    const int cv = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;       // packed column of the value
+                    const int oc = (col0 + wn * TN + j * 32 + 8 * g) / 2 + 4 * hi;  // output (inner) index
                     if (row < a.M && cv < a.N) {
                         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
                         if (a.bias) {
                             bv = *reinterpret_cast<const float4*>(a.bias + cv);
-                            bg = *reinterpret_cast<const float4*>(a.bias + cv + 32);
+                            bg = *reinterpret_cast<const float4*>(a.bias + cv + 8);
                         }
-                        const float v0 = acc[i][j][4 * g + 0] + bv.x, g0 = acc[i][j + 1][4 * g + 0] + bg.x;
-                        const float v1 = acc[i][j][4 * g + 1] + bv.y, g1 = acc[i][j + 1][4 * g + 1] + bg.y;
-                        const float v2 = acc[i][j][4 * g + 2] + bv.z, g2 = acc[i][j + 1][4 * g + 2] + bg.z;
-                        const float v3 = acc[i][j][4 * g + 3] + bv.w, g3 = acc[i][j + 1][4 * g + 3] + bg.w;
+                        const float v0 = acc[i][j][4 * g + 0] + bv.x, g0 = acc[i][j][4 * g + 4] + bg.x;
+                        const float v1 = acc[i][j][4 * g + 1] + bv.y, g1 = acc[i][j][4 * g + 5] + bg.y;
+                        const float v2 = acc[i][j][4 * g + 2] + bv.z, g2 = acc[i][j][4 * g + 6] + bg.z;
+                        const float v3 = acc[i][j][4 * g + 3] + bv.w, g3 = acc[i][j][4 * g + 7] + bg.w;
                         uint2 o;
                         o.x = pack_bf2(v0 * gelu_erf(g0), v1 * gelu_erf(g1));
                         o.y = pack_bf2(v2 * gelu_erf(g2), v3 * gelu_erf(g3));
@@ -229,7 +279,7 @@ void launch_t(const GemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
 }
 
-// tile / pipeline configurations (GemmArgs.tile); GEGLU needs an even number of 32-column fragments per wave
+// tile / pipeline configurations (GemmArgs.tile)
 //   id  tile     waves  ring  LDS     note
 //   0   128x128  2x2    4     128 KB
 //   1   128x64   2x2    3      72 KB
@@ -243,6 +293,8 @@ void launch_t(const GemmArgs& a, hipStream_t st) {
 //   9   128x128  4x2    3      96 KB  8 waves
 //   10  256x128  4x2    3     144 KB  8 waves
 //   11  256x256  4x2    2     128 KB  8 waves, wave tile 64x128
+//   12  128x288  4x3    2     104 KB  12 waves: N = 9216 -> 8 x 32 = 256 workgroups at M = 1000 (89 flop/B ingest)
+//   13  128x288  4x3    3     156 KB  same, ring 3 (one whole tile in flight behind the one being consumed)
 template <int EPI>
 void launch_e(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
@@ -255,15 +307,15 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
         case 9: launch_t<128, 128, 4, 2, 3, EPI>(a, st); return;
         case 10: launch_t<256, 128, 4, 2, 3, EPI>(a, st); return;
         case 11: launch_t<256, 256, 4, 2, 2, EPI>(a, st); return;
+        case 12: launch_t<128, 288, 4, 3, 2, EPI>(a, st); return;
+        case 13: launch_t<128, 288, 4, 3, 3, EPI>(a, st); return;
         default: break;
     }
-    if constexpr (EPI != EPI_GEGLU) {
-        switch (a.tile) {
-            case 1: launch_t<128, 64, 2, 2, 3, EPI>(a, st); return;
-            case 3: launch_t<128, 64, 2, 2, 4, EPI>(a, st); return;
-            case 5: launch_t<128, 64, 2, 2, 2, EPI>(a, st); return;
-            default: break;
-        }
+    switch (a.tile) {
+        case 1: launch_t<128, 64, 2, 2, 3, EPI>(a, st); return;
+        case 3: launch_t<128, 64, 2, 2, 4, EPI>(a, st); return;
+        case 5: launch_t<128, 64, 2, 2, 2, EPI>(a, st); return;
+        default: break;
     }
     launch_t<128, 64, 4, 1, 2, EPI>(a, st);
 }

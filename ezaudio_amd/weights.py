@@ -26,15 +26,15 @@ def param_table(handle):
     return out
 
 
-def _geglu32(t):
+def _geglu8(t):
     """[2I, cols] with value rows first, gate rows second (GEGLU chunk order, modules.py:274-275) ->
-    groups of 64 rows = 32 value rows followed by their 32 gate rows."""
+    groups of 16 rows = 8 value rows followed by their 8 gate rows (what the GEMM epilogue pairs in-lane)."""
     two_i, cols = t.shape
     inner = two_i // 2
-    if inner % 32:
-        raise NotImplementedError(f'GEGLU inner dim {inner} not a multiple of 32')
-    val = t[:inner].reshape(inner // 32, 32, cols)
-    gate = t[inner:].reshape(inner // 32, 32, cols)
+    if inner % 8:
+        raise NotImplementedError(f'GEGLU inner dim {inner} not a multiple of 8')
+    val = t[:inner].reshape(inner // 8, 8, cols)
+    gate = t[inner:].reshape(inner // 8, 8, cols)
     return torch.cat([val, gate], dim=1).reshape(two_i, cols)
 
 
@@ -55,8 +55,8 @@ def pack_state_dict(handle, state_dict, strict=True):
             used.add(key)
         vec = p['rows'] == 1
         t = torch.cat([x.reshape(1, -1) if vec else x.reshape(x.shape[0], -1) for x in parts], dim=1 if vec else 0)
-        if p['transform'] == _lib.T_GEGLU32:
-            t = _geglu32(t.reshape(-1, 1)).reshape(1, -1) if vec else _geglu32(t)
+        if p['transform'] == _lib.T_GEGLU8:
+            t = _geglu8(t.reshape(-1, 1)).reshape(1, -1) if vec else _geglu8(t)
         if tuple(t.shape) != (p['rows'], p['cols']):
             raise ValueError(f"{p['name']}: checkpoint shape {tuple(t.shape)} != expected {(p['rows'], p['cols'])}")
         dt = torch.bfloat16 if p['dtype'] == _lib.P_BF16 else torch.float32

@@ -62,7 +62,7 @@ enum {
 enum { EZDIT_P_F32 = 0, EZDIT_P_BF16 = 1 };
 enum {
     EZDIT_T_NONE = 0,
-    EZDIT_T_GEGLU32 = 1 /* rows re-ordered so each 64-row group = 32 value rows then their 32 gate rows */
+    EZDIT_T_GEGLU8 = 1 /* rows re-ordered so each 16-row group = 8 value rows then their 8 gate rows */
 };
 typedef struct {
     char    name[64];      /* our slot name, e.g. "blk3.wqkv" */

@@ -26,20 +26,20 @@ def timeit(fn, iters=30, warm=5):
 def bench_gemm(lib):
     dev = 'cuda'
     names = {0: '128x128 r4', 1: '128x64 r3', 2: '128x128 r2', 3: '128x64 r4', 4: '128x128 r3', 5: '128x64 r2',
-             6: '128x64 4x1 r2', 7: '128x128 8w r2', 8: '256x128 8w r2', 9: '128x128 8w r3'}
-    geglu_ok = (0, 2, 4, 6, 8)
+             6: '128x64 4x1 r2', 7: '128x128 8w r2', 8: '256x128 8w r2', 9: '128x128 8w r3', 12: '128x288 12w r2', 13: '128x288 12w r3'}
+    geglu_ok = tuple(range(14))
     shapes = [('qkv', 1000, 3456, 1152), ('geglu-in', 1000, 9216, 1152), ('proj', 1000, 1152, 1152),
               ('skip', 1000, 1152, 2304), ('mlp-out', 1000, 1152, 4608),
               ('qkv B8', 4000, 3456, 1152), ('geglu-in B8', 4000, 9216, 1152), ('proj B8', 4000, 1152, 1152), ('mlp-out B8', 4000, 1152, 4608)]
     for name, M, N, K in shapes:
         A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-        W = (torch.randn((N + 127) // 128 * 128, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+        W = (torch.randn((N + 287) // 288 * 288 + 288, K, device=dev) / K ** 0.5).to(torch.bfloat16)
         bias = torch.zeros(N, device=dev)
         Mp = (M + 127) // 128 * 128
         out = torch.empty(8 * Mp * max(N, 1152), device=dev)
         fl = 2.0 * M * N * K
         res = []
-        for tile in (2, 5, 6, 7, 8, 9):
+        for tile in (2, 5, 6, 7, 12, 13):
             for epi, splits in ((0, [1]), (1, [1, 2, 3, 4, 6])) if N <= 1152 else ((0, [1]), (2, [1])):
                 if epi == 2 and tile not in geglu_ok:
                     continue

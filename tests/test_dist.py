@@ -1,0 +1,86 @@
+"""CPU tests of the N > 1 path: world_size 2 over gloo (no GPU needed).  The sharding must be placement-independent:
+sharded result == single-process result, bitwise (no cross-sample math exists on the path)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ezaudio_amd.dist import gather_samples, sample_sharded, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_sample(start, end, C=4, L=16, seed=2024, steps=3):
+    """Stand-in for the GPU sampler with the SAME RNG discipline as ezaudio_amd.sampler.draw_noises:
+    one generator per sample, seeded seed + global index, init noise first then one draw per step."""
+    from ezaudio_amd.sampler import draw_noises
+    outs = []
+    for i in range(start, end):
+        init, step = draw_noises(C, L, steps, 1.0, seed + i, 'cpu', n_prompts=1)
+        outs.append(init[0] * 0.5 + step.sum(dim=0)[0])
+    return torch.stack(outs) if outs else torch.zeros(0, C, L)
+
+
+def _worker(rank, world, port, n_prompts, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        out = sample_sharded(_fake_sample, n_prompts)
+        q.put((rank, out.clone()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_prompts', [5, 2, 1])
+def test_sharded_equals_single_process_gloo_world2(n_prompts):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_prompts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _fake_sample(0, n_prompts)
+    for r in range(world):
+        assert torch.equal(results[r], ref)       # every rank holds the full, identical, placement-independent result
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_is_identity_without_process_group():
+    x = torch.arange(12.).reshape(3, 4)
+    assert gather_samples(x, 3) is x
+
+
+def test_draw_noises_matches_reference_draw_order():
+    """Batch-1 call: init noise then one randn per step from ONE generator (src/inference.py:58-67 + scheduler.step)."""
+    from ezaudio_amd.sampler import draw_noises
+    init, step = draw_noises(3, 5, 4, 1.0, 7, 'cpu')
+    g = torch.Generator().manual_seed(7)
+    assert torch.equal(init, torch.randn((1, 3, 5), generator=g))
+    for i in range(4):
+        assert torch.equal(step[i], torch.randn((1, 3, 5), generator=g))
+    init0, step0 = draw_noises(3, 5, 4, 0.0, 7, 'cpu')
+    assert torch.equal(init0, init) and step0 is None

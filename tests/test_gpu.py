@@ -70,6 +70,10 @@ def t_(a, dev='cuda:0'):
     (1000, 1152, 1152, 7 * 4 + 1, 2),   # 128x128, 8 waves
     (1000, 1152, 1152, 8 * 4 + 0, 1),   # 256x128, 8 waves
     (1000, 1152, 1152, 9 * 4 + 1, 3),   # 128x128, 8 waves, ring 3
+    (1000, 1152, 1152, 12 * 4 + 0, 1),  # 128x288, 12 waves
+    (500, 300, 192, 12 * 4 + 1, 2),     # 128x288 ragged
+    (1000, 1152, 1152, 13 * 4 + 0, 1),  # 128x288, ring 3
+    (1000, 1152, 1152, 13 * 4 + 1, 6),  # 128x288, ring 3, 3 K tiles per slice
 ])
 def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     g = torch.Generator().manual_seed(M + N + K)
@@ -99,15 +103,15 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [2, 6, 8])
+@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13])
 def test_gemm_geglu_epilogue(lib, dev, tile):
-    M, D, inner = 300, 128, 512
+    M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
     A = torch.randn(M, D, generator=g).to(torch.bfloat16)
     W = (torch.randn(2 * inner, D, generator=g) / D ** 0.5).to(torch.bfloat16)
     b = torch.randn(2 * inner, generator=g) * 0.1
-    from ezaudio_amd.weights import _geglu32
-    Wi, bi = _geglu32(W.float()).to(torch.bfloat16), _geglu32(b.reshape(-1, 1)).reshape(-1)
+    from ezaudio_amd.weights import _geglu8
+    Wi, bi = _geglu8(W.float()).to(torch.bfloat16), _geglu8(b.reshape(-1, 1)).reshape(-1)
     h = A.float().double() @ W.float().double().T + b.double()
     val, gate = h[:, :inner], h[:, inner:]
     ref = val * torch.nn.functional.gelu(gate)

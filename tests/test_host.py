@@ -84,10 +84,10 @@ def test_pack_roundtrip_and_geglu_interleave(lib):
         got = raw[:p['rows'], :p['cols']]
         want = np.concatenate([np.asarray(sd[k]).reshape(1, -1) if p['rows'] == 1 else np.asarray(sd[k]).reshape(sd[k].shape[0], -1)
                                for k in p['src']], axis=1 if p['rows'] == 1 else 0)
-        if p['transform'] == 1:  # GEGLU32: row 64g+i (i<32) = value row 32g+i ; row 64g+32+i = gate row inner+32g+i
+        if p['transform'] == 1:  # GEGLU8: row 16g+i (i<8) = value row 8g+i ; row 16g+8+i = gate row inner+8g+i
             w2 = want.reshape(-1, 1) if p['rows'] == 1 else want
-            perm = np.concatenate([np.concatenate([np.arange(32 * g, 32 * g + 32), inner + np.arange(32 * g, 32 * g + 32)])
-                                   for g in range(inner // 32)])
+            perm = np.concatenate([np.concatenate([np.arange(8 * g, 8 * g + 8), inner + np.arange(8 * g, 8 * g + 8)])
+                                   for g in range(inner // 8)])
             w2 = w2[perm]
             want = w2.reshape(1, -1) if p['rows'] == 1 else w2
         tol = 0 if p['dtype'] == 0 else 2 ** -8
