@@ -100,6 +100,10 @@ def main():
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true', help='A/B: disable the Infinity-Cache weight prefetcher')
+    ap.add_argument('--geglu-tile', type=int, default=-1)
+    ap.add_argument('--opt', action='append', default=[], help='name=value tuning knob passed to ezdit_set_option')
+    ap.add_argument('--prefetch', action='store_true')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -130,6 +134,15 @@ def main():
     sd = random_state_dict(cfg, seed=1234)
     unet = MaskDiT(device=dev, **cfg)
     unet.load_state_dict(sd)
+    if a.no_prefetch:
+        unet.lib.ezdit_set_option(unet._h, b'prefetch', 0)
+    if a.geglu_tile >= 0:
+        unet.lib.ezdit_set_option(unet._h, b'geglu_tile', a.geglu_tile)
+    if a.prefetch:
+        unet.lib.ezdit_set_option(unet._h, b'prefetch', 1)
+    for kv in a.opt:
+        k, v = kv.split('=')
+        assert unet.lib.ezdit_set_option(unet._h, k.encode(), int(v)) == 0, kv
 
     # synthetic inputs, generated on CPU with seeded generators (identical on every box)
     g = torch.Generator().manual_seed(11 + rank)

@@ -73,6 +73,11 @@ struct ezdit_handle {
 
     int launches = 0;
     int geglu_tile = -1;  // tuning override (tests/bench)
+    size_t step_weights_end = 0;
+    hipStream_t pf_stream = nullptr;   // side stream of the weight prefetcher
+    std::vector<hipEvent_t> pf_events;  // fork/join events (one pair per use so capture sees distinct nodes)
+    int prefetch = 0;      // measured -12 % on MI355X (profiles/): the side stream disturbs the GEMMs more than warm weights help
+    int opt_split18 = 2, opt_split36 = 2, opt_split72 = 4, opt_tile_partial = 5, opt_tile_f32 = 6;  // tuning knobs
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
 
     template <typename T>
@@ -173,24 +178,30 @@ void build_params(ezdit_handle* h) {
     };
     for (const V& v : vecs)
         for (int b = 0; b < h->nblk; ++b) add_param(h, bn(b, v.name), {blk_prefix(h, b) + "." + v.key}, F, 1, v.n);
+    // per-STEP matrices of one block are contiguous (one prefetch range per block, see forward_impl)
     for (int b = 0; b < h->nblk; ++b) {
         const std::string p = blk_prefix(h, b);
         add_param(h, bn(b, "b1"), {p + ".mlp.net.0.proj.bias"}, F, 1, 2 * I, EZDIT_T_GEGLU8);
-        add_param(h, bn(b, "lora_a"), {p + ".adaln.lora_a.weight"}, F, r6, D);
-        add_param(h, bn(b, "lora_b"), {p + ".adaln.lora_b.weight"}, F, 6 * D, r6);
-        add_param(h, bn(b, "wqkv"), {p + ".attn.to_q.weight", p + ".attn.to_k.weight", p + ".attn.to_v.weight"}, Bf, 3 * D, D);
-        add_param(h, bn(b, "wo"), {p + ".attn.proj.weight"}, Bf, D, D);
-        add_param(h, bn(b, "wq2"), {p + ".cross_attn.to_q.weight"}, Bf, D, D);
-        add_param(h, bn(b, "wkv2"), {p + ".cross_attn.to_k.weight", p + ".cross_attn.to_v.weight"}, Bf, 2 * D, D);
-        add_param(h, bn(b, "wo2"), {p + ".cross_attn.proj.weight"}, Bf, D, D);
-        add_param(h, bn(b, "w1"), {p + ".mlp.net.0.proj.weight"}, Bf, 2 * I, D, EZDIT_T_GEGLU8);
-        add_param(h, bn(b, "w2"), {p + ".mlp.net.2.weight"}, Bf, D, I);
         if (b > h->nhalf) {
             add_param(h, bn(b, "snw"), {p + ".skip_norm.weight"}, F, 1, 2 * D);
             add_param(h, bn(b, "snb"), {p + ".skip_norm.bias"}, F, 1, 2 * D);
             add_param(h, bn(b, "wskip"), {p + ".skip_linear.weight"}, Bf, D, 2 * D);
             add_param(h, bn(b, "bskip"), {p + ".skip_linear.bias"}, F, 1, D);
         }
+        add_param(h, bn(b, "wqkv"), {p + ".attn.to_q.weight", p + ".attn.to_k.weight", p + ".attn.to_v.weight"}, Bf, 3 * D, D);
+        add_param(h, bn(b, "wo"), {p + ".attn.proj.weight"}, Bf, D, D);
+        add_param(h, bn(b, "wq2"), {p + ".cross_attn.to_q.weight"}, Bf, D, D);
+        add_param(h, bn(b, "wo2"), {p + ".cross_attn.proj.weight"}, Bf, D, D);
+        add_param(h, bn(b, "w1"), {p + ".mlp.net.0.proj.weight"}, Bf, 2 * I, D, EZDIT_T_GEGLU8);
+        add_param(h, bn(b, "w2"), {p + ".mlp.net.2.weight"}, Bf, D, I);
+    }
+    h->step_weights_end = h->param_bytes;
+    // used once per CALL only (context K/V projection, AdaLN-SOLA low-rank factors)
+    for (int b = 0; b < h->nblk; ++b) {
+        const std::string p = blk_prefix(h, b);
+        add_param(h, bn(b, "wkv2"), {p + ".cross_attn.to_k.weight", p + ".cross_attn.to_v.weight"}, Bf, 2 * D, D);
+        add_param(h, bn(b, "lora_a"), {p + ".adaln.lora_a.weight"}, F, r6, D);
+        add_param(h, bn(b, "lora_b"), {p + ".adaln.lora_b.weight"}, F, 6 * D, r6);
     }
 }
 
@@ -215,6 +226,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("rope_sin", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
     add("cfgpart", (size_t)B * 64 * 4 * 4);
+    add("sink", 256);
     add("ape", Mp * h->ldPE * 2);
     add("h", Mp * D * 4);
     add("skips", (size_t)h->nhalf * Mp * D * 4);
@@ -286,16 +298,16 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
 
 // Tile / split-K heuristics from tests/bench_kernels.py on MI355X (profiles/): with M ~ 1000 rows the 128x64 tile at
 // 3 workgroups per CU wins everywhere (occupancy beats ring depth); from M ~ 4000 the 128x128 8-wave tile is ahead.
-int tile_for(int M, bool partial) {
-    if (M <= 2048) return partial ? 5 : 6;
+int tile_for(const ezdit_handle* h, int M, bool partial) {
+    if (M <= 2048) return partial ? h->opt_tile_partial : h->opt_tile_f32;
     return partial ? 5 : 7;
 }
 
-int pick_splitk(int M, int N, int K) {
+int pick_splitk(const ezdit_handle* h, int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = K / 64;
     if (tiles >= 256) return 1;
-    int s = nk >= 72 ? 4 : nk >= 36 ? 2 : 1;   // fewer slabs = less traffic for the row kernel that reduces them
+    int s = nk >= 72 ? h->opt_split72 : nk >= 36 ? h->opt_split36 : h->opt_split18;  // fewer slabs = less row-kernel traffic
     if (s > nk) s = nk;
     if (s < 1) s = 1;
     return s;
@@ -305,8 +317,8 @@ int pick_splitk(int M, int N, int K) {
 int gemm_partial(Ctx& c, const bf16_t* A, int lda, const std::string& wname, int M, int N) {
     ezdit_handle* h = c.h;
     const int K = h->pld(wname);
-    const int s = pick_splitk(M, N, K);
-    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, tile_for(M, true), s, (long)h->Mp * h->D);
+    const int s = pick_splitk(h, M, N, K);
+    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, tile_for(h, M, true), s, (long)h->Mp * h->D);
     return s;
 }
 
@@ -359,6 +371,8 @@ int ezdit_destroy(ezdit_handle* h) {
     if (!h) return EZDIT_OK;
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
+    for (auto& e : h->pf_events) (void)hipEventDestroy(e);
+    if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
     delete h;
     return EZDIT_OK;
 }
@@ -401,6 +415,11 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     h->ctx_ready = h->ts_ready = false;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    if (!h->pf_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking));
+        h->pf_events.resize(2 * (h->nblk + 2));
+        for (auto& e : h->pf_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     // zero everything once: all padding rows / columns / keys stay zero for the lifetime of the binding
     HIPCHK(hipMemsetAsync(ws, 0, need, st));
     launch_rope_table(h->buf<float>("rope_cos"), h->buf<float>("rope_sin"), h->cfg.max_len, h->dh, st);
@@ -418,9 +437,9 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
     else HIPCHK(hipMemsetAsync(km, 1, Mc, c.st));
     // context_embed: Linear -> SiLU -> Linear  (udit.py:94-97)
     launch_cast_bf16(ctx, h->Cctx, h->buf<bf16_t>("ctx_bf"), h->ldCtx, Mc, h->Cctx, 0, c.st);
-    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, "ce.w1", h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, tile_for(Mc, false));
+    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, "ce.w1", h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
     launch_cast_bf16(h->buf<float>("c1"), D, h->buf<bf16_t>("c1b"), h->ldD, Mc, D, 1, c.st);
-    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, "ce.w2", h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, tile_for(Mc, false));
+    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, "ce.w2", h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
     for (int b = 0; b < h->nblk; ++b) {
         // norm_context (blocks.py:150) -> to_k / to_v -> head LayerNorm on k (attention.py:128-142)
         RowArgs r;
@@ -433,7 +452,7 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
         r.ld_u = h->ldD;
         r.M = Mc; r.D = D; r.L = h->Lc;
         launch_row(r, c.st);
-        gemm(c, h->buf<bf16_t>("cu"), h->ldD, bn(b, "wkv2"), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, tile_for(Mc, false));
+        gemm(c, h->buf<bf16_t>("cu"), h->ldD, bn(b, "wkv2"), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, tile_for(h, Mc, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("ckv"); hn.ldx = 2 * D;
@@ -527,7 +546,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     launch_assemble(as, st);
     h->launches++;
     STOPCHK();
-    gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, tile_for(M, false));
+    gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, tile_for(h, M, false));
 
     auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
                    long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
@@ -552,8 +571,22 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
     const float* hcur = hA;
 
+    // weight prefetch: while block b computes, a side stream pulls block b+1's per-step matrices into the Infinity Cache
+    const bool use_pf = h->prefetch && h->pf_stream && h->debug_stop == 0;
+    int n_fork = 0;
+    auto prefetch_block = [&](int blk) {
+        if (!use_pf || blk >= nblk) return;
+        const size_t beg = (size_t)h->params[h->pidx.at(bn(blk, "b1"))].offset;
+        const size_t end = blk + 1 < nblk ? (size_t)h->params[h->pidx.at(bn(blk + 1, "b1"))].offset : h->step_weights_end;
+        hipEvent_t ev = h->pf_events[n_fork++];
+        (void)hipEventRecord(ev, st);
+        (void)hipStreamWaitEvent(h->pf_stream, ev, 0);
+        launch_prefetch(h->wblob + beg, end - beg, h->buf<unsigned>("sink"), h->pf_stream);
+    };
+    prefetch_block(0);
     for (int b = 0; b < nblk; ++b) {
         const bool is_in = b < nhalf, is_out = b > nhalf;
+        prefetch_block(b + 1);
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
@@ -564,7 +597,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         }
         // ---- self attention (blocks.py:136-141) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32, tile_for(M, false));
+        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32, tile_for(h, M, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = 3 * D;
@@ -576,7 +609,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
         STOPCHK();
         launch_headnorm(hn, st);
-        h->launches += 2;
+        h->launches++;
         AttnArgs at;
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
         at.out = h->buf<bf16_t>("ao"); at.ldo = h->ldD;
@@ -593,7 +626,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hcur = hA;
         // ---- cross attention (blocks.py:147-151) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, tile_for(M, false));
+        gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, tile_for(h, M, false));
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = D;
         hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
@@ -643,7 +676,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     }
     // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
     STOPCHK();
-    gemm(c, u, h->ldD, "fin.w", h->w<float>("fin.b"), h->buf<float>("y"), h->C, M, h->C, EPI_F32, tile_for(M, false));
+    gemm(c, u, h->ldD, "fin.w", h->w<float>("fin.b"), h->buf<float>("y"), h->C, M, h->C, EPI_F32, tile_for(h, M, false));
     FinalConvArgs fc;
     fc.y = h->buf<float>("y"); fc.ldy = h->C;
     fc.w = h->w<float>("fin.cw"); fc.b = h->w<float>("fin.cb");
@@ -651,6 +684,11 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     STOPCHK();
     launch_final_conv(fc, st);
     h->launches++;
+    if (use_pf) {  // join the side stream (mandatory inside a capture; cheap otherwise)
+        hipEvent_t ev = h->pf_events[n_fork++];
+        (void)hipEventRecord(ev, h->pf_stream);
+        (void)hipStreamWaitEvent(st, ev, 0);
+    }
     return EZDIT_OK;
 }
 
@@ -777,6 +815,20 @@ int ezdit_last_launch_count(const ezdit_handle* h) { return h ? h->launches : 0;
 int ezdit_debug_stop_after(ezdit_handle* h, int n) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
     h->debug_stop = n;
+    return EZDIT_OK;
+}
+int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
+    if (!h || !name) return fail(EZDIT_E_INVALID, "null argument");
+    if (!strcmp(name, "prefetch")) h->prefetch = value;
+    else if (!strcmp(name, "geglu_tile")) h->geglu_tile = value;
+    else if (!strcmp(name, "split18")) h->opt_split18 = value;
+    else if (!strcmp(name, "split36")) h->opt_split36 = value;
+    else if (!strcmp(name, "split72")) h->opt_split72 = value;
+    else if (!strcmp(name, "tile_partial")) h->opt_tile_partial = value;
+    else if (!strcmp(name, "tile_f32")) h->opt_tile_f32 = value;
+    else return fail(EZDIT_E_INVALID, "unknown option %s", name);
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     return EZDIT_OK;
 }
 

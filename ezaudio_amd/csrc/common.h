@@ -136,5 +136,6 @@ struct CfgDdimArgs {
     int P, n;            // n = C*L elements per sample
 };
 void launch_cfg_ddim(const CfgDdimArgs& a, float* partial /* [P][64][4] scratch */, hipStream_t st);
+void launch_prefetch(const void* p, size_t bytes, unsigned* sink, hipStream_t st);  // warm the Infinity Cache
 void launch_set_int(int* p, int v, int add, hipStream_t st);  // *p = add ? *p + v : v
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu

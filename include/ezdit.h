@@ -151,6 +151,9 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t
 int ezdit_last_launch_count(const ezdit_handle* h);
 /* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
 int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
+/* tuning knobs (A/B measurements): "prefetch" 0/1 (Infinity-Cache weight prefetch on a side stream),
+ * "geglu_tile" (GEMM tile configuration id for the GEGLU GEMM, -1 = heuristic). */
+int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 
 #ifdef __cplusplus
 }
