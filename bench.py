@@ -26,6 +26,11 @@ PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
 GEGLU_VARIANT = 12 * 4 + 2  # ezdit_test_gemm: tile config 12 (128x288, 12 waves: what the step uses at M <= 2048), GEGLU epilogue
 
 
+def load_yaml(path):
+    from ezaudio_amd.config import load_yaml_with_includes
+    return load_yaml_with_includes(path)
+
+
 def model_section(size):
     from ezaudio_amd.config import configs, load_yaml_with_includes
     if size in ('xl', 'l'):
@@ -104,6 +109,7 @@ def main():
     ap.add_argument('--geglu-tile', type=int, default=-1)
     ap.add_argument('--opt', action='append', default=[], help='name=value tuning knob passed to ezdit_set_option')
     ap.add_argument('--prefetch', action='store_true')
+    ap.add_argument('--controlnet', action='store_true', help='BASELINE config #5: add an energy ControlNet of the same width')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -158,8 +164,20 @@ def main():
     noise = torch.randn(n_ddim, P, cfg['out_chans'], L, generator=g)
 
     smp = LatentSampler(unet, DDIMScheduler(**params['diff']))
+    cn_kw, gs, gr = {}, 5.0, 0.75
+    if a.controlnet:   # api/controlnet.py:113-118 defaults: guidance 3.5, rescale 0, conditioning_scale 1
+        from ezaudio_amd import DiTControlNet
+        from ezaudio_amd.config import controlnet_configs
+        from ezaudio_amd.weights import random_controlnet_state_dict
+        cn_cfg = load_yaml(controlnet_configs['energy']['config'])['controlnet']
+        ccfg = dict(cfg); ccfg.update(cn_cfg)
+        cn = DiTControlNet(device=dev, **ccfg)
+        cn.load_state_dict(random_controlnet_state_dict(cfg, cn_cfg, seed=99))
+        cond = torch.rand(P, 1, 2 * L, generator=g)      # a [0,1] control curve at 100 Hz (EnergyExtractor output range)
+        cn_kw = dict(controlnet=cn, condition=cond, conditioning_scale=1.0)
+        gs, gr = 3.5, 0.0
     # API defaults of generate_audio except the step count: guidance 5, rescale 0.75, eta 1
-    smp.prepare(text, text_mask, uncond, uncond_mask, init, noise, 5.0, 0.75, n_ddim, 1.0)
+    smp.prepare(text, text_mask, uncond, uncond_mask, init, noise, gs, gr, n_ddim, 1.0, **cn_kw)
     init_dev = init.to(dev)
     use_graph = not a.no_graph
 
@@ -206,11 +224,14 @@ def main():
     if rank == 0:
         B = 2 * P
         fl = flops_per_step(cfg, B, L, Lc)
+        if a.controlnet:  # + depth/2 ControlNet blocks, its patch embed and depth/2 zero-Linears (2.29 TFLOP for XL)
+            D_, nh = cfg['embed_dim'], cfg['depth'] // 2
+            fl += 2.0 * B * (nh * (18 * L * D_ * D_ + 2 * L * L * D_ + 2 * L * Lc * D_) + L * D_ * cfg['in_chans'] + nh * L * D_ * D_)
         steps_per_s = a.steps / dt                       # loop iterations per second (per GPU)
         value = steps_per_s * P * world                  # sample-steps/s over the whole job
         ach = fl * (a.steps / (ev_ms * 1e-3)) / 1e12     # TFLOP/s from HIP events around the timed loop
         res = {
-            'metric': 'denoising steps/sec (EzAudio-%s, 10 s latent, CFG on)' % a.size.upper(),
+            'metric': 'denoising steps/sec (EzAudio-%s%s, 10 s latent, CFG on)' % (a.size.upper(), ' + ControlNet(energy)' if a.controlnet else ''),
             'value': value, 'unit': 'sample-steps/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': dt * 1e3 / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',

@@ -15,7 +15,13 @@ def __getattr__(name):  # lazy: importing the package must not require torch / t
     if name in ('DDIMScheduler',):
         from .scheduler import DDIMScheduler
         return DDIMScheduler
-    if name in ('inference', 'LatentSampler'):
+    if name in ('DiTControlNet',):
+        from .controlnet import DiTControlNet
+        return DiTControlNet
+    if name in ('EzAudio_ControlNet',):
+        from .api import EzAudio_ControlNet
+        return EzAudio_ControlNet
+    if name in ('inference', 'inference_controlnet', 'LatentSampler'):
         from . import sampler
         return getattr(sampler, name)
     raise AttributeError(name)

@@ -15,7 +15,8 @@ class EzditConfig(C.Structure):
     _fields_ = [('embed_dim', C.c_int32), ('num_heads', C.c_int32), ('depth', C.c_int32),
                 ('in_chans', C.c_int32), ('out_chans', C.c_int32), ('context_dim', C.c_int32),
                 ('ada_sola_rank', C.c_int32), ('ada_sola_alpha', C.c_float), ('mlp_ratio', C.c_float),
-                ('max_len', C.c_int32)]
+                ('max_len', C.c_int32), ('controlnet', C.c_int32), ('cond_in', C.c_int32), ('cond_c0', C.c_int32),
+                ('cond_c1', C.c_int32), ('cond_mask', C.c_int32)]
 
 
 class EzditParamInfo(C.Structure):
@@ -50,6 +51,11 @@ PROTOTYPES = {
     'ezdit_set_step': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'ezdit_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]),
+    'ezdit_prepare_condition': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'ezdit_controlnet_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'ezdit_controlnet_residuals': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
+    'ezdit_sampler_attach_controlnet': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float]),
+    'ezdit_set_cn_scale': (C.c_int, [C.c_void_p, C.c_float]),
     'ezdit_sampler_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(EzditDdimCoef), C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ezdit_sampler_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

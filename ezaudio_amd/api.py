@@ -11,9 +11,9 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from .config import configs, load_yaml_with_includes
+from .config import configs, controlnet_configs, load_yaml_with_includes
 from .denoiser import MaskDiT
-from .sampler import inference
+from .sampler import inference, inference_controlnet
 from .scheduler import DDIMScheduler
 
 MAX_SEED = np.iinfo(np.int32).max
@@ -133,3 +133,56 @@ class EzAudio:
         pred = pred[:round(chunk_length * sr)]
         output_audio[round(start_idx * sr):round(end_idx * sr)] = pred
         return sr, output_audio
+
+
+class EzAudio_ControlNet(EzAudio):
+    """api/controlnet.py:31-160: EzAudio-L + energy ControlNet (``model_name='energy'``)."""
+
+    def __init__(self, model_name, ckpt_path=None, controlnet_path=None, vae_path=None, device='cuda', autoencoder=None,
+                 tokenizer=None, text_encoder=None, state_dict=None, controlnet_state_dict=None):
+        self.device = device
+        config_name = controlnet_configs[model_name]['config']
+        if ckpt_path is None and state_dict is None:
+            ckpt_path = self.download_ckpt(controlnet_configs['l'])
+        if controlnet_path is None and controlnet_state_dict is None:
+            controlnet_path = self.download_ckpt(controlnet_configs[model_name])
+        if vae_path is None and autoencoder is None:
+            vae_path = self.download_ckpt(controlnet_configs['vae'])
+        (self.autoencoder, self.unet, self.tokenizer, self.text_encoder, self.noise_scheduler,
+         self.params) = self.load_models(config_name, ckpt_path, vae_path, device, autoencoder, tokenizer, text_encoder,
+                                         state_dict)
+        from .conditions import Conditioner
+        from .controlnet import DiTControlNet
+        cfg = self.params['model'].copy()
+        cfg.update(self.params['controlnet'])                      # api/controlnet.py:92-95
+        self.controlnet = DiTControlNet(device=device, **cfg)
+        if controlnet_state_dict is None:
+            controlnet_state_dict = torch.load(controlnet_path, map_location='cpu')['model']
+        self.controlnet.load_state_dict(controlnet_state_dict)
+        self.conditioner = Conditioner(**self.params['conditioner'])
+
+    def generate_audio(self, text, audio_path, surpass_noise=0, guidance_scale=3.5, guidance_rescale=0, ddim_steps=50,
+                       eta=1, conditioning_scale=1, random_seed=None, randomize_seed=False):
+        """api/controlnet.py:113-160: the control curve is the frame energy of a reference recording."""
+        import librosa
+        sr = self.params['autoencoder']['sr']
+        gt, _ = librosa.load(audio_path, sr=sr)
+        gt = gt / (np.max(np.abs(gt)) + 1e-9)
+        if surpass_noise > 0:
+            gt[np.abs(gt) <= surpass_noise] = 0
+        original_length = len(gt)
+        num_samples = int(10 * sr)
+        audio_frames = round(num_samples / sr * self.params['autoencoder']['latent_sr'])
+        gt = np.pad(gt, (0, num_samples - len(gt)), 'constant') if len(gt) < num_samples else gt[:num_samples]
+        gt_audio = torch.tensor(gt).unsqueeze(0).unsqueeze(1).to(self.device)
+        latent_shape = (1, self.params['autoencoder']['dim'], audio_frames)   # the reference encodes only to get this shape
+        condition = self.conditioner(gt_audio.squeeze(1), latent_shape)
+        if randomize_seed:
+            random_seed = random.randint(0, MAX_SEED)
+        pred = inference_controlnet(self.autoencoder, self.unet, self.controlnet, None, None, condition, self.tokenizer,
+                                    self.text_encoder, self.params, self.noise_scheduler, text, neg_text=None,
+                                    audio_frames=audio_frames, guidance_scale=guidance_scale,
+                                    guidance_rescale=guidance_rescale, ddim_steps=ddim_steps, eta=eta,
+                                    random_seed=random_seed, conditioning_scale=conditioning_scale, device=self.device)
+        pred = pred.cpu().numpy().squeeze(0).squeeze(0)[:original_length]
+        return sr, pred

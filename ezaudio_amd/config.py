@@ -39,6 +39,17 @@ def load_yaml_with_includes(yaml_file):
         return yaml.load(f, Loader=_Loader)
 
 
+# ControlNet registry, same names as api/controlnet.py:20-27
+controlnet_configs = {
+    'energy': {'path': 'ckpts/controlnet/s3_l_energy.pt',
+               'url': 'https://huggingface.co/OpenSound/EzAudio-ControlNet/resolve/main/s3_l_energy.pt',
+               'config': os.path.join(CONFIG_DIR, 'controlnet', 'energy_l.yml')},
+    'l': {'path': 'ckpts/s3/ezaudio_s3_l.pt',
+          'url': 'https://huggingface.co/OpenSound/EzAudio/resolve/main/ckpts/s3/ezaudio_s3_l.pt'},
+    'vae': configs['vae'],
+}
+
+
 # the one combination of UDiT options the shipped checkpoints use (ckpts/ezaudio-xl.yml:3-36)
 _REQUIRED = dict(input_type='1d', patch_size=1, qkv_bias=False, qk_scale=None, qk_norm='layernorm',
                  norm_layer='layernorm', act_layer='geglu', context_norm=True,

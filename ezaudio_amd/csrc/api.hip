@@ -58,7 +58,7 @@ struct ezdit_handle {
     size_t ws_bytes = 0;
     int B = 0, L = 0, Lc = 0, n_slots = 0, M = 0, Mp = 0, Lp = 0, Lcp = 0, Mc = 0;
     std::map<std::string, Buf> bufs;
-    bool ctx_ready = false, ts_ready = false;
+    bool ctx_ready = false, ts_ready = false, cond_ready = false;
     int n_ts = 0, per_row = 0;
 
     // sampler
@@ -72,6 +72,11 @@ struct ezdit_handle {
     hipGraph_t graph = nullptr;
 
     int launches = 0;
+    bool is_cn = false;          // ControlNet variant (cfg.controlnet)
+    int c0 = 0, c0m = 0, c1 = 0; // condition-embed channel counts
+    ezdit_handle* cn = nullptr;  // ControlNet attached to this backbone's sampler
+    float cn_scale = 1.0f;       // conditioning_scale applied to ControlNet residuals
+    const float* ext_mask_embed = nullptr;
     int geglu_tile = -1;  // tuning override (tests/bench)
     size_t step_weights_end = 0;
     hipStream_t pf_stream = nullptr;   // side stream of the weight prefetcher
@@ -128,7 +133,8 @@ void add_param(ezdit_handle* h, const std::string& name, std::vector<std::string
 
 std::string blk_prefix(const ezdit_handle* h, int b) {
     char s[64];
-    if (b < h->nhalf) snprintf(s, sizeof s, "model.in_blocks.%d", b);
+    if (h->is_cn) snprintf(s, sizeof s, "in_blocks.%d", b);  // DiTControlNet is not wrapped: no "model." prefix
+    else if (b < h->nhalf) snprintf(s, sizeof s, "model.in_blocks.%d", b);
     else if (b == h->nhalf) snprintf(s, sizeof s, "model.mid_block");
     else snprintf(s, sizeof s, "model.out_blocks.%d", b - h->nhalf - 1);
     return s;
@@ -142,27 +148,48 @@ std::string bn(int b, const char* k) {
 void build_params(ezdit_handle* h) {
     const long D = h->D, C = h->C, I = h->I, dh = h->dh, r6 = h->r6;
     const int F = EZDIT_P_F32, Bf = EZDIT_P_BF16;
-    add_param(h, "mask_embed", {"mask_embed"}, F, 1, C);
-    add_param(h, "pe.w", {"model.patch_embed.proj.weight"}, Bf, D, h->Cin);
-    add_param(h, "pe.b", {"model.patch_embed.proj.bias"}, F, 1, D);
-    add_param(h, "te.w1", {"model.time_embed.mlp.0.weight"}, F, D, 256);
-    add_param(h, "te.b1", {"model.time_embed.mlp.0.bias"}, F, 1, D);
-    add_param(h, "te.w2", {"model.time_embed.mlp.2.weight"}, F, D, D);
-    add_param(h, "te.b2", {"model.time_embed.mlp.2.bias"}, F, 1, D);
-    add_param(h, "ada.w", {"model.time_ada.weight"}, F, 6 * D, D);
-    add_param(h, "ada.b", {"model.time_ada.bias"}, F, 1, 6 * D);
-    add_param(h, "adaf.w", {"model.time_ada_final.weight"}, F, 2 * D, D);
-    add_param(h, "adaf.b", {"model.time_ada_final.bias"}, F, 1, 2 * D);
-    add_param(h, "ce.w1", {"model.context_embed.0.weight"}, Bf, D, h->Cctx);
-    add_param(h, "ce.b1", {"model.context_embed.0.bias"}, F, 1, D);
-    add_param(h, "ce.w2", {"model.context_embed.2.weight"}, Bf, D, D);
-    add_param(h, "ce.b2", {"model.context_embed.2.bias"}, F, 1, D);
-    add_param(h, "fin.nw", {"model.final_block.norm.weight"}, F, 1, D);
-    add_param(h, "fin.nb", {"model.final_block.norm.bias"}, F, 1, D);
-    add_param(h, "fin.w", {"model.final_block.linear.weight"}, Bf, C, D);
-    add_param(h, "fin.b", {"model.final_block.linear.bias"}, F, 1, C);
-    add_param(h, "fin.cw", {"model.final_block.final_layer.weight"}, F, C, C * 3);
-    add_param(h, "fin.cb", {"model.final_block.final_layer.bias"}, F, 1, C);
+    const std::string m = h->is_cn ? "" : "model.";
+    if (!h->is_cn) add_param(h, "mask_embed", {"mask_embed"}, F, 1, C);
+    add_param(h, "pe.w", {m + "patch_embed.proj.weight"}, Bf, D, h->Cin);
+    add_param(h, "pe.b", {m + "patch_embed.proj.bias"}, F, 1, D);
+    add_param(h, "te.w1", {m + "time_embed.mlp.0.weight"}, F, D, 256);
+    add_param(h, "te.b1", {m + "time_embed.mlp.0.bias"}, F, 1, D);
+    add_param(h, "te.w2", {m + "time_embed.mlp.2.weight"}, F, D, D);
+    add_param(h, "te.b2", {m + "time_embed.mlp.2.bias"}, F, 1, D);
+    add_param(h, "ada.w", {m + "time_ada.weight"}, F, 6 * D, D);
+    add_param(h, "ada.b", {m + "time_ada.bias"}, F, 1, 6 * D);
+    add_param(h, "ce.w1", {m + "context_embed.0.weight"}, Bf, D, h->Cctx);
+    add_param(h, "ce.b1", {m + "context_embed.0.bias"}, F, 1, D);
+    add_param(h, "ce.w2", {m + "context_embed.2.weight"}, Bf, D, D);
+    add_param(h, "ce.b2", {m + "context_embed.2.bias"}, F, 1, D);
+    if (!h->is_cn) {
+        add_param(h, "adaf.w", {"model.time_ada_final.weight"}, F, 2 * D, D);
+        add_param(h, "adaf.b", {"model.time_ada_final.bias"}, F, 1, 2 * D);
+        add_param(h, "fin.nw", {"model.final_block.norm.weight"}, F, 1, D);
+        add_param(h, "fin.nb", {"model.final_block.norm.bias"}, F, 1, D);
+        add_param(h, "fin.w", {"model.final_block.linear.weight"}, Bf, C, D);
+        add_param(h, "fin.b", {"model.final_block.linear.bias"}, F, 1, C);
+        add_param(h, "fin.cw", {"model.final_block.final_layer.weight"}, F, C, C * 3);
+        add_param(h, "fin.cb", {"model.final_block.final_layer.bias"}, F, 1, C);
+    } else {
+        // DiTControlNetEmbed (controlnet.py:10-39) and the zero-initialised output Linears (:228-234)
+        const long c0 = h->c0, c0m = h->c0m, c1 = h->c1, ci = h->cfg.cond_in;
+        add_param(h, "cn.cin.w", {"controlnet_pre.conv_in.weight"}, F, c0, ci);
+        add_param(h, "cn.cin.b", {"controlnet_pre.conv_in.bias"}, F, 1, c0);
+        if (h->cfg.cond_mask) add_param(h, "cn.mask_embed", {"controlnet_pre.mask_embed"}, F, 1, c0);
+        add_param(h, "cn.c0.w", {"controlnet_pre.blocks.0.0.weight"}, F, c0m, c0m * 3);
+        add_param(h, "cn.c0.b", {"controlnet_pre.blocks.0.0.bias"}, F, 1, c0m);
+        add_param(h, "cn.c1.w", {"controlnet_pre.blocks.0.2.weight"}, F, c1, c0m * 3);
+        add_param(h, "cn.c1.b", {"controlnet_pre.blocks.0.2.bias"}, F, 1, c1);
+        add_param(h, "cn.cout.w", {"controlnet_pre.conv_out.weight"}, F, D, c1);
+        add_param(h, "cn.cout.b", {"controlnet_pre.conv_out.bias"}, F, 1, D);
+        for (int b = 0; b < h->nblk; ++b) {
+            char k[64];
+            snprintf(k, sizeof k, "controlnet_zero_blocks.%d", b);
+            add_param(h, bn(b, "zw"), {std::string(k) + ".weight"}, Bf, D, D);
+            add_param(h, bn(b, "zb"), {std::string(k) + ".bias"}, F, 1, D);
+        }
+    }
     // per-block parameters, kind-major so that one kind is a constant-stride array over blocks
     struct V { const char* name; const char* key; long n; };
     const V vecs[] = {
@@ -227,6 +254,15 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
     add("cfgpart", (size_t)B * 64 * 4 * 4);
     add("sink", 256);
+    if (h->is_cn) {
+        const long Lc2 = 2L * L;
+        add("cn_e0", (size_t)B * h->c0 * Lc2 * 4);
+        add("cn_e1", (size_t)B * h->c0m * Lc2 * 4);
+        add("cn_e2", (size_t)B * h->c1 * L * 4);
+        add("cembed", (size_t)rup((long)B * L, 128) * h->D * 4);
+        add("cnres", (size_t)h->nhalf * rup((long)B * L, 128) * h->D * 4);
+        add("skipbf", (size_t)rup((long)B * L, 128) * h->ldD * 2);
+    }
     add("ape", Mp * h->ldPE * 2);
     add("h", Mp * D * 4);
     add("skips", (size_t)h->nhalf * Mp * D * 4);
@@ -348,7 +384,17 @@ int ezdit_create(const ezdit_config* cfg, ezdit_handle** out) {
     h->H = cfg->num_heads;
     h->dh = dh;
     h->nhalf = cfg->depth / 2;
-    h->nblk = cfg->depth + 1;
+    h->is_cn = cfg->controlnet != 0;
+    h->nblk = h->is_cn ? cfg->depth / 2 : cfg->depth + 1;
+    if (h->is_cn) {
+        if (cfg->cond_in <= 0 || cfg->cond_c0 <= 0 || cfg->cond_c1 <= 0) {
+            delete h;
+            return fail(EZDIT_E_INVALID, "controlnet needs cond_in / cond_blocks");
+        }
+        h->c0 = cfg->cond_c0;
+        h->c0m = cfg->cond_c0 + (cfg->cond_mask ? 1 : 0);
+        h->c1 = cfg->cond_c1;
+    }
     h->I = (int)(cfg->embed_dim * cfg->mlp_ratio);
     h->C = cfg->out_chans;
     h->Cin = cfg->in_chans;
@@ -412,7 +458,7 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     h->B = B; h->L = L; h->Lc = Lc; h->n_slots = n_slots > 0 ? n_slots : 1;
     h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 64); h->Lcp = (int)rup(Lc, 64);
     h->Mc = B * Lc;
-    h->ctx_ready = h->ts_ready = false;
+    h->ctx_ready = h->ts_ready = h->cond_ready = false;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     if (!h->pf_stream) {
@@ -485,7 +531,8 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
     launch_linear_f32(nullptr, h->buf<int>("ts"), 1, h->w<float>("te.w1"), h->w<float>("te.b1"), h->buf<float>("t1"), n, D, 256, 1, D, st);
     launch_linear_f32(h->buf<float>("t1"), nullptr, 0, h->w<float>("te.w2"), h->w<float>("te.b2"), h->buf<float>("tt"), n, D, D, 1, D, st);
     launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>("ada.w"), h->w<float>("ada.b"), h->buf<float>("ada"), n, 6 * D, D, 0, 6 * D, st);
-    launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>("adaf.w"), h->w<float>("adaf.b"), h->buf<float>("adaf"), n, 2 * D, D, 0, 2 * D, st);
+    if (!h->is_cn)
+        launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>("adaf.w"), h->w<float>("adaf.b"), h->buf<float>("adaf"), n, 2 * D, D, 0, 2 * D, st);
     for (int b = 0; b < nblk; ++b) {
         launch_linear_f32(h->buf<float>("tt"), nullptr, 0, h->w<float>(bn(b, "lora_a")), nullptr, h->buf<float>("la"), n, h->r6, D, 0, h->r6, st);
         launch_linear_f32(h->buf<float>("la"), nullptr, 0, h->w<float>(bn(b, "lora_b")), nullptr,
@@ -502,9 +549,12 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
     m.n3w = h->w<float>(bn(0, "n3w")); m.n3b = h->w<float>(bn(0, "n3b"));
     m.norm_stride = nblk > 1 ? (h->w<float>(bn(1, "n1w")) - h->w<float>(bn(0, "n1w"))) : 0;
     m.mod = h->buf<float>("mod");
-    m.ada_final = h->buf<float>("adaf");
-    m.nfw = h->w<float>("fin.nw"); m.nfb = h->w<float>("fin.nb");
-    m.mod_final = h->buf<float>("modf");
+    m.has_final = h->is_cn ? 0 : 1;
+    if (!h->is_cn) {
+        m.ada_final = h->buf<float>("adaf");
+        m.nfw = h->w<float>("fin.nw"); m.nfb = h->w<float>("fin.nb");
+        m.mod_final = h->buf<float>("modf");
+    }
     m.n = n; m.nblk = nblk; m.D = D;
     launch_mod_finalize(m, st);
     h->ts_ready = true;
@@ -523,6 +573,7 @@ int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream) {
 // ------------------------------------------------------------------------------------------------------
 static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
                         const float* const* cn, int n_cn, float* out, hipStream_t st) {
+    const bool cn_mode = h->is_cn;  // ControlNet: in-blocks only, then one zero-Linear per skip (controlnet.py:303-315)
     Ctx c{h, st};
     const int D = h->D, M = h->M, nblk = h->nblk, nhalf = h->nhalf, Mp = h->Mp;
     const int* cur = h->buf<int>("ints");
@@ -539,7 +590,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     // A4 + A5: input assembly and patch embed (Conv1d k=1 == per-token Linear)
     AssembleArgs as;
     as.x = x; as.x_rows = x_rows; as.in_ch = in_ch;
-    as.gt = gt; as.gt_mask = gt_mask; as.mask_embed = h->w<float>("mask_embed");
+    as.gt = gt; as.gt_mask = gt_mask; as.mask_embed = cn_mode ? h->ext_mask_embed : h->w<float>("mask_embed");
     as.out = h->buf<bf16_t>("ape"); as.ldo = h->ldPE;
     as.B = h->B; as.C = h->C; as.L = h->L;
     STOPCHK();
@@ -548,17 +599,19 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     STOPCHK();
     gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, tile_for(h, M, false));
 
+    const float* part_src = part;
     auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
                    long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
                    int ld_u) {
         RowArgs r;
         memset(&r, 0, sizeof r);
         r.h_in = h_in; r.h_out = h_out;
-        r.part = part; r.nsplit = nsplit; r.part_stride = (long)Mp * D; r.ld_part = D;
+        r.part = part_src; r.nsplit = nsplit; r.part_stride = (long)Mp * D; r.ld_part = D;
+        r.cn_scale = h->cn_scale;
         r.bias = bias; r.gate = gate; r.gate_slot_stride = gate_stride; r.mode = mode;
         r.ln_g = lg; r.ln_c = lc; r.ln_slot_stride = ln_stride;
         r.skip = skip; r.cn = cnp;
-        r.u = u; r.ld_u = ld_u;
+        r.u = lg ? u : nullptr; r.ld_u = ld_u;
         r.M = M; r.D = D; r.L = h->L;
         r.cur_step = cur; r.row_slot = row_slot;
         launch_row(r, st);
@@ -566,9 +619,15 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     };
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
 
-    // LN1 of block 0 on the patch embedding
+    // LN1 of block 0 on the patch embedding (ControlNet: x = patch_embed(x) + controlnet_pre(condition) first, :263-266)
     STOPCHK();
-    row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
+    if (cn_mode) {
+        part_src = h->buf<float>("cembed");
+        row(1, hA, hA, 1, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
+        part_src = part;
+    } else {
+        row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
+    }
     const float* hcur = hA;
 
     // weight prefetch: while block b computes, a side stream pulls block b+1's per-step matrices into the Infinity Cache
@@ -656,7 +715,10 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
         const float* b2 = h->w<float>(bn(b, "b2"));
-        if (b == nblk - 1) {
+        if (cn_mode && b == nblk - 1) {
+            STOPCHK();
+            row(1, hA, skips + (size_t)b * Mp * D, s, b2, modv(b, 5), mod_slot, nullptr, nullptr, 0, nullptr, nullptr, h->ldD);
+        } else if (b == nblk - 1) {
             const float* mf = h->buf<float>("modf");
             STOPCHK();
             row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, mf, mf + D, 2L * D, nullptr, nullptr, h->ldD);
@@ -673,6 +735,16 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             row(1, hA, dst, s, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
+    }
+    if (cn_mode) {
+        // controlnet_skips[i] = zero_Linear_i(skip_i) (* conditioning_scale, applied by the consumer)  controlnet.py:311-313
+        for (int i = 0; i < nblk; ++i) {
+            launch_cast_bf16(skips + (size_t)i * Mp * D, D, h->buf<bf16_t>("skipbf"), h->ldD, M, D, 0, st);
+            h->launches++;
+            gemm(c, h->buf<bf16_t>("skipbf"), h->ldD, bn(i, "zw"), h->w<float>(bn(i, "zb")),
+                 h->buf<float>("cnres") + (size_t)i * Mp * D, D, M, D, EPI_F32, tile_for(h, M, false));
+        }
+        return EZDIT_OK;
     }
     // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
     STOPCHK();
@@ -695,6 +767,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
 int ezdit_forward(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
                   const float* const* cn_skips, int n_cn, float* out, ezdit_stream stream) {
     if (!h || !x || !out) return fail(EZDIT_E_INVALID, "null argument");
+    if (h->is_cn) return fail(EZDIT_E_INVALID, "this handle is a ControlNet: use ezdit_controlnet_forward");
     if (!h->wblob || !h->ws) return fail(EZDIT_E_STATE, "bind weights and workspace first");
     if (!h->ctx_ready) return fail(EZDIT_E_STATE, "ezdit_prepare_context has not run for this workspace");
     if (!h->ts_ready) return fail(EZDIT_E_STATE, "ezdit_prepare_timesteps has not run for this workspace");
@@ -703,6 +776,71 @@ int ezdit_forward(ezdit_handle* h, const float* x, int in_ch, int x_rows, const 
     if ((gt == nullptr) != (gt_mask == nullptr)) return fail(EZDIT_E_INVALID, "gt and gt_mask must be given together");
     if (n_cn != 0 && n_cn != h->nhalf) return fail(EZDIT_E_INVALID, "n_cn %d: expected 0 or %d", n_cn, h->nhalf);
     return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, cn_skips, n_cn, out, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------------
+int ezdit_prepare_condition(ezdit_handle* h, const float* cond, int Lcond, ezdit_stream stream) {
+    if (!h || !cond) return fail(EZDIT_E_INVALID, "null argument");
+    if (!h->is_cn) return fail(EZDIT_E_INVALID, "not a ControlNet handle");
+    if (!h->wblob || !h->ws) return fail(EZDIT_E_STATE, "bind weights and workspace first");
+    if (Lcond != 2 * h->L) return fail(EZDIT_E_INVALID, "condition length %d != 2 * L (%d): the embed has one stride-2 conv", Lcond, 2 * h->L);
+    hipStream_t st = (hipStream_t)stream;
+    Conv1dArgs a;
+    memset(&a, 0, sizeof a);
+    // conv_in: Conv1d(cond_in, c0, 1)                                               controlnet.py:15,66
+    a.x = cond; a.w = h->w<float>("cn.cin.w"); a.b = h->w<float>("cn.cin.b"); a.out = h->buf<float>("cn_e0");
+    a.B = h->B; a.Cin = h->cfg.cond_in; a.cin_valid = a.Cin; a.Cout = h->c0; a.Lin = Lcond; a.Lout = Lcond; a.ksize = 1; a.stride = 1; a.pad = 0;
+    launch_conv1d(a, st);
+    // eval: no position is masked, the appended mask channel is all zeros (:68-74) -> channel c0 is an implicit zero input
+    a.x = h->buf<float>("cn_e0"); a.w = h->w<float>("cn.c0.w"); a.b = h->w<float>("cn.c0.b"); a.out = h->buf<float>("cn_e1");
+    a.Cin = h->c0m; a.cin_valid = h->c0; a.Cout = h->c0m; a.ksize = 3; a.pad = 1; a.act = 1;
+    launch_conv1d(a, st);
+    a.x = h->buf<float>("cn_e1"); a.w = h->w<float>("cn.c1.w"); a.b = h->w<float>("cn.c1.b"); a.out = h->buf<float>("cn_e2");
+    a.Cin = h->c0m; a.cin_valid = h->c0m; a.Cout = h->c1; a.Lout = h->L; a.stride = 2;
+    launch_conv1d(a, st);
+    // conv_out: Conv1d(c1, D, 1) then transpose to [B, L, D]                         :37,79-82
+    a.x = h->buf<float>("cn_e2"); a.w = h->w<float>("cn.cout.w"); a.b = h->w<float>("cn.cout.b"); a.out = h->buf<float>("cembed");
+    a.Cin = h->c1; a.cin_valid = h->c1; a.Cout = h->D; a.Lin = h->L; a.Lout = h->L; a.ksize = 1; a.stride = 1; a.pad = 0; a.act = 0;
+    a.out_token_major = 1;
+    launch_conv1d(a, st);
+    h->cond_ready = true;
+    return EZDIT_OK;
+}
+
+int ezdit_controlnet_forward(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
+                             const float* mask_embed, ezdit_stream stream) {
+    if (!h || !x) return fail(EZDIT_E_INVALID, "null argument");
+    if (!h->is_cn) return fail(EZDIT_E_INVALID, "not a ControlNet handle");
+    if (!h->wblob || !h->ws) return fail(EZDIT_E_STATE, "bind weights and workspace first");
+    if (!h->ctx_ready || !h->ts_ready || !h->cond_ready) return fail(EZDIT_E_STATE, "prepare context, timesteps and condition first");
+    if (in_ch != h->C && in_ch != h->Cin) return fail(EZDIT_E_INVALID, "in_ch %d: expected %d or %d", in_ch, h->C, h->Cin);
+    if (in_ch == h->C && !mask_embed) return fail(EZDIT_E_INVALID, "in_ch = C needs the backbone's mask_embed");
+    if (in_ch == h->C && (x_rows <= 0 || h->B % x_rows)) return fail(EZDIT_E_INVALID, "x_rows %d does not divide B %d", x_rows, h->B);
+    h->ext_mask_embed = mask_embed;
+    return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, nullptr, 0, nullptr, (hipStream_t)stream);
+}
+
+int ezdit_controlnet_residuals(ezdit_handle* h, const float** out, int n) {
+    if (!h || !out || !h->is_cn || !h->ws) return fail(EZDIT_E_INVALID, "need a bound ControlNet handle");
+    if (n != h->nhalf) return fail(EZDIT_E_INVALID, "n %d != depth/2 %d", n, h->nhalf);
+    for (int i = 0; i < n; ++i) out[i] = h->buf<float>("cnres") + (size_t)i * h->Mp * h->D;
+    return EZDIT_OK;
+}
+
+int ezdit_sampler_attach_controlnet(ezdit_handle* h, ezdit_handle* cn, float conditioning_scale) {
+    if (!h || h->is_cn) return fail(EZDIT_E_INVALID, "first argument must be a backbone handle");
+    if (cn && !cn->is_cn) return fail(EZDIT_E_INVALID, "second argument must be a ControlNet handle");
+    h->cn = cn;
+    h->cn_scale = cn ? conditioning_scale : 1.0f;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    return EZDIT_OK;
+}
+
+int ezdit_set_cn_scale(ezdit_handle* h, float scale) {
+    if (!h) return fail(EZDIT_E_INVALID, "null handle");
+    h->cn_scale = scale;
+    return EZDIT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -734,7 +872,19 @@ int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noi
 
 static int sampler_step(ezdit_handle* h, hipStream_t st) {
     float* pred = h->buf<float>("pred");
-    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, pred, st);
+    const float* cnp[64];
+    int n_cn = 0;
+    if (h->cn) {  // src/inference_controlnet.py:89-99: ControlNet on the same assembled input, then the backbone with its skips
+        ezdit_handle* cn = h->cn;
+        if (cn->B != h->B || cn->L != h->L || cn->nhalf != h->nhalf || cn->D != h->D || !cn->ctx_ready || !cn->ts_ready || !cn->cond_ready)
+            return fail(EZDIT_E_STATE, "attached ControlNet is not prepared for this shape (bind/context/timesteps/condition)");
+        cn->ext_mask_embed = h->w<float>("mask_embed");
+        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, nullptr, st);
+        if (rc0) return rc0;
+        n_cn = cn->nhalf;
+        for (int i = 0; i < n_cn; ++i) cnp[i] = cn->buf<float>("cnres") + (size_t)i * cn->Mp * cn->D;
+    }
+    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, pred, st);
     if (rc) return rc;
     CfgDdimArgs a;
     a.pred = pred; a.latents = h->latents; a.noise = h->noise;

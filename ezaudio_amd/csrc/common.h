@@ -71,6 +71,7 @@ struct RowArgs {
     int mode;  // 0 COPY, 1 RES, 2 SET
     // LN output: u = LN(x) * g + c (per-slot or static vectors), bf16, zero padded to ld_u
     const float* ln_g; const float* ln_c; long ln_slot_stride;
+    float cn_scale;                      // multiplies cn (conditioning_scale, controlnet.py:313)
     const float* skip; const float* cn;  // concat mode: x = [h_new | skip (+ cn)], LN over 2D with ln_g/ln_c of length 2D
     bf16_t* u; int ld_u;
     int M, D, L;           // rows, width, rows per batch element
@@ -121,6 +122,7 @@ struct ModFinalizeArgs {
     const float* nfw; const float* nfb;
     float* mod_final;       // [n][2][D]: gF,cF
     int n, nblk, D;
+    int has_final;          // 0 for the ControlNet (no FinalBlock)
 };
 void launch_mod_finalize(const ModFinalizeArgs& a, hipStream_t st);
 
@@ -138,4 +140,11 @@ struct CfgDdimArgs {
 void launch_cfg_ddim(const CfgDdimArgs& a, float* partial /* [P][64][4] scratch */, hipStream_t st);
 void launch_prefetch(const void* p, size_t bytes, unsigned* sink, hipStream_t st);  // warm the Infinity Cache
 void launch_set_int(int* p, int v, int add, hipStream_t st);  // *p = add ? *p + v : v
+struct Conv1dArgs {  // out[b][co][lo] = act(bias[co] + sum_{ci,k} w[co][ci][k] * x[b][ci][lo*stride + k - pad]); fp32
+    const float* x; const float* w; const float* b; float* out;
+    int B, Cin, Cout, Lin, Lout, ksize, stride, pad, act;  // act 1 = SiLU
+    int cin_valid;      // channels >= cin_valid of x are implicit zeros (the eval-time mask channel)
+    int out_token_major;  // 1: out[b][lo][co] (token-major rows, ld = Cout)
+};
+void launch_conv1d(const Conv1dArgs& a, hipStream_t st);
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
                 float4 v = ld4(a.skip + (long)row * D + c * 4);
                 if (a.cn) {
                     const float4 w = ld4(a.cn + (long)row * D + c * 4);
-                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                    v.x += a.cn_scale * w.x; v.y += a.cn_scale * w.y; v.z += a.cn_scale * w.z; v.w += a.cn_scale * w.w;
                 }
                 y[j] = v;
             }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_linear_f32(const float* __restrict__ x,
 __global__ __launch_bounds__(256) void k_mod_finalize(ModFinalizeArgs a) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int D = a.D;
-    const long per_slot = (long)(a.nblk + 1) * D;  // nblk block entries + 1 final entry
+    const long per_slot = (long)(a.nblk + a.has_final) * D;  // nblk block entries (+ 1 final entry)
     if (idx >= per_slot * a.n) return;
     const int s = (int)(idx / per_slot);
     const int r = (int)(idx % per_slot);
@@ -435,19 +435,44 @@ __global__ __launch_bounds__(256) void k_cfg_apply(CfgDdimArgs a, const float* p
 
 __global__ void k_set_int(int* p, int v, int add) { *p = add ? *p + v : v; }
 
+// small direct Conv1d in fp32 for the ControlNet condition embed (controlnet.py:15-39,65-84): 4 tiny layers, once per call
+__global__ __launch_bounds__(256) void k_conv1d(Conv1dArgs a) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.Cout * a.Lout;
+    if (idx >= total) return;
+    const int lo = (int)(idx % a.Lout);
+    const int co = (int)((idx / a.Lout) % a.Cout);
+    const int b = (int)(idx / ((long)a.Lout * a.Cout));
+    float acc = a.b ? a.b[co] : 0.f;
+    for (int ci = 0; ci < a.cin_valid; ++ci) {
+        const float* xr = a.x + ((long)b * a.cin_valid + ci) * a.Lin;
+        const float* wr = a.w + ((long)co * a.Cin + ci) * a.ksize;
+        for (int k = 0; k < a.ksize; ++k) {
+            const int li = lo * a.stride + k - a.pad;
+            if (li >= 0 && li < a.Lin) acc += wr[k] * xr[li];
+        }
+    }
+    if (a.act == 1) acc = acc / (1.f + expf(-acc));
+    if (a.out_token_major) a.out[((long)b * a.Lout + lo) * a.Cout + co] = acc;
+    else a.out[((long)b * a.Cout + co) * a.Lout + lo] = acc;
+}
+
+// EXPERIMENT, off by default (ezdit_set_option "prefetch"): measured -9...-13 % on MI355X, see DESIGN.md.
 // Touch a byte range so that it is resident in the memory-side Infinity Cache (256 MB) when the GEMMs of the NEXT block ask
 // for it: the step streams 1.75 GB of weights exactly once, every GEMM workgroup would otherwise start with an HBM round
 // trip (measured: the same GEMM takes 10 us on warm weights and 17 us in the step).  Runs on a side stream next to the
 // compute kernels; 64 small workgroups, so it takes CU slots from nobody.
-__global__ __launch_bounds__(256) void k_prefetch(const uint4* __restrict__ p, long n16, unsigned* sink) {
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__global__ __launch_bounds__(256) void k_prefetch(const u32x4* __restrict__ p, long n16, unsigned* sink) {
     unsigned acc = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256 * 4) {
-        // 4 independent 16-byte loads in flight per thread
-        const long i1 = i + (long)gridDim.x * 256, i2 = i1 + (long)gridDim.x * 256, i3 = i2 + (long)gridDim.x * 256;
-        const uint4 a = p[i];
-        const uint4 b = i1 < n16 ? p[i1] : a;
-        const uint4 c = i2 < n16 ? p[i2] : a;
-        const uint4 d = i3 < n16 ? p[i3] : a;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * 4) {
+        // 4 independent 16-byte non-temporal loads in flight per thread (stream through L2, fill the Infinity Cache)
+        const long i1 = i + stride, i2 = i1 + stride, i3 = i2 + stride;
+        const u32x4 a = __builtin_nontemporal_load(p + i);
+        const u32x4 b = i1 < n16 ? __builtin_nontemporal_load(p + i1) : a;
+        const u32x4 c = i2 < n16 ? __builtin_nontemporal_load(p + i2) : a;
+        const u32x4 d = i3 < n16 ? __builtin_nontemporal_load(p + i3) : a;
         acc ^= a.x ^ b.y ^ c.z ^ d.w;
     }
     if (acc == 0x9e3779b9u) *sink = acc;  // never true in practice; keeps the loads alive
@@ -503,7 +528,7 @@ void launch_linear_f32(const float* x, const int* ts, int x_mode, const float* W
 }
 
 void launch_mod_finalize(const ModFinalizeArgs& a, hipStream_t st) {
-    const long total = (long)(a.nblk + 1) * a.D * a.n;
+    const long total = (long)(a.nblk + a.has_final) * a.D * a.n;
     hipLaunchKernelGGL(k_mod_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
 }
 
@@ -525,7 +550,12 @@ void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int 
 
 void launch_prefetch(const void* p, size_t bytes, unsigned* sink, hipStream_t st) {
     if (bytes < 16) return;
-    hipLaunchKernelGGL(k_prefetch, dim3(64), dim3(256), 0, st, reinterpret_cast<const uint4*>(p), (long)(bytes / 16), sink);
+    hipLaunchKernelGGL(k_prefetch, dim3(32), dim3(256), 0, st, reinterpret_cast<const u32x4*>(p), (long)(bytes / 16), sink);
+}
+
+void launch_conv1d(const Conv1dArgs& a, hipStream_t st) {
+    const long total = (long)a.B * a.Cout * a.Lout;
+    hipLaunchKernelGGL(k_conv1d, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
 }
 
 void launch_set_int(int* p, int v, int add, hipStream_t st) {

@@ -29,7 +29,8 @@ class LatentSampler:
         self.latents = None
 
     def prepare(self, text, text_mask, uncond_text, uncond_mask, init_noise, step_noises, guidance_scale,
-                guidance_rescale, ddim_steps, eta, gt=None, gt_mask=None):
+                guidance_rescale, ddim_steps, eta, gt=None, gt_mask=None, controlnet=None, condition=None,
+                conditioning_scale=1.0):
         u = self.unet
         dev = u.device
         P, Cc, L = init_noise.shape
@@ -55,6 +56,15 @@ class LatentSampler:
             u.bind(B, L, ctx.shape[1], ddim_steps)
             u.prepare_context(ctx, msk)
             u.prepare_timesteps(ts, per_row=False)
+            if controlnet is not None:  # src/inference_controlnet.py:78-99: condition duplicated for the CFG pair
+                cond = torch.cat([condition, condition], dim=0) if use_cfg else condition
+                controlnet.bind(B, L, ctx.shape[1], ddim_steps)
+                controlnet.prepare_context(ctx, msk)
+                controlnet.prepare_timesteps(ts, per_row=False)
+                controlnet.prepare_condition(cond)
+            _lib.check(u.lib.ezdit_sampler_attach_controlnet(u._h, controlnet._h if controlnet is not None else None,
+                                                             float(conditioning_scale)))
+            self.controlnet = controlnet
             arr = (_lib.EzditDdimCoef * ddim_steps)(*[_lib.EzditDdimCoef(*c) for c in coefs])
             _lib.check(u.lib.ezdit_sampler_begin(u._h, _ptr(self.latents), P, _ptr(self.noise), arr, ddim_steps,
                                                  float(guidance_scale or 0.0), float(guidance_rescale or 0.0),
@@ -96,9 +106,20 @@ def draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n
 
 
 @torch.no_grad()
+def inference_controlnet(autoencoder, unet, controlnet, gt, gt_mask, condition, tokenizer, text_encoder, params,
+                         noise_scheduler, text_raw, neg_text=None, audio_frames=500, guidance_scale=3,
+                         guidance_rescale=0.0, ddim_steps=50, eta=1, random_seed=2024, conditioning_scale=1.0,
+                         device='cuda', use_graph=True):
+    """Same signature and semantics as the reference's ControlNet ``inference`` (src/inference_controlnet.py:27-129)."""
+    return inference(autoencoder, unet, gt, gt_mask, tokenizer, text_encoder, params, noise_scheduler, text_raw, neg_text,
+                     audio_frames, guidance_scale, guidance_rescale, ddim_steps, eta, random_seed, device, use_graph,
+                     controlnet=controlnet, condition=condition, conditioning_scale=conditioning_scale)
+
+
+@torch.no_grad()
 def inference(autoencoder, unet, gt, gt_mask, tokenizer, text_encoder, params, noise_scheduler, text_raw,
               neg_text=None, audio_frames=500, guidance_scale=3, guidance_rescale=0.0, ddim_steps=50, eta=1,
-              random_seed=2024, device='cuda', use_graph=True):
+              random_seed=2024, device='cuda', use_graph=True, controlnet=None, condition=None, conditioning_scale=1.0):
     """Same signature and semantics as the reference's ``inference`` (src/inference.py:26-107)."""
     if neg_text is None:
         neg_text = [""]
@@ -121,7 +142,8 @@ def inference(autoencoder, unet, gt, gt_mask, tokenizer, text_encoder, params, n
     init, step_noises = draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n_prompts)
     smp = LatentSampler(unet, noise_scheduler)
     smp.prepare(text.float(), text_mask, uncond_text.float(), uncond_mask, init, step_noises, guidance_scale,
-                guidance_rescale, ddim_steps, eta, gt=gt, gt_mask=gt_mask)
+                guidance_rescale, ddim_steps, eta, gt=gt, gt_mask=gt_mask, controlnet=controlnet, condition=condition,
+                conditioning_scale=conditioning_scale)
     smp.run(use_graph=use_graph)
     latents = smp.finish()
     pred = scale_shift_re(latents, params['autoencoder']['scale'], params['autoencoder']['shift'])

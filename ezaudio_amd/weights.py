@@ -121,3 +121,39 @@ def random_state_dict(model_cfg, seed=0):
     mat('model.final_block.linear.weight', C, D); vec('model.final_block.linear.bias', C)
     mat('model.final_block.final_layer.weight', C, C, 3); vec('model.final_block.final_layer.bias', C)
     return sd
+
+
+def random_controlnet_state_dict(model_cfg, cn_cfg, seed=0):
+    """Random-init DiTControlNet weights with the reference's key names (src/models/controlnet.py): the backbone's
+    embeds + first depth/2 blocks without the 'model.' prefix, controlnet_pre.*, controlnet_zero_blocks.* -- all non-zero
+    (the reference zero-initialises conv_out and the zero blocks, which would make the branch a no-op)."""
+    full = random_state_dict(model_cfg, seed)
+    D = model_cfg['embed_dim']
+    sd = {}
+    for k, v in full.items():
+        if not k.startswith('model.'):
+            continue
+        k2 = k[len('model.'):]
+        if k2.startswith(('mid_block', 'out_blocks', 'final_block', 'time_ada_final')):
+            continue
+        sd[k2] = v
+    g = torch.Generator().manual_seed(seed + 1)
+    c0, c1 = cn_cfg['cond_blocks']
+    c0m = c0 + (1 if cn_cfg.get('cond_mask') else 0)
+
+    def t(*shape, std):
+        return torch.randn(*shape, generator=g) * std
+    sd['controlnet_pre.conv_in.weight'] = t(c0, cn_cfg['cond_in'], 1, std=0.5)
+    sd['controlnet_pre.conv_in.bias'] = t(c0, std=0.02)
+    if cn_cfg.get('cond_mask'):
+        sd['controlnet_pre.mask_embed'] = t(c0, std=0.02)
+    sd['controlnet_pre.blocks.0.0.weight'] = t(c0m, c0m, 3, std=(1.0 / (3 * c0m)) ** 0.5)
+    sd['controlnet_pre.blocks.0.0.bias'] = t(c0m, std=0.02)
+    sd['controlnet_pre.blocks.0.2.weight'] = t(c1, c0m, 3, std=(1.0 / (3 * c0m)) ** 0.5)
+    sd['controlnet_pre.blocks.0.2.bias'] = t(c1, std=0.02)
+    sd['controlnet_pre.conv_out.weight'] = t(D, c1, 1, std=0.02)
+    sd['controlnet_pre.conv_out.bias'] = t(D, std=0.02)
+    for i in range(model_cfg['depth'] // 2):
+        sd[f'controlnet_zero_blocks.{i}.weight'] = t(D, D, std=(1.0 / D) ** 0.5 * 0.2)
+        sd[f'controlnet_zero_blocks.{i}.bias'] = t(D, std=0.02)
+    return sd

@@ -48,6 +48,13 @@ typedef struct {
     float   ada_sola_alpha;
     float   mlp_ratio;     /* 4.0 */
     int32_t max_len;       /* longest latent sequence the RoPE table covers */
+    /* ControlNet variant (src/models/controlnet.py:87-315): the first depth/2 blocks of the backbone + condition embed +
+     * one zero-initialised Linear per skip; no mid/out blocks, no final block.  0 = plain UDiT. */
+    int32_t controlnet;
+    int32_t cond_in;       /* channels of the control signal (1 for energy) */
+    int32_t cond_c0;       /* cond_blocks[0] = 64 (+1 mask channel when cond_mask) */
+    int32_t cond_c1;       /* cond_blocks[1] = 128 */
+    int32_t cond_mask;     /* DiTControlNetEmbed cond_mask: append the (all-zero at inference) mask channel */
 } ezdit_config;
 
 enum {
@@ -118,6 +125,22 @@ int ezdit_forward(ezdit_handle* h, const float* dev_x, int in_ch, int x_rows,
                   const float* dev_gt, const uint8_t* dev_gt_mask,
                   const float* const* cn_skips, int n_cn,
                   float* dev_out, ezdit_stream stream);
+
+/* ---- ControlNet (handle created with cfg.controlnet = 1) ------------------------------------------------ */
+/* DiTControlNetEmbed (controlnet.py:65-84) on the control signal, hoisted out of the step loop (it depends on the
+ * condition only): cond fp32 [B, cond_in, Lcond] with Lcond = 2 L (the embed has one stride-2 conv). */
+int ezdit_prepare_condition(ezdit_handle* cn, const float* dev_cond, int Lcond, ezdit_stream stream);
+/* DiTControlNet.forward (controlnet.py:252-315): x as in ezdit_forward (in_ch = C needs `dev_mask_embed`, the [C] fp32
+ * mask_embed of the MaskDiT that assembles the input, conditioners.py:161-176); the depth/2 residuals
+ * zero_linear_i(skip_i) land in the ControlNet workspace.  They are NOT yet multiplied by conditioning_scale. */
+int ezdit_controlnet_forward(ezdit_handle* cn, const float* dev_x, int in_ch, int x_rows, const float* dev_gt,
+                             const uint8_t* dev_gt_mask, const float* dev_mask_embed, ezdit_stream stream);
+/* pointers to the residuals of the last ezdit_controlnet_forward, in the reference's list order (out[i] <-> skip i) */
+int ezdit_controlnet_residuals(ezdit_handle* cn, const float** out, int n);
+/* the backbone's sampler then runs ControlNet + backbone per step (src/inference_controlnet.py:89-99) */
+int ezdit_sampler_attach_controlnet(ezdit_handle* h, ezdit_handle* cn, float conditioning_scale);
+/* scale applied to cn_skips inside ezdit_forward (default 1.0: residuals already scaled by the caller) */
+int ezdit_set_cn_scale(ezdit_handle* h, float scale);
 
 /* ---- sampler: CFG + rescale + DDIM, src/inference.py:70-100 + diffusers DDIMScheduler.step ---- */
 typedef struct {

@@ -90,9 +90,10 @@ def sdpa(q, k, v, key_mask=None):
 class DiTOracle:
     """MaskDiT.forward restated (src/models/conditioners.py:156-183 -> src/models/udit.py:281-362)."""
 
-    def __init__(self, cfg, sd, dtype=np.float32):
+    def __init__(self, cfg, sd, dtype=np.float32, prefix='model.'):
         self.cfg = cfg
         self.dtype = dtype
+        self.prefix = prefix  # '' for DiTControlNet (not wrapped by MaskDiT)
         self.sd = {k: np.asarray(v).astype(dtype) for k, v in sd.items()}
         self.D = cfg['embed_dim']
         self.H = cfg['num_heads']
@@ -196,8 +197,8 @@ class DiTOracle:
 
     # --- A6: context path, udit.py:94-97,295-296 ----------------------------------------------------
     def context_embed(self, ctx):
-        c = linear(np.asarray(ctx, dtype=self.dtype), self.p('model.context_embed.0.weight'), self.p('model.context_embed.0.bias'))
-        return linear(silu(c), self.p('model.context_embed.2.weight'), self.p('model.context_embed.2.bias'))
+        c = linear(np.asarray(ctx, dtype=self.dtype), self.p(self.prefix + 'context_embed.0.weight'), self.p(self.prefix + 'context_embed.0.bias'))
+        return linear(silu(c), self.p(self.prefix + 'context_embed.2.weight'), self.p(self.prefix + 'context_embed.2.bias'))
 
     # --- A7: time path, modules.py:50-60; udit.py:305-316 -------------------------------------------
     def time_path(self, t, B):
@@ -205,11 +206,14 @@ class DiTOracle:
         if t.ndim == 0:  # udit.py:286-287
             t = np.broadcast_to(t, (B,))
         e = timestep_embedding(t, 256, self.dtype)
-        tt = linear(silu(linear(e, self.p('model.time_embed.mlp.0.weight'), self.p('model.time_embed.mlp.0.bias'))),
-                    self.p('model.time_embed.mlp.2.weight'), self.p('model.time_embed.mlp.2.bias'))
+        m = self.prefix
+        tt = linear(silu(linear(e, self.p(m + 'time_embed.mlp.0.weight'), self.p(m + 'time_embed.mlp.0.bias'))),
+                    self.p(m + 'time_embed.mlp.2.weight'), self.p(m + 'time_embed.mlp.2.bias'))
         tt = silu(tt)  # time_act, udit.py:313
-        ada_final = linear(tt, self.p('model.time_ada_final.weight'), self.p('model.time_ada_final.bias'))
-        ada = linear(tt, self.p('model.time_ada.weight'), self.p('model.time_ada.bias'))
+        ada_final = None
+        if (m + 'time_ada_final.weight') in self.sd:  # the ControlNet has no FinalBlock (controlnet.py:160-168)
+            ada_final = linear(tt, self.p(m + 'time_ada_final.weight'), self.p(m + 'time_ada_final.bias'))
+        ada = linear(tt, self.p(m + 'time_ada.weight'), self.p(m + 'time_ada.bias'))
         return tt, ada, ada_final
 
     # --- A17: UDiT.forward, udit.py:281-362 ---------------------------------------------------------

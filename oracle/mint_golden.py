@@ -133,6 +133,42 @@ class _OracleScheduler:
         return types.SimpleNamespace(prev_sample=torch.from_numpy(out))
 
 
+def mint_controlnet(name, size, L, Lc, t, seed_w, seed_in, scale=1.0, out_dir='tests/golden'):
+    """Reference DiTControlNet residuals + the backbone's prediction with them (src/inference_controlnet.py:89-99)."""
+    import torch
+    from .controlnet import CN_DEFAULT, make_controlnet_state_dict
+    from .weights import model_config, make_inputs, uniform_pm1
+    _import_reference()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.models.controlnet import DiTControlNet
+    cfg = model_config(size)
+    m, _ = build_reference(cfg, seed_w)
+    ccfg = dict(cfg)
+    ccfg.update({k: (list(v) if isinstance(v, list) else v) for k, v in CN_DEFAULT.items()})
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = DiTControlNet(**ccfg).eval()
+    sd = make_controlnet_state_dict(cfg, CN_DEFAULT, seed_w)
+    ref_sd = cn.state_dict()
+    assert set(ref_sd.keys()) == set(sd.keys()) | {k for k in ref_sd if k.endswith('inv_freq')}, sorted(set(ref_sd) ^ set(sd))[:10]
+    for k, v in sd.items():
+        assert tuple(ref_sd[k].shape) == v.shape, (k, tuple(ref_sd[k].shape), v.shape)
+    cn.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=False)
+    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, n_valid=(7, 1), seed=seed_in)
+    cond = (0.5 + 0.5 * uniform_pm1('in.cond', 2 * 2 * L, seed_in)).reshape(2, 1, 2 * L)
+    with torch.no_grad():
+        x257, _ = m(torch.from_numpy(inp['x'].copy()), torch.tensor(t), None, forward_model=False)
+        skips = cn(x257, torch.tensor(t), torch.from_numpy(inp['ctx']), context_mask=torch.from_numpy(inp['ctx_mask']),
+                   cls_token=None, condition=torch.from_numpy(cond), conditioning_scale=scale)
+        res = [s_.numpy().copy() for s_ in skips]
+        pred = m.model(x257, torch.tensor(t), torch.from_numpy(inp['ctx']), context_mask=torch.from_numpy(inp['ctx_mask']),
+                       cls_token=None, controlnet_skips=list(skips))
+    meta = dict(size=size, L=L, Lc=Lc, t=t, seed_w=seed_w, seed_in=seed_in, scale=scale)
+    path = os.path.join(out_dir, f'{name}.npz')
+    np.savez(path, meta=np.array(repr(meta)), pred=pred.numpy().astype(np.float32),
+             **{f'res{i}': r.astype(np.float32) for i, r in enumerate(res)})
+    print('wrote', path, pred.shape, float(pred.std()), [float(r.std()) for r in res])
+
+
 DIFF = dict(num_train_timesteps=1000, beta_schedule='scaled_linear', beta_start=0.00085, beta_end=0.012,
             prediction_type='v_prediction', rescale_betas_zero_snr=True, timestep_spacing='trailing',
             clip_sample=False)
@@ -185,6 +221,8 @@ JOBS = {
     's_edit':    (mint_forward, dict(size='s', L=300, Lc=100, timesteps=[499], seed_w=1234, seed_in=12, with_gt=True)),
     'l':         (mint_forward, dict(size='l', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=11)),
     'xl':        (mint_forward, dict(size='xl', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=11)),
+    'cn_xs':     (mint_controlnet, dict(size='xs', L=96, Lc=20, t=499, seed_w=1, seed_in=31, scale=1.0)),
+    'cn_s':      (mint_controlnet, dict(size='s', L=100, Lc=20, t=979, seed_w=1234, seed_in=32, scale=0.7)),
     'smp_xs':    (mint_sampler, dict(size='xs', L=96, Lc=20, steps=50, seed_w=1, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
     'smp_xs_e0': (mint_sampler, dict(size='xs', L=96, Lc=20, steps=20, seed_w=1, seed_in=22, guidance_scale=3.5, guidance_rescale=0.0, eta=0.0, with_gt=True)),
     'smp_s':     (mint_sampler, dict(size='s', L=500, Lc=100, steps=50, seed_w=1234, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),

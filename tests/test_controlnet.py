@@ -1,0 +1,143 @@
+"""ControlNet branch: oracle vs the reference goldens on CPU, HIP path vs both on the GPU."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+from oracle.controlnet import CN_DEFAULT, ControlNetOracle, conv1d, energy_curve, make_controlnet_state_dict
+from oracle.dit import DiTOracle
+from oracle.weights import make_inputs, make_state_dict, model_config, uniform_pm1
+from tests.util import GOLDEN, rel_l2
+
+
+def cn_case(name):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    meta = ast.literal_eval(str(g['meta']))
+    cfg = model_config(meta['size'])
+    sd = make_state_dict(cfg, meta['seed_w'])
+    csd = make_controlnet_state_dict(cfg, CN_DEFAULT, meta['seed_w'])
+    inp = make_inputs(cfg, B=2, L=meta['L'], Lc=meta['Lc'], n_valid=(7, 1), seed=meta['seed_in'])
+    cond = (0.5 + 0.5 * uniform_pm1('in.cond', 2 * 2 * meta['L'], meta['seed_in'])).reshape(2, 1, 2 * meta['L'])
+    return cfg, sd, csd, inp, cond, g, meta
+
+
+@pytest.mark.parametrize('name', ['cn_xs', 'cn_s'])
+def test_controlnet_oracle_matches_reference_golden(name):
+    cfg, sd, csd, inp, cond, g, meta = cn_case(name)
+    o = DiTOracle(cfg, sd)
+    co = ControlNetOracle(cfg, csd)
+    x257, _ = o.assemble_input(inp['x'])
+    res = co.forward(x257, meta['t'], inp['ctx'], inp['ctx_mask'], cond, meta['scale'])
+    assert len(res) == cfg['depth'] // 2
+    for i, r in enumerate(res):
+        assert rel_l2(r, g[f'res{i}']) < 1e-5
+    pred = o.udit_forward(x257, meta['t'], inp['ctx'], inp['ctx_mask'], controlnet_skips=res)
+    assert rel_l2(pred, g['pred']) < 1e-5
+
+
+def test_conv1d_and_energy_curve_against_torch():
+    import torch
+    import torch.nn.functional as F
+    x = uniform_pm1('x', 2 * 5 * 40, 0).reshape(2, 5, 40)
+    w = uniform_pm1('w', 7 * 5 * 3, 1).reshape(7, 5, 3)
+    b = uniform_pm1('b', 7, 2)
+    for stride in (1, 2):
+        ref = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=1).numpy()
+        np.testing.assert_allclose(conv1d(x, w, b, stride, 1), ref, rtol=1e-5, atol=1e-6)
+    # EnergyExtractor restated with torch ops exactly as energy.py:19-56 writes them
+    wav = 0.1 * uniform_pm1('wav', 24000, 5).reshape(1, 24000)
+    a = torch.from_numpy(wav)
+    pad = (1920 - 240) // 2
+    sq = F.pad(a, (pad, pad), mode='reflect') ** 2
+    en = F.unfold(sq[:, None, None, :], (1, 1920), stride=240)[:, :, :100].mean(dim=1)
+    gdb = 10 * torch.log10(torch.maximum(en, torch.tensor(np.power(10, -60 / 10))))
+    gdb = (gdb + 60) / (gdb.max(dim=-1, keepdim=True)[0] + 60 + 1e-8)
+    np.testing.assert_allclose(energy_curve(wav)[..., 0], gdb.numpy(), rtol=1e-4, atol=1e-5)
+    from ezaudio_amd.conditions import Conditioner
+    c = Conditioner('energy', hop_size=240, window_size=1920, padding='reflect', min_db=-60, norm=True)(a, (1, 128, 50))
+    assert c.shape == (1, 1, 100)
+    np.testing.assert_allclose(c[:, 0].numpy(), gdb.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _models(cfg, sd, csd):
+    from ezaudio_amd import DiTControlNet, MaskDiT
+    m = MaskDiT(device='cuda:0', **cfg)
+    m.load_state_dict(sd)
+    ccfg = dict(cfg)
+    ccfg.update(CN_DEFAULT)
+    cn = DiTControlNet(device='cuda:0', **ccfg)
+    cn.load_state_dict(csd)
+    return m, cn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['cn_xs', 'cn_s'])
+def test_controlnet_hip_matches_reference_golden(lib, name):
+    import torch
+    cfg, sd, csd, inp, cond, g, meta = cn_case(name)
+    m, cn = _models(cfg, sd, csd)
+    t = torch.tensor(meta['t'])
+    x257, _ = m(_t(inp['x']), t, None, forward_model=False)               # src/inference_controlnet.py:89-91
+    skips = cn(x257, t, _t(inp['ctx']), context_mask=_t(inp['ctx_mask']), cls_token=None, condition=_t(cond),
+               conditioning_scale=meta['scale'])
+    assert len(skips) == cfg['depth'] // 2
+    for i, s in enumerate(skips):
+        r = rel_l2(s.cpu().numpy(), g[f'res{i}'])
+        print(f'{name} residual {i}: rel-L2 {r:.3e}')
+        assert r < 2e-2
+    pred = m.model(x257, t, _t(inp['ctx']), context_mask=_t(inp['ctx_mask']), cls_token=None, controlnet_skips=skips)
+    r = rel_l2(pred.cpu().numpy(), g['pred'])
+    print(f'{name} backbone prediction with ControlNet skips: rel-L2 {r:.3e}')
+    assert r < 2e-2 and float(np.abs(pred.cpu().numpy() - g['pred']).max()) < 0.15
+
+
+@pytest.mark.gpu
+def test_controlnet_fused_sampler_equals_stepwise_calls(lib):
+    """The device loop with an attached ControlNet (one hipGraph per step: ControlNet + backbone + CFG/DDIM) against the
+    same step assembled from the public call surfaces, driven by the oracle's restatement of the reference loop."""
+    import torch
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    from oracle.sampler import sample as oracle_sample
+    from tests.util import DIFF
+    cfg, sd, csd, inp, cond, g, meta = cn_case('cn_xs')
+    m, cn = _models(cfg, sd, csd)
+    C, L, steps, scale = cfg['out_chans'], meta['L'], 6, 0.8
+    s3 = np.float32(np.sqrt(3.0))
+    init = (uniform_pm1('c.init', C * L, 1) * s3).reshape(1, C, L)
+    noises = [(uniform_pm1(f'c.z{i}', C * L, 1) * s3).reshape(1, C, L) for i in range(50)]
+    cond1 = cond[0:1]
+
+    def denoise(x, t, ctx, msk, gt, gm):
+        tt = torch.tensor(t)
+        x257, _ = m(_t(x), tt, None, forward_model=False)
+        sk = cn(x257, tt, _t(ctx), context_mask=_t(msk), cls_token=None, condition=_t(np.concatenate([cond1, cond1], 0)),
+                conditioning_scale=scale)
+        return m.model(x257, tt, _t(ctx), context_mask=_t(msk), cls_token=None, controlnet_skips=sk).cpu().numpy()
+    tr = []
+    oracle_sample(denoise, inp['ctx'][0:1], inp['ctx_mask'][0:1], inp['ctx'][1:2], inp['ctx_mask'][1:2], init, noises,
+                  guidance_scale=3.5, guidance_rescale=0.0, ddim_steps=50, eta=1.0, diff_params=DIFF, trace=tr)
+    smp = LatentSampler(m, DDIMScheduler(**DIFF))
+    smp.prepare(_t(inp['ctx'][0:1]), _t(inp['ctx_mask'][0:1]), _t(inp['ctx'][1:2]), _t(inp['ctx_mask'][1:2]), _t(init),
+                torch.stack([_t(z) for z in noises], 0), 3.5, 0.0, 50, 1.0, controlnet=cn, condition=_t(cond1),
+                conditioning_scale=scale)
+    smp.run(steps)
+    lat = smp.finish()
+    torch.cuda.synchronize()
+    assert torch.isfinite(lat).all()
+    assert rel_l2(lat.cpu().numpy(), tr[steps - 1]) < 5e-3
+    # and the ControlNet really matters: detaching it changes the trajectory
+    smp2 = LatentSampler(m, DDIMScheduler(**DIFF))
+    smp2.prepare(_t(inp['ctx'][0:1]), _t(inp['ctx_mask'][0:1]), _t(inp['ctx'][1:2]), _t(inp['ctx_mask'][1:2]), _t(init),
+                 torch.stack([_t(z) for z in noises], 0), 3.5, 0.0, 50, 1.0)
+    smp2.run(steps)
+    lat2 = smp2.finish()
+    torch.cuda.synchronize()
+    assert rel_l2(lat2.cpu().numpy(), tr[steps - 1]) > 1e-2
