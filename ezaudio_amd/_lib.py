@@ -59,6 +59,10 @@ PROTOTYPES = {
     'ezdit_sampler_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(EzditDdimCoef), C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ezdit_sampler_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'ezvae_gemm': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    'ezvae_snake_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    'ezvae_conv_out1': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
     'ezdit_test_gemm': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_test_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libezaudio_hip.so')
-SOURCES = ['gemm.hip', 'attn.hip', 'rowops.hip', 'api.hip']
+SOURCES = ['gemm.hip', 'attn.hip', 'rowops.hip', 'api.hip', 'vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

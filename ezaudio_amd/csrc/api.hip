@@ -328,6 +328,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.epi = epi;
     g.tile = tile;
     g.debug = 0;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0;
     launch_gemm(g, c.st);
     h->launches++;
 }
@@ -933,6 +934,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.epi > EPI_GEGLU || g.tile > 13) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);

@@ -48,7 +48,12 @@ struct GemmArgs {
     int splitk;                 // >= 1 (EPI_PARTIAL only)
     int epi;
     int tile;                   // tile / pipeline configuration, see gemm.hip
-    int debug;                  // 0 normal; 1 = stage only (no LDS reads / MFMA); 2 = compute only (no global loads)
+    int debug;                  // unused (kept for ABI stability of the probe hook)
+    // convolution-as-GEMM addressing (VAE decoder): K tile t reads A at byte offset (t / conv_cpb) * conv_tap_bytes +
+    // (t % conv_cpb) * 128, i.e. tap t/conv_cpb is the SAME activation rows shifted by a fixed number of rows.
+    // conv_cpb = 0: plain GEMM (offset t * 128).
+    int conv_cpb; long conv_tap_bytes;
+    const float* resid; int ldr;  // EPI_F32: out += resid[row][col] (residual connection), nullable
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 

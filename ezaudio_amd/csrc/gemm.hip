@@ -127,11 +127,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     stage_offsets<BM, NT>(aoff, a.lda, row0, a.M - 1, tid);
     stage_offsets<BN, NT>(boff, a.ldw, col0, a.wrows - 1, tid);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);  // provably wave-uniform -> SGPR
-    const char* gA = reinterpret_cast<const char*>(a.A) + (long)kb * BK * 2;
+    const char* gA = reinterpret_cast<const char*>(a.A);
     const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
     auto stage = [&](int t) {  // K tile t (relative) -> ring slot t % NS
         char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
-        stage_tile<BM, NT>(gA + t * (BK * 2), aoff, dst, tid);
+        const long a_off = a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
+                                      : (long)(kb + t) * (BK * 2);
+        stage_tile<BM, NT>(gA + a_off, aoff, dst, tid);
         stage_tile<BN, NT>(gW + t * (BK * 2), boff, dst + A_BYTES, tid);
     };
 #pragma unroll
@@ -255,6 +257,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                             if (a.bias) {
                                 const float4 b = *reinterpret_cast<const float4*>(a.bias + col);
                                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                            }
+                            if (a.resid) {
+                                const float4 r = *reinterpret_cast<const float4*>(a.resid + (long)row * a.ldr + col);
+                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                             }
                         }
                         *reinterpret_cast<float4*>(out + (long)row * a.ldo + col) = v;

@@ -1,0 +1,94 @@
+// Oobleck VAE decoder building blocks (reference:
+// src/modules/stable_vae/models/autoencoders.py:38-61,82-113,149-190, models/blocks.py:317-358, nn/layers.py:9-14).
+//
+// Every Conv1d / ConvTranspose1d of the decoder is run on the SAME bf16 MFMA GEMM as the DiT projections:
+//   * activations are kept token-major [L][C] (C = GEMM K), bf16, with zero "halo" rows before and after the sequence, so a
+//     k-tap (dilated) convolution is one GEMM whose K dimension is taps x C: K tile t reads the activation rows shifted by
+//     tap(t) * dilation rows (GemmArgs.conv_*), weights are pre-arranged [Cout][tap][Cin];
+//   * ConvTranspose1d(kernel 2s, stride s, padding ceil(s/2)) is one GEMM with K = 2 Cin (x[q], x[q-1]) and N = s * Cout: the
+//     output [q][r * Cout + co] IS the up-sampled sequence [(q s + r)][co], read back with a row offset of `padding`;
+//   * SnakeBeta (x + sin^2(alpha x) / beta, log-scale parameters) is fused with the fp32 -> bf16 cast that feeds the next conv;
+//   * residual adds ride in the GEMM epilogue (fp32).
+// The layer sequence itself is host code (ezaudio_amd/vae.py): it runs once per call, not per denoising step.
+#include "../../include/ezdit.h"
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_snake_bf16(const float* __restrict__ x, int ldx, const float* __restrict__ alpha,
+                                                    const float* __restrict__ inv_beta, bf16_t* __restrict__ out, int ldo,
+                                                    long L, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // one thread per 4 channels
+    const int c4n = C >> 2;
+    if (idx >= L * c4n) return;
+    const long l = idx / c4n;
+    const int c = (int)(idx % c4n) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + l * ldx + c);
+    float r[4] = {v.x, v.y, v.z, v.w};
+    if (alpha) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float s = sinf(r[e] * alpha[c + e]);
+            r[e] = r[e] + inv_beta[c + e] * s * s;   // blocks.py:317-318 snake_beta
+        }
+    }
+    uint2 o;
+    o.x = pack_bf2(r[0], r[1]);
+    o.y = pack_bf2(r[2], r[3]);
+    *reinterpret_cast<uint2*>(out + l * ldo + c) = o;
+}
+
+// final WNConv1d(C -> 1, k = 7, padding 3, no bias) on a haloed bf16 sequence (3 zero rows each side): one wave per 64 outputs
+__global__ __launch_bounds__(256) void k_conv_out1(const bf16_t* __restrict__ xb /* row 0 = position -3 */, int ldx,
+                                                   const float* __restrict__ w /* [7][C] */, float* __restrict__ out, long L, int C) {
+    const long l = (long)blockIdx.x * 256 + threadIdx.x;
+    if (l >= L) return;
+    float acc = 0.f;
+    for (int k = 0; k < 7; ++k) {
+        const bf16_t* xr = xb + (l + k) * ldx;
+        const float* wr = w + k * C;
+        for (int c = 0; c < C; c += 8) {
+            const uint4 v = *reinterpret_cast<const uint4*>(xr + c);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc += __uint_as_float(u[e] << 16) * wr[c + 2 * e];
+                acc += __uint_as_float(u[e] & 0xffff0000u) * wr[c + 2 * e + 1];
+            }
+        }
+    }
+    out[l] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// out fp32 [M][ldo] = A . W^T (+ bias) (+ resid); conv_cpb / conv_tap_bytes as in GemmArgs.  N multiple of 4.
+int ezvae_gemm(const void* A, int lda, const void* W, int ldw, int wrows, const float* bias, const float* resid, int ldr,
+               float* out, int ldo, int M, int N, int K, int conv_cpb, long conv_tap_bytes, int tile, ezdit_stream stream) {
+    if (K % 64 || N % 4) return EZDIT_E_INVALID;
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = wrows; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.slab_stride = 0; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_F32; g.tile = tile;
+    g.debug = 0; g.conv_cpb = conv_cpb; g.conv_tap_bytes = conv_tap_bytes; g.resid = resid; g.ldr = ldr;
+    launch_gemm(g, (hipStream_t)stream);
+    return EZDIT_OK;
+}
+
+int ezvae_snake_bf16(const float* x, int ldx, const float* alpha, const float* inv_beta, void* out, int ldo, long L, int C,
+                     ezdit_stream stream) {
+    if (C % 4) return EZDIT_E_INVALID;
+    const long total = L * (C / 4);
+    hipLaunchKernelGGL(k_snake_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, inv_beta,
+                       (bf16_t*)out, ldo, L, C);
+    return EZDIT_OK;
+}
+
+int ezvae_conv_out1(const void* xb, int ldx, const float* w, float* out, long L, int C, ezdit_stream stream) {
+    if (C % 8) return EZDIT_E_INVALID;
+    hipLaunchKernelGGL(k_conv_out1, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xb, ldx, w, out, L, C);
+    return EZDIT_OK;
+}
+
+}  // extern "C"

@@ -161,6 +161,20 @@ int ezdit_sampler_begin(ezdit_handle* h, float* dev_latents, int P, const float*
  * hipGraph on first use and replays it (no host work between kernels). */
 int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream);
 
+/* ---- Oobleck VAE decoder building blocks (src/modules/stable_vae/models/autoencoders.py:38-61,82-113,149-190) --------
+ * Stateless ops on caller-owned device buffers; the layer sequence is host code (ezaudio_amd/vae.py), run once per call.
+ * Activations are token-major [L][C] with zero halo rows so that convolutions are GEMMs over shifted rows. */
+/* out fp32 [M][ldo] = A[M][K] . W[N][K]^T (+ bias[N]) (+ resid[M][ldr]); K tile t (64 wide) of A is read at byte offset
+ * (t / conv_cpb) * conv_tap_bytes + (t % conv_cpb) * 128 (conv_cpb = 0: plain GEMM).  A, W bf16. */
+int ezvae_gemm(const void* dev_a, int lda, const void* dev_w, int ldw, int wrows, const float* dev_bias, const float* dev_resid,
+               int ldr, float* dev_out, int ldo, int M, int N, int K, int conv_cpb, long conv_tap_bytes, int tile,
+               ezdit_stream stream);
+/* SnakeBeta (models/blocks.py:317-358) fused with the fp32 -> bf16 cast: out = x + inv_beta * sin(alpha x)^2; alpha NULL = cast only */
+int ezvae_snake_bf16(const float* dev_x, int ldx, const float* dev_alpha, const float* dev_inv_beta, void* dev_out, int ldo,
+                     long L, int C, ezdit_stream stream);
+/* final WNConv1d(C -> 1, k 7, pad 3, no bias): xb bf16 haloed (row 0 = position -3), w fp32 [7][C] -> out fp32 [L] */
+int ezvae_conv_out1(const void* dev_xb, int ldx, const float* dev_w, float* dev_out, long L, int C, ezdit_stream stream);
+
 /* ---- unit-test hooks: one kernel family each, same code the forward uses ---------------------- */
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw,
                     const float* dev_bias, void* dev_out, int ldo, int M, int N, int K, int splitk,

@@ -210,6 +210,85 @@ def mint_sampler(name, size, L, Lc, steps, seed_w, seed_in, guidance_scale, guid
     print('wrote', path, out.shape, float(out.std()))
 
 
+def _import_reference_vae():
+    """OobleckDecoder / OobleckEncoder from the reference; third-party modules its file imports at the top but the
+    Oobleck path never touches (torchaudio, alias_free_torch, vector_quantize_pytorch; autoencoders.py:7-8, bottleneck.py:6)
+    and the in-tree audiotools (needs flatten_dict; pulled in only by nn/loss.py:6-7) are absent / unimportable here and stubbed."""
+    import torch  # noqa: F401
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name, attrs in (('torchaudio', ()), ('torchaudio.transforms', ()), ('alias_free_torch', ('Activation1d',)),
+                        ('vector_quantize_pytorch', ('ResidualVQ', 'FSQ')), ('audiotools', ('AudioSignal', 'STFTParams'))):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, type(a, (), {}))
+            sys.modules[name] = m
+    sys.modules['torchaudio'].transforms = sys.modules['torchaudio.transforms']
+    import warnings
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from src.modules.stable_vae.models.autoencoders import OobleckDecoder, OobleckEncoder
+    return OobleckDecoder, OobleckEncoder
+
+
+def _load_vae_module(mod, sd, prefix):
+    import torch
+    ref_sd = mod.state_dict()
+    mine = {k[len(prefix):]: v for k, v in sd.items()}
+    assert set(ref_sd.keys()) == set(mine.keys()), sorted(set(ref_sd) ^ set(mine))[:10]
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == mine[k].shape, (k, tuple(v.shape), mine[k].shape)
+    mod.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in mine.items()})
+    return mod.eval()
+
+
+def mint_vae_decoder(name, cfg_name, L, seed_w, seed_in, out_dir='tests/golden'):
+    """Reference OobleckDecoder (autoencoders.py:149-190) in fp32 on CPU on a deterministic latent [2, latent_dim, L]."""
+    import torch
+    import warnings
+    from . import vae as V
+    from .weights import uniform_pm1
+    cfg = dict(getattr(V, cfg_name))
+    OobleckDecoder, _ = _import_reference_vae()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dec = OobleckDecoder(out_channels=cfg['out_channels'], channels=cfg['channels'], latent_dim=cfg['latent_dim'],
+                             c_mults=cfg['c_mults'], strides=cfg['strides'], use_snake=True, final_tanh=False)
+    sd = V.make_vae_state_dict(cfg, seed_w)
+    _load_vae_module(dec, sd, 'decoder.')
+    z = (1.2 * uniform_pm1(f'vae_z_{name}', 2 * cfg['latent_dim'] * L, seed_in)).reshape(2, cfg['latent_dim'], L).astype(np.float32)
+    torch.set_num_threads(os.cpu_count())
+    with torch.no_grad():
+        audio = dec(torch.from_numpy(z.copy())).numpy()
+    np.savez_compressed(os.path.join(out_dir, f'{name}.npz'), cfg_name=cfg_name, L=L, seed_w=seed_w, seed_in=seed_in,
+                        audio=audio.astype(np.float32))
+    print(f'[mint] {name}: audio {audio.shape} std {audio.std():.4f} max {np.abs(audio).max():.4f}', flush=True)
+
+
+def mint_vae_encoder(name, cfg_name, T, seed_w, seed_in, out_dir='tests/golden'):
+    """Reference OobleckEncoder (autoencoders.py:115-147) on a deterministic waveform [2, 1, T] -> [2, 2*latent, T/ratio]."""
+    import torch
+    import warnings
+    from . import vae as V
+    from .weights import uniform_pm1
+    cfg = dict(getattr(V, cfg_name))
+    _, OobleckEncoder = _import_reference_vae()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        enc = OobleckEncoder(in_channels=1, channels=cfg['channels'], latent_dim=2 * cfg['latent_dim'],
+                             c_mults=cfg['c_mults'], strides=cfg['strides'], use_snake=True)
+    sd = V.make_vae_state_dict(cfg, seed_w, encoder=True)
+    _load_vae_module(enc, sd, 'encoder.')
+    wav = (0.5 * uniform_pm1(f'vae_wav_{name}', 2 * T, seed_in)).reshape(2, 1, T).astype(np.float32)
+    torch.set_num_threads(os.cpu_count())
+    with torch.no_grad():
+        lat = enc(torch.from_numpy(wav.copy())).numpy()
+    np.savez_compressed(os.path.join(out_dir, f'{name}.npz'), cfg_name=cfg_name, T=T, seed_w=seed_w, seed_in=seed_in,
+                        latent=lat.astype(np.float32))
+    print(f'[mint] {name}: latent {lat.shape} std {lat.std():.4f}', flush=True)
+
+
 JOBS = {
     # name: (fn, kwargs)
     'xs':        (mint_forward, dict(size='xs', L=96, Lc=20, timesteps=[999, 499, 19], seed_w=1, seed_in=11, n_valid=(7, 1))),
@@ -223,6 +302,10 @@ JOBS = {
     'xl':        (mint_forward, dict(size='xl', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=11)),
     'cn_xs':     (mint_controlnet, dict(size='xs', L=96, Lc=20, t=499, seed_w=1, seed_in=31, scale=1.0)),
     'cn_s':      (mint_controlnet, dict(size='s', L=100, Lc=20, t=979, seed_w=1234, seed_in=32, scale=0.7)),
+    'vae_dec_tiny': (mint_vae_decoder, dict(cfg_name='VAE_TINY', L=40, seed_w=5, seed_in=41)),
+    'vae_dec':      (mint_vae_decoder, dict(cfg_name='VAE_DEFAULT', L=25, seed_w=6, seed_in=42)),
+    'vae_enc_tiny': (mint_vae_encoder, dict(cfg_name='VAE_TINY', T=8 * 48, seed_w=5, seed_in=43)),
+    'vae_enc':      (mint_vae_encoder, dict(cfg_name='VAE_DEFAULT', T=480 * 20, seed_w=6, seed_in=44)),
     'smp_xs':    (mint_sampler, dict(size='xs', L=96, Lc=20, steps=50, seed_w=1, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
     'smp_xs_e0': (mint_sampler, dict(size='xs', L=96, Lc=20, steps=20, seed_w=1, seed_in=22, guidance_scale=3.5, guidance_rescale=0.0, eta=0.0, with_gt=True)),
     'smp_s':     (mint_sampler, dict(size='s', L=500, Lc=100, steps=50, seed_w=1234, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),

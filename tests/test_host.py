@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(ezdit_[a-z_0-9]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(ez(?:dit|vae)_[a-z_0-9]+)\s*\(', src)))
 
 
 def test_library_exports_every_symbol_the_header_declares(lib):
@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares(lib):
     declared = _header_functions()
     assert len(declared) >= 20
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r' T (ezdit_[a-z_0-9]+)', out))
+    exported = set(re.findall(r' T (ez(?:dit|vae)_[a-z_0-9]+)', out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     assert set(declared) == set(_lib.PROTOTYPES), sorted(set(declared) ^ set(_lib.PROTOTYPES))
     assert lib.ezdit_abi_version() == 1

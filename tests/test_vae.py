@@ -1,0 +1,153 @@
+"""Oobleck VAE: oracle vs goldens minted from the reference's OobleckDecoder / OobleckEncoder
+on CPU; the HIP decoder vs the goldens and vs the oracle at the real 10 s size on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vae as V
+from oracle.weights import uniform_pm1
+from tests.util import GOLDEN, rel_l2
+
+
+def dec_case(name):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    cfg = dict(getattr(V, str(g['cfg_name'])))
+    L = int(g['L'])
+    sd = V.make_vae_state_dict(cfg, int(g['seed_w']))
+    z = (1.2 * uniform_pm1(f'vae_z_{name}', 2 * cfg['latent_dim'] * L, int(g['seed_in']))).reshape(2, cfg['latent_dim'], L)
+    return cfg, sd, z.astype(np.float32), g
+
+
+def enc_case(name):
+    g = np.load(os.path.join(GOLDEN, name + '.npz'))
+    cfg = dict(getattr(V, str(g['cfg_name'])))
+    T = int(g['T'])
+    sd = V.make_vae_state_dict(cfg, int(g['seed_w']), encoder=True)
+    wav = (0.5 * uniform_pm1(f'vae_wav_{name}', 2 * T, int(g['seed_in']))).reshape(2, 1, T)
+    return cfg, sd, wav.astype(np.float32), g
+
+
+@pytest.mark.parametrize('name', ['vae_dec_tiny', 'vae_dec'])
+def test_decoder_oracle_matches_reference_golden(name):
+    cfg, sd, z, g = dec_case(name)
+    audio = V.DecoderOracle(cfg, sd)(z)
+    assert audio.shape == g['audio'].shape == (2, 1, z.shape[2] * int(np.prod(cfg['strides'])))
+    assert rel_l2(audio, g['audio']) < 2e-5
+
+
+@pytest.mark.parametrize('name', ['vae_enc_tiny', 'vae_enc'])
+def test_encoder_oracle_matches_reference_golden(name):
+    cfg, sd, wav, g = enc_case(name)
+    lat = V.EncoderOracle(cfg, sd)(wav)
+    assert lat.shape == g['latent'].shape == (2, 2 * cfg['latent_dim'], wav.shape[2] // int(np.prod(cfg['strides'])))
+    assert rel_l2(lat, g['latent']) < 2e-5
+
+
+def test_oracle_ops_against_torch_functional():
+    import torch
+    import torch.nn.functional as F
+    x = uniform_pm1('x', 2 * 6 * 50, 0).reshape(2, 6, 50)
+    w = uniform_pm1('w', 5 * 6 * 7, 1).reshape(5, 6, 7)
+    b = uniform_pm1('b', 5, 2)
+    for stride, pad, dil in ((1, 3, 1), (1, 9, 3), (2, 1, 1), (1, 27, 9)):
+        ref = F.conv1d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=stride, padding=pad, dilation=dil)
+        np.testing.assert_allclose(V.conv1d(x, w, b, stride, pad, dil), ref.numpy(), rtol=1e-5, atol=1e-6)
+    for s in (2, 4, 6, 10, 3):
+        wt = uniform_pm1(f'wt{s}', 6 * 5 * 2 * s, 3).reshape(6, 5, 2 * s)
+        p = -(-s // 2)
+        ref = F.conv_transpose1d(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), stride=s, padding=p)
+        np.testing.assert_allclose(V.conv_transpose1d(x, wt, b, s, p), ref.numpy(), rtol=1e-5, atol=1e-6)
+    g = 1.0 + 0.3 * uniform_pm1('g', 5, 4).reshape(5, 1, 1)
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(6, 5, 7))
+    conv.weight_g.data = torch.from_numpy(g)
+    conv.weight_v.data = torch.from_numpy(w)
+    conv(torch.zeros(1, 6, 8))
+    np.testing.assert_allclose(V.weight_norm(g, w), conv.weight.detach().numpy(), rtol=1e-5, atol=1e-7)
+    from ezaudio_amd.vae import _fold_weight_norm
+    np.testing.assert_allclose(_fold_weight_norm(torch.from_numpy(g), torch.from_numpy(w)).numpy(), V.weight_norm(g, w), rtol=1e-6)
+    al, be = 0.3 * uniform_pm1('al', 6, 5), 0.3 * uniform_pm1('be', 6, 6)
+    t = torch.from_numpy(x)
+    ref = t + (1.0 / (torch.exp(torch.from_numpy(be))[None, :, None] + 1e-9)) * torch.sin(t * torch.exp(torch.from_numpy(al))[None, :, None]) ** 2
+    np.testing.assert_allclose(V.snake_beta(x, al, be), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_decoder_rejects_unbuilt_recipes():
+    from ezaudio_amd.vae import OobleckDecoder
+    for kw in (dict(use_snake=False), dict(final_tanh=True), dict(out_channels=2), dict(use_nearest_upsample=True),
+               dict(channels=96), dict(strides=(2, 3, 4, 5))):
+        with pytest.raises(NotImplementedError):
+            OobleckDecoder(**kw)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP decoder through the C ABI
+# ----------------------------------------------------------------------------------------------------------------------
+def _hip_decoder(cfg, sd):
+    from ezaudio_amd.vae import OobleckDecoder
+    dec = OobleckDecoder(out_channels=1, channels=cfg['channels'], latent_dim=cfg['latent_dim'], c_mults=cfg['c_mults'],
+                         strides=cfg['strides'], use_snake=True, final_tanh=False, device='cuda')
+    return dec.load_state_dict(sd)
+
+
+# Tolerance: GEMM operands (activations after SnakeBeta, folded weights) are bf16 with fp32 accumulation, residual stream /
+# snake / final conv fp32: rel-L2 2e-2 and max-abs 6 % of the output's max through the 35 convolutions of the decoder.
+VAE_REL, VAE_MAX = 2e-2, 0.06
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['vae_dec_tiny', 'vae_dec'])
+def test_hip_decoder_matches_reference_golden(name):
+    import torch
+    cfg, sd, z, g = dec_case(name)
+    dec = _hip_decoder(cfg, sd)
+    audio = dec(torch.from_numpy(z).cuda()).cpu().numpy()
+    assert audio.shape == g['audio'].shape
+    assert np.isfinite(audio).all()
+    r = rel_l2(audio, g['audio'])
+    m = np.abs(audio - g['audio']).max() / np.abs(g['audio']).max()
+    print(f'{name}: rel_l2 {r:.3e} max/max {m:.3e}')
+    assert r < VAE_REL and m < VAE_MAX
+    # a second call reuses the cached halo buffers: must be bitwise identical, and batch rows independent
+    again = dec(torch.from_numpy(z[1:]).cuda()).cpu().numpy()
+    assert np.array_equal(again[0], audio[1])
+
+
+@pytest.mark.gpu
+def test_hip_decoder_full_length_vs_oracle():
+    """10 s of audio (250 latent frames -> 120000 samples), the size generate_audio() decodes."""
+    import torch
+    cfg = dict(V.VAE_DEFAULT)
+    sd = V.make_vae_state_dict(cfg, 6)
+    L = 250
+    z = (1.2 * uniform_pm1('vae_z_full', cfg['latent_dim'] * L, 7)).reshape(1, cfg['latent_dim'], L).astype(np.float32)
+    ref = V.DecoderOracle(cfg, sd)(z)
+    dec = _hip_decoder(cfg, sd)
+    audio = dec(torch.from_numpy(z).cuda()).cpu().numpy()
+    assert audio.shape == (1, 1, 120000)
+    r = rel_l2(audio, ref)
+    m = np.abs(audio - ref).max() / np.abs(ref).max()
+    print(f'full: rel_l2 {r:.3e} max/max {m:.3e}')
+    assert r < VAE_REL and m < VAE_MAX
+    # shorter latent afterwards (editing / variable length): halo geometry changes, buffers are per-shape
+    z2 = z[:, :, :77]
+    a2 = dec(torch.from_numpy(z2).cuda()).cpu().numpy()
+    assert rel_l2(a2, V.DecoderOracle(cfg, sd)(z2)) < VAE_REL
+
+
+@pytest.mark.gpu
+def test_autoencoder_wrapper_surface():
+    import torch
+    from ezaudio_amd.vae import Autoencoder
+    cfg = dict(V.VAE_TINY)
+    sd = {k: torch.from_numpy(v) for k, v in V.make_vae_state_dict(cfg, 5).items()}
+    config = {'model': {'decoder': {'type': 'oobleck', 'config': dict(out_channels=1, channels=cfg['channels'], c_mults=cfg['c_mults'],
+                                                                     strides=cfg['strides'], latent_dim=cfg['latent_dim'],
+                                                                     use_snake=True, final_tanh=False)}}}
+    ae = Autoencoder(model_type='stable_vae', quantization_first=True, config=config, state_dict=sd)
+    z = torch.zeros(1, cfg['latent_dim'], 16, device='cuda')
+    assert ae(embedding=z).shape == (1, 1, 16 * 8)
+    with pytest.raises(ValueError):
+        ae()
+    with pytest.raises(NotImplementedError):
+        Autoencoder(model_type='dac', config=config, state_dict=sd)
