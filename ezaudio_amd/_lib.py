@@ -63,6 +63,8 @@ PROTOTYPES = {
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     'ezvae_snake_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     'ezvae_conv_out1': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
+    'ezvae_conv_in1': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
+    'ezvae_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_test_gemm': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_test_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

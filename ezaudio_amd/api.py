@@ -56,10 +56,10 @@ class EzAudio:
                     text_encoder=None, state_dict=None):
         """api/ezaudio.py:68-99."""
         params = load_yaml_with_includes(config_name)
-        if autoencoder is None:
-            raise NotImplementedError(
-                'the Oobleck VAE decoder is not built yet (SURVEY.md section 8f row 1): pass autoencoder=<callable '
-                'with the reference Autoencoder surface (embedding=z -> wav, audio=wav -> z)>')
+        if autoencoder is None:   # api/ezaudio.py:75-79; an injected callable with the same surface is also accepted
+            from .vae import Autoencoder
+            autoencoder = Autoencoder(ckpt_path=vae_path, model_type=params['autoencoder']['name'],
+                                      quantization_first=params['autoencoder']['q_first'], device=device)
         if tokenizer is None or text_encoder is None:
             from transformers import T5EncoderModel, T5Tokenizer
             tokenizer = T5Tokenizer.from_pretrained(params['text_encoder']['model'])

@@ -60,6 +60,37 @@ __global__ __launch_bounds__(256) void k_conv_out1(const bf16_t* __restrict__ xb
     out[l] = acc;
 }
 
+// encoder input WNConv1d(1 -> C, k = 7, padding 3): wav fp32 [T] -> x fp32 [T][C]; w fp32 [7][C]
+__global__ __launch_bounds__(256) void k_conv_in1(const float* __restrict__ wav, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ out, long T, int C) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C >> 2;
+    if (idx >= T * c4n) return;
+    const long t = idx / c4n;
+    const int c = (int)(idx % c4n) * 4;
+    float4 acc = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const long j = t + k - 3;
+        const float x = (j >= 0 && j < T) ? wav[j] : 0.f;
+        const float4 wk = *reinterpret_cast<const float4*>(w + k * C + c);
+        acc.x = fmaf(x, wk.x, acc.x); acc.y = fmaf(x, wk.y, acc.y); acc.z = fmaf(x, wk.z, acc.z); acc.w = fmaf(x, wk.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(out + t * C + c) = acc;
+}
+
+// VAE bottleneck (models/bottleneck.py:67-71): enc fp32 [L][2 lat] token-major (mean | scale) + noise [lat][L] -> z [lat][L]
+__global__ __launch_bounds__(256) void k_vae_sample(const float* __restrict__ enc, const float* __restrict__ noise,
+                                                    float* __restrict__ z, int L, int lat) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= L * lat) return;
+    const int c = idx / L, l = idx % L;
+    const float mean = enc[(long)l * 2 * lat + c];
+    const float sc = enc[(long)l * 2 * lat + lat + c];
+    const float softplus = sc > 20.f ? sc : log1pf(expf(sc));   // torch softplus, threshold 20
+    z[idx] = (noise ? noise[idx] : 0.f) * (softplus + 1e-4f) + mean;
+}
+
 }  // namespace
 
 extern "C" {
@@ -88,6 +119,19 @@ int ezvae_snake_bf16(const float* x, int ldx, const float* alpha, const float* i
 int ezvae_conv_out1(const void* xb, int ldx, const float* w, float* out, long L, int C, ezdit_stream stream) {
     if (C % 8) return EZDIT_E_INVALID;
     hipLaunchKernelGGL(k_conv_out1, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xb, ldx, w, out, L, C);
+    return EZDIT_OK;
+}
+
+int ezvae_conv_in1(const float* wav, const float* w, const float* bias, float* out, long T, int C, ezdit_stream stream) {
+    if (C % 4) return EZDIT_E_INVALID;
+    const long total = T * (C / 4);
+    hipLaunchKernelGGL(k_conv_in1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav, w, bias, out, T, C);
+    return EZDIT_OK;
+}
+
+int ezvae_sample(const float* enc, const float* noise, float* z, int L, int latent_dim, ezdit_stream stream) {
+    const int total = L * latent_dim;
+    hipLaunchKernelGGL(k_vae_sample, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, enc, noise, z, L, latent_dim);
     return EZDIT_OK;
 }
 

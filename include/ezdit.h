@@ -175,6 +175,12 @@ int ezvae_snake_bf16(const float* dev_x, int ldx, const float* dev_alpha, const 
 /* final WNConv1d(C -> 1, k 7, pad 3, no bias): xb bf16 haloed (row 0 = position -3), w fp32 [7][C] -> out fp32 [L] */
 int ezvae_conv_out1(const void* dev_xb, int ldx, const float* dev_w, float* dev_out, long L, int C, ezdit_stream stream);
 
+/* encoder input WNConv1d(1 -> C, k 7, pad 3) (autoencoders.py:130-132): wav fp32 [T], w fp32 [7][C], bias [C] -> out fp32 [T][C] */
+int ezvae_conv_in1(const float* dev_wav, const float* dev_w, const float* dev_bias, float* dev_out, long T, int C, ezdit_stream stream);
+/* VAEBottleneck.encode (models/bottleneck.py:67-71,77-87): enc fp32 [L][2*latent] token-major (mean | scale), noise fp32
+ * [latent][L] (caller's randn; NULL = return the mean) -> z fp32 [latent][L] = noise * (softplus(scale) + 1e-4) + mean */
+int ezvae_sample(const float* dev_enc, const float* dev_noise, float* dev_z, int L, int latent_dim, ezdit_stream stream);
+
 /* ---- unit-test hooks: one kernel family each, same code the forward uses ---------------------- */
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw,
                     const float* dev_bias, void* dev_out, int ldo, int M, int N, int K, int splitk,

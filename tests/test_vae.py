@@ -135,19 +135,145 @@ def test_hip_decoder_full_length_vs_oracle():
     assert rel_l2(a2, V.DecoderOracle(cfg, sd)(z2)) < VAE_REL
 
 
+def _hip_encoder(cfg, sd):
+    from ezaudio_amd.vae import OobleckEncoder
+    enc = OobleckEncoder(in_channels=1, channels=cfg['channels'], latent_dim=2 * cfg['latent_dim'], c_mults=cfg['c_mults'],
+                         strides=cfg['strides'], use_snake=True, device='cuda')
+    return enc.load_state_dict(sd)
+
+
 @pytest.mark.gpu
-def test_autoencoder_wrapper_surface():
+@pytest.mark.parametrize('name', ['vae_enc_tiny', 'vae_enc'])
+def test_hip_encoder_matches_reference_golden(name):
+    import torch
+    cfg, sd, wav, g = enc_case(name)
+    enc = _hip_encoder(cfg, sd)
+    lat = enc(torch.from_numpy(wav).cuda()).cpu().numpy()
+    assert lat.shape == g['latent'].shape
+    r = rel_l2(lat, g['latent'])
+    m = np.abs(lat - g['latent']).max() / np.abs(g['latent']).max()
+    print(f'{name}: rel_l2 {r:.3e} max/max {m:.3e}')
+    assert r < VAE_REL and m < VAE_MAX
+
+
+@pytest.mark.gpu
+def test_hip_encoder_ragged_length_and_bottleneck():
+    """A waveform whose length is not a multiple of any stride (editing_audio crops arbitrarily): every strided conv floors."""
+    import torch
+    from ezaudio_amd.vae import VAEBottleneck
+    cfg = dict(V.VAE_DEFAULT)
+    sd = V.make_vae_state_dict(cfg, 6, encoder=True)
+    T = 480 * 9 + 317
+    wav = (0.5 * uniform_pm1('vae_wav_ragged', T, 3)).reshape(1, 1, T).astype(np.float32)
+    ref = V.EncoderOracle(cfg, sd)(wav)
+    lat = _hip_encoder(cfg, sd)(torch.from_numpy(wav).cuda())
+    assert tuple(lat.shape) == ref.shape
+    assert rel_l2(lat.cpu().numpy(), ref) < VAE_REL
+    noise = uniform_pm1('vae_noise', ref.shape[1] // 2 * ref.shape[2], 4).reshape(1, ref.shape[1] // 2, ref.shape[2])
+    z = VAEBottleneck('cuda').encode(torch.from_numpy(ref).cuda(), noise=torch.from_numpy(noise).cuda()).cpu().numpy()
+    np.testing.assert_allclose(z, V.vae_sample(ref[:, :128], ref[:, 128:], noise), rtol=1e-5, atol=1e-5)
+    z0 = VAEBottleneck('cuda').encode(torch.from_numpy(ref).cuda())
+    assert z0.shape == (1, 128, ref.shape[2]) and torch.isfinite(z0).all()
+
+
+MINI_VAE = dict(channels=64, c_mults=[1, 2], strides=[2, 4], latent_dim=128, out_channels=1)   # DiT-compatible latent width
+
+
+def _mini_autoencoder(device='cuda'):
     import torch
     from ezaudio_amd.vae import Autoencoder
-    cfg = dict(V.VAE_TINY)
+    cfg = MINI_VAE
     sd = {k: torch.from_numpy(v) for k, v in V.make_vae_state_dict(cfg, 5).items()}
-    config = {'model': {'decoder': {'type': 'oobleck', 'config': dict(out_channels=1, channels=cfg['channels'], c_mults=cfg['c_mults'],
-                                                                     strides=cfg['strides'], latent_dim=cfg['latent_dim'],
-                                                                     use_snake=True, final_tanh=False)}}}
-    ae = Autoencoder(model_type='stable_vae', quantization_first=True, config=config, state_dict=sd)
-    z = torch.zeros(1, cfg['latent_dim'], 16, device='cuda')
-    assert ae(embedding=z).shape == (1, 1, 16 * 8)
+    sd.update({k: torch.from_numpy(v) for k, v in V.make_vae_state_dict(cfg, 5, encoder=True).items()})
+    common = dict(channels=cfg['channels'], c_mults=cfg['c_mults'], strides=cfg['strides'], use_snake=True)
+    config = {'model': {'encoder': {'type': 'oobleck', 'config': dict(in_channels=1, latent_dim=2 * cfg['latent_dim'], **common)},
+                        'decoder': {'type': 'oobleck', 'config': dict(out_channels=1, latent_dim=cfg['latent_dim'], final_tanh=False, **common)},
+                        'bottleneck': {'type': 'vae'}}}
+    return Autoencoder(model_type='stable_vae', quantization_first=True, config=config, state_dict=sd, device=device), config, sd
+
+
+@pytest.mark.gpu
+def test_autoencoder_wrapper_surface(tmp_path):
+    """src/modules/autoencoder_wrapper.py:68-83: embedding -> audio, audio -> sampled latent; ckpt + config.json loading."""
+    import json
+    import torch
+    from ezaudio_amd.vae import Autoencoder
+    ae, config, sd = _mini_autoencoder()
+    z = torch.from_numpy(uniform_pm1('z', 128 * 16, 1).reshape(1, 128, 16)).cuda()
+    wav = ae(embedding=z)
+    assert wav.shape == (1, 1, 16 * 8)
+    lat = ae(audio=wav)
+    assert lat.shape == (1, 128, 16)
     with pytest.raises(ValueError):
         ae()
     with pytest.raises(NotImplementedError):
         Autoencoder(model_type='dac', config=config, state_dict=sd)
+    # the reference's on-disk format: <dir>/config.json + torch checkpoint {'state_dict': {'autoencoder.<key>': tensor}}
+    with open(tmp_path / 'config.json', 'w') as f:
+        json.dump(config, f)
+    torch.save({'state_dict': {'autoencoder.' + k: v for k, v in sd.items()}}, tmp_path / 'vae.pt')
+    ae2 = Autoencoder(ckpt_path=str(tmp_path / 'vae.pt'), model_type='stable_vae', quantization_first=True)
+    assert torch.equal(ae2(embedding=z), wav)
+
+
+class _Tok:
+    """Stand-in for T5Tokenizer (no checkpoints offline): deterministic ids, per-prompt valid length."""
+
+    def __call__(self, texts, max_length, padding, truncation, return_tensors):
+        import torch
+        ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+        mask = torch.zeros(len(texts), max_length, dtype=torch.long)
+        for i, t in enumerate(texts):
+            n = max(1, min(max_length, len(t.split()) + 1))
+            ids[i, :n] = torch.tensor([(j % 97) + 1 for j in range(len(t), len(t) + n)])
+            mask[i, :n] = 1
+        return type('Batch', (), dict(input_ids=ids, attention_mask=mask))()
+
+
+class _Enc:
+    def __init__(self, dim):
+        self.dim = dim
+
+    def __call__(self, input_ids, attention_mask):
+        import torch
+        g = torch.Generator().manual_seed(7)
+        table = torch.randn(128, self.dim, generator=g).to(input_ids.device)
+        return type('Out', (), dict(last_hidden_state=table[input_ids % 128]))()
+
+
+@pytest.mark.gpu
+def test_public_api_text_to_audio_and_editing_end_to_end(tmp_path, monkeypatch):
+    """api/ezaudio.py:101-207 through the native sampler AND the native VAE: prompt -> waveform, waveform -> edited waveform."""
+    import sys
+    import types
+    import yaml
+    import torch
+    import ezaudio_amd
+    from ezaudio_amd import api as A
+    from ezaudio_amd.config import load_yaml_with_includes
+    from oracle.weights import make_state_dict, model_config
+    base = os.path.join(os.path.dirname(ezaudio_amd.__file__), 'configs', 'ezaudio-xl.yml')
+    params = load_yaml_with_includes(base)
+    cfg = model_config('xs')
+    params['model'] = dict(cfg)
+    params['text_encoder']['dim'] = cfg['context_dim']
+    yml = tmp_path / 'mini.yml'
+    with open(yml, 'w') as f:
+        yaml.safe_dump(params, f)
+    monkeypatch.setitem(A.configs, 'mini', {'path': str(tmp_path / 'none.pt'), 'url': '', 'config': str(yml)})
+    ae, _, _ = _mini_autoencoder()
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(cfg, 1).items()}
+    ez = A.EzAudio('mini', autoencoder=ae, tokenizer=_Tok(), text_encoder=_Enc(cfg['context_dim']), state_dict=sd)
+    sr, audio = ez.generate_audio('a dog barking', length=2, ddim_steps=20, random_seed=3)
+    assert sr == 24000 and audio.shape == (100 * 8,) and np.isfinite(audio).all() and audio.std() > 0
+    sr, again = ez.generate_audio('a dog barking', length=2, ddim_steps=20, random_seed=3)
+    assert np.array_equal(audio, again)
+    # editing: librosa is absent offline; the API only uses librosa.load(file, sr=) -> (waveform, sr)
+    src = (0.3 * uniform_pm1('edit_src', 24000, 9)).astype(np.float32)
+    monkeypatch.setitem(sys.modules, 'librosa', types.SimpleNamespace(load=lambda f, sr: (src.copy(), sr)))
+    sr, edited = ez.editing_audio('rain', boundary=0.1, gt_file='unused.wav', mask_start=0.3, mask_length=0.2, ddim_steps=20,
+                                  random_seed=3)
+    assert edited.shape == src.shape and np.isfinite(edited).all()
+    keep = np.ones(len(src), bool)
+    keep[round(0.2 * 24000):round(0.6 * 24000)] = False
+    assert np.array_equal(edited[keep], (src / (np.abs(src).max() + 1e-9))[keep])      # outside the re-synthesised chunk: untouched
