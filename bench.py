@@ -236,9 +236,10 @@ def main():
             'ms_per_step': dt * 1e3 / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'EzAudio-%s (ezaudio-%s.yml) %d-step DDIM sampler, 10 s latent (L=%d, Lc=%d), CFG on '
-                                   '(guidance 5, rescale 0.75, eta 1), %d prompt(s)/GPU = %d denoiser rows/GPU, random-init '
+                                   '(guidance %g, rescale %g, eta 1)%s, %d prompt(s)/GPU = %d denoiser rows/GPU, random-init '
                                    'weights, bf16 MFMA / fp32 accumulate + fp32 residual stream'
-                                   % (a.size.upper(), a.size, n_ddim, L, Lc, P, B),
+                                   % (a.size.upper(), a.size, n_ddim, L, Lc, gs, gr,
+                                      ' + energy ControlNet (conditioning_scale 1)' if a.controlnet else '', P, B),
                        'prompts_per_gpu': P, 'rows_per_gpu': B, 'latent_frames': L, 'hipgraph': use_graph,
                        'kernel_launches_per_step': unet.last_launch_count},
             'loop_steps_per_s_per_gpu': steps_per_s,
@@ -246,6 +247,12 @@ def main():
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                          'flops_per_step': fl, 'event_ms_per_step': ev_ms / a.steps, 'traffic': None},
         }
+        if a.size == 'xl' and P == 1 and not a.controlnet and L == 500:
+            # HBM-side bytes per denoising step from two separate rocprofv3 --pmc passes of this same command
+            # (profiles/r01_c_pmc_{fetch,write}_size.txt): FETCH_SIZE 5.577 GB raw, doubled per the gfx950 correction of
+            # MI355X_MICROARCH.md (16-byte/lane streaming reads are tallied at half), + WRITE_SIZE 3.22 GB (uncalibrated).
+            res['roofline']['traffic'] = 2 * 5.5773e9 + 3.22e9
+            res['roofline']['traffic_unit'] = 'bytes per step (offline PMC passes, see profiles/r01_c_*)'
         try:
             res['roofline']['dominant_kernel'] = dominant_kernel_probe(unet, cfg, B * L, smp.stream)
         except Exception as e:  # the probe must never cost the headline number

@@ -84,7 +84,7 @@ class LatentSampler:
         return self.latents
 
 
-def draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n_prompts=1):
+def draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n_prompts=1, first_index=0):
     """Init noise + per-step DDIM noise in the order the reference draws them from ONE generator
     (src/inference.py:58-67 then one randn per scheduler.step, diffusers `randn_tensor`).  For several
     prompts each sample gets its own generator seeded seed + index, so results do not depend on how
@@ -93,7 +93,7 @@ def draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n
     for i in range(n_prompts):
         g = torch.Generator(device=device)
         if random_seed is not None:
-            g.manual_seed(random_seed + i)
+            g.manual_seed(random_seed + first_index + i)
         else:
             g.seed()
         inits.append(torch.randn((1, codec_dim, audio_frames), generator=g, device=device))
@@ -119,12 +119,32 @@ def inference_controlnet(autoencoder, unet, controlnet, gt, gt_mask, condition, 
 @torch.no_grad()
 def inference(autoencoder, unet, gt, gt_mask, tokenizer, text_encoder, params, noise_scheduler, text_raw,
               neg_text=None, audio_frames=500, guidance_scale=3, guidance_rescale=0.0, ddim_steps=50, eta=1,
-              random_seed=2024, device='cuda', use_graph=True, controlnet=None, condition=None, conditioning_scale=1.0):
-    """Same signature and semantics as the reference's ``inference`` (src/inference.py:26-107)."""
+              random_seed=2024, device='cuda', use_graph=True, controlnet=None, condition=None, conditioning_scale=1.0,
+              first_index=None):
+    """Same signature and semantics as the reference's ``inference`` (src/inference.py:26-107).
+
+    Extension: with ``torch.distributed`` initialised and several prompts, every rank samples AND
+    VAE-decodes its own contiguous shard of the prompts and the waveforms are all-gathered once (RCCL)."""
     if neg_text is None:
         neg_text = [""]
     if isinstance(text_raw, str):
         text_raw = [text_raw]
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and len(text_raw) > 1 and first_index is None:
+        from .dist import sample_sharded
+        n_all = len(text_raw)
+        neg_all = list(neg_text) * n_all if len(neg_text) == 1 else list(neg_text)
+
+        def local(s, e):
+            if e == s:   # more ranks than prompts: contribute an empty shard of the common shape
+                ratio = params['autoencoder']['sr'] // params['autoencoder']['latent_sr']
+                return torch.zeros(0, 1, audio_frames * ratio, device=device)
+            sl = lambda t: t if t is None or t.shape[0] == 1 else t[s:e]   # noqa: E731  per-prompt tensors are sliced
+            return inference(autoencoder, unet, sl(gt), sl(gt_mask), tokenizer, text_encoder, params, noise_scheduler,
+                             list(text_raw[s:e]), neg_all[s:e], audio_frames, guidance_scale, guidance_rescale, ddim_steps, eta,
+                             random_seed, device, use_graph, controlnet, sl(condition), conditioning_scale, first_index=s)
+        return sample_sharded(local, n_all)
+    first_index = first_index or 0
     n_prompts = len(text_raw)
     if tokenizer is not None:
         max_len = params['text_encoder']['max_length']
@@ -139,7 +159,7 @@ def inference(autoencoder, unet, gt, gt_mask, tokenizer, text_encoder, params, n
         raise NotImplementedError('tokenizer=None (unconditional model) is not a shipped configuration')
     codec_dim = params['model']['out_chans']
     unet.eval()
-    init, step_noises = draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n_prompts)
+    init, step_noises = draw_noises(codec_dim, audio_frames, ddim_steps, eta, random_seed, device, n_prompts, first_index)
     smp = LatentSampler(unet, noise_scheduler)
     smp.prepare(text.float(), text_mask, uncond_text.float(), uncond_mask, init, step_noises, guidance_scale,
                 guidance_rescale, ddim_steps, eta, gt=gt, gt_mask=gt_mask, controlnet=controlnet, condition=condition,
