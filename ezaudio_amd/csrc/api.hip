@@ -82,7 +82,10 @@ struct ezdit_handle {
     hipStream_t pf_stream = nullptr;   // side stream of the weight prefetcher
     std::vector<hipEvent_t> pf_events;  // fork/join events (one pair per use so capture sees distinct nodes)
     int prefetch = 0;      // measured -12 % on MI355X (profiles/): the side stream disturbs the GEMMs more than warm weights help
-    int opt_split18 = 2, opt_split36 = 2, opt_split72 = 4, opt_tile_partial = 5, opt_tile_f32 = 6;  // tuning knobs
+    // tuning knobs (M <= 2048 rows); defaults from tests/bench_cold.py + tests/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
+    // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
+    int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
+    int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
 
     template <typename T>
@@ -328,7 +331,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.epi = epi;
     g.tile = tile;
     g.debug = 0;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h->opt_xcd_map;
     launch_gemm(g, c.st);
     h->launches++;
 }
@@ -355,7 +358,13 @@ int gemm_partial(Ctx& c, const bf16_t* A, int lda, const std::string& wname, int
     ezdit_handle* h = c.h;
     const int K = h->pld(wname);
     const int s = pick_splitk(h, M, N, K);
-    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, tile_for(h, M, true), s, (long)h->Mp * h->D);
+    int tile = tile_for(h, M, true);
+    if (M <= 2048) {
+        const int nk = K / 64;
+        const int o = nk >= 72 ? h->opt_tile_p72 : nk >= 36 ? h->opt_tile_p36 : h->opt_tile_p18;
+        if (o >= 0) tile = o;
+    }
+    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, tile, s, (long)h->Mp * h->D);
     return s;
 }
 
@@ -657,7 +666,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         }
         // ---- self attention (blocks.py:136-141) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32, tile_for(h, M, false));
+        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32,
+             (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = 3 * D;
@@ -711,7 +721,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU,
-             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 12 : 2));
+             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 13 : 2));
         STOPCHK();
         s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
@@ -928,16 +938,15 @@ int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream
 // ------------------------------------------------------------------------------------------------------
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                     int ldo, int M, int N, int K, int splitk, ezdit_stream stream) {
-    (void)h;
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
-    if (g.epi > EPI_GEGLU || g.tile > 13) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
+    if (g.epi > EPI_GEGLU || g.tile > 28) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     launch_gemm(g, (hipStream_t)stream);
     return EZDIT_OK;
@@ -978,6 +987,11 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "split72")) h->opt_split72 = value;
     else if (!strcmp(name, "tile_partial")) h->opt_tile_partial = value;
     else if (!strcmp(name, "tile_f32")) h->opt_tile_f32 = value;
+    else if (!strcmp(name, "xcd_map")) h->opt_xcd_map = value;
+    else if (!strcmp(name, "tile_p18")) h->opt_tile_p18 = value;
+    else if (!strcmp(name, "tile_p36")) h->opt_tile_p36 = value;
+    else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;
+    else if (!strcmp(name, "tile_qkv")) h->opt_tile_qkv = value;
     else return fail(EZDIT_E_INVALID, "unknown option %s", name);
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }

@@ -54,6 +54,10 @@ struct GemmArgs {
     // conv_cpb = 0: plain GEMM (offset t * 128).
     int conv_cpb; long conv_tap_bytes;
     const float* resid; int ldr;  // EPI_F32: out += resid[row][col] (residual connection), nullable
+    // workgroup -> XCD placement: the (M tiles x N tiles x K splits) grid is cut into pm x pn x pz = 8 boxes, one per XCD
+    // (hardware deals workgroups to XCDs round-robin), so each XCD's private 4 MB L2 sees only its box's slice of A and W.
+    // Filled by launch_gemm (xcd_map: 0 = legacy 1 x 8 x 1, 1 = smallest per-XCD footprint).
+    int xcd_map; int pm, pn, pz, bm, bn, bz;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 

@@ -71,15 +71,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else static_assert(N == 0, "unsupported vmcnt");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `younger` (0 .. MAXY) whole tiles of PER loads each are still in flight
+template <int PER, int MAXY>
+__device__ __forceinline__ void wait_tiles(int younger) {
+    if constexpr (MAXY >= 5) { if (younger >= 5) { wait_vmcnt<5 * PER>(); return; } }
+    if constexpr (MAXY >= 4) { if (younger >= 4) { wait_vmcnt<4 * PER>(); return; } }
+    if constexpr (MAXY >= 3) { if (younger >= 3) { wait_vmcnt<3 * PER>(); return; } }
+    if constexpr (MAXY >= 2) { if (younger >= 2) { wait_vmcnt<2 * PER>(); return; } }
+    if constexpr (MAXY >= 1) { if (younger >= 1) { wait_vmcnt<PER>(); return; } }
+    wait_vmcnt<0>();
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI>
@@ -98,18 +102,20 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile map
+    // XCD-aware tile map: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the tile grid, M tiles fastest inside
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     const int xcd = blockIdx.x & 7;
-    const int idx = blockIdx.x >> 3;
-    const int tn = (idx / tilesM) * 8 + xcd;
-    const int tm = idx % tilesM;
-    if (tn >= tilesN) return;
+    const int l = blockIdx.x >> 3;
+    const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
+    const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
+    const int tm = xm * a.bm + lm;
+    const int tn = xn * a.bn + ln;
+    const int z = xz * a.bz + lz;
+    if (tm >= tilesM || tn >= tilesN || z >= a.splitk) return;
     const int row0 = tm * BM, col0 = tn * BN;
 
     const int nk = a.K / BK;
-    const int z = blockIdx.z;
     const int kb = nk * z / a.splitk;
     const int ke = nk * (z + 1) / a.splitk;
     const int nt = ke - kb;
@@ -157,15 +163,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             constexpr int REM_WAVES = (((BM * 8) % NT) + ((BN * 8) % NT)) / 64;
             static_assert(((BM * 8) % NT == 0) || ((BN * 8) % NT == 0), "at most one ragged operand");
             constexpr int LO = (BM * 8) / NT + (BN * 8) / NT;
+            static_assert(NS <= 3, "ragged staging supports rings up to 3");
             if (NS >= 3 && younger >= 1) {
                 if (wave_u < REM_WAVES) wait_vmcnt<LO + 1>(); else wait_vmcnt<LO>();
             } else {
                 wait_vmcnt<0>();
             }
         } else {
-            if (NS >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
-            else if (NS >= 3 && younger >= 1) wait_vmcnt<LPT>();
-            else wait_vmcnt<0>();
+            constexpr int MAXY = NS - 2 < 5 ? NS - 2 : 5;   // tiles t+1 .. t+NS-2 are in flight here (t+NS-1 is issued below)
+            static_assert(MAXY * LPT < 64, "ring too deep for the 6-bit vmcnt");  // deeper rings wait conservatively (at most 5 tiles in flight)
+            wait_tiles<LPT, MAXY>(younger);
         }
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
         if (t + NS - 1 < nt) stage(t + NS - 1);  // overwrites the slot of tile t-1
@@ -271,10 +278,27 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI>
-void launch_t(const GemmArgs& a, hipStream_t st) {
+void launch_t(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
-    dim3 grid(8 * tilesM * ((tilesN + 7) / 8), 1, a.splitk);
+    const int S = a.splitk;
+    // choose the 8-box partition with the smallest per-XCD operand footprint (bytes of A + W one XCD touches)
+    double best = 1e30;
+    for (int pm = 1; pm <= 8; pm *= 2)
+        for (int pn = 1; pm * pn <= 8; pn *= 2) {
+            const int pz = 8 / (pm * pn);
+            if (pz > S && pz != 1) continue;
+            if (a.xcd_map == 0 && !(pm == 1 && pn == 8)) continue;
+            const int bm = (tilesM + pm - 1) / pm, bn = (tilesN + pn - 1) / pn, bz = (S + pz - 1) / pz;
+            const double rows = (double)(bm * BM < a.M ? bm * BM : a.M) + (double)(bn * BN < a.N ? bn * BN : a.N);
+            double fp = rows * ((double)a.K * bz / S) * 2.0;
+            const int slots = bm * bn * bz * 8, work = tilesM * tilesN * S;
+            fp *= (double)slots / work;                       // ragged boxes waste launch slots and unbalance XCDs
+            if (pm == 1 && pn == 8) fp *= 0.9;               // near-ties keep the weight stream disjoint across XCDs
+            if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
+        }
+    dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
     constexpr int SMEM = NS * (BM + BN) * 128;
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in attribute once per kernel
     if (!attr_set) {
@@ -301,6 +325,21 @@ void launch_t(const GemmArgs& a, hipStream_t st) {
 //   11  256x256  4x2    2     128 KB  8 waves, wave tile 64x128
 //   12  128x288  4x3    2     104 KB  12 waves: N = 9216 -> 8 x 32 = 256 workgroups at M = 1000 (89 flop/B ingest)
 //   13  128x288  4x3    3     156 KB  same, ring 3 (one whole tile in flight behind the one being consumed)
+//   14  128x64   4x1    3      72 KB  deeper rings for the cold-weight (HBM latency bound) small GEMMs
+//   15  128x64   4x1    4      96 KB
+//   16  64x64    2x2    4      64 KB  288 tiles for N = 1152 at M = 1000 without split-K
+//   17  64x128   2x2    3      72 KB
+//   18  128x64   4x1    6     144 KB  the whole LDS as one deep ring (1 workgroup / CU): ~120 KB of loads in flight
+//   19  64x64    2x2    8     128 KB
+//   20  128x64   4x1    5     120 KB
+//   21  64x64    2x2    5      80 KB  2 workgroups / CU
+//   22  128x128  4x4    3      96 KB  16 waves: scratch/ingest2.hip shows L2 -> LDS ingest per CU scales with the number of
+//   23  128x128  4x4    2      64 KB  waves issuing loads (4: 39, 8: 70, 16: 95 GB/s), not with the depth per wave
+//   24  128x64   4x2    3      72 KB  8 waves
+//   25  128x64   4x2    4      96 KB
+//   26  128x128  4x4    4     128 KB
+//   27  256x128  8x2    2      96 KB  16 waves
+//   28  128x256  4x4    2      96 KB  16 waves
 template <int EPI>
 void launch_e(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
@@ -321,6 +360,21 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
         case 1: launch_t<128, 64, 2, 2, 3, EPI>(a, st); return;
         case 3: launch_t<128, 64, 2, 2, 4, EPI>(a, st); return;
         case 5: launch_t<128, 64, 2, 2, 2, EPI>(a, st); return;
+        case 14: launch_t<128, 64, 4, 1, 3, EPI>(a, st); return;
+        case 15: launch_t<128, 64, 4, 1, 4, EPI>(a, st); return;
+        case 16: launch_t<64, 64, 2, 2, 4, EPI>(a, st); return;
+        case 17: launch_t<64, 128, 2, 2, 3, EPI>(a, st); return;
+        case 18: launch_t<128, 64, 4, 1, 6, EPI>(a, st); return;
+        case 19: launch_t<64, 64, 2, 2, 8, EPI>(a, st); return;
+        case 20: launch_t<128, 64, 4, 1, 5, EPI>(a, st); return;
+        case 21: launch_t<64, 64, 2, 2, 5, EPI>(a, st); return;
+        case 22: launch_t<128, 128, 4, 4, 3, EPI>(a, st); return;
+        case 23: launch_t<128, 128, 4, 4, 2, EPI>(a, st); return;
+        case 24: launch_t<128, 64, 4, 2, 3, EPI>(a, st); return;
+        case 25: launch_t<128, 64, 4, 2, 4, EPI>(a, st); return;
+        case 26: launch_t<128, 128, 4, 4, 4, EPI>(a, st); return;
+        case 27: launch_t<256, 128, 8, 2, 2, EPI>(a, st); return;
+        case 28: launch_t<128, 256, 4, 4, 2, EPI>(a, st); return;
         default: break;
     }
     launch_t<128, 64, 4, 1, 2, EPI>(a, st);
