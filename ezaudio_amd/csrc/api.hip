@@ -85,6 +85,8 @@ struct ezdit_handle {
     // tuning knobs (M <= 2048 rows); defaults from tests/bench_cold.py + tests/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
     // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
+    int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
+    int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
 
@@ -332,6 +334,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.tile = tile;
     g.debug = 0;
     g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h->opt_xcd_map;
+    g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     launch_gemm(g, c.st);
     h->launches++;
 }
@@ -617,6 +620,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         memset(&r, 0, sizeof r);
         r.h_in = h_in; r.h_out = h_out;
         r.part = part_src; r.nsplit = nsplit; r.part_stride = (long)Mp * D; r.ld_part = D;
+        r.part_bf16 = (part_src == part) ? h->opt_slab_bf16 : 0;
         r.cn_scale = h->cn_scale;
         r.bias = bias; r.gate = gate; r.gate_slot_stride = gate_stride; r.mode = mode;
         r.ln_g = lg; r.ln_c = lc; r.ln_slot_stride = ln_stride;
@@ -682,6 +686,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         h->launches++;
         AttnArgs at;
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
+        at.q_raw = nullptr; at.ld_qraw = 0; at.qn_w = nullptr; at.qn_b = nullptr;
         at.out = h->buf<bf16_t>("ao"); at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
@@ -703,9 +708,13 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hn.qn_w = h->w<float>(bn(b, "c.qnw")); hn.qn_b = h->w<float>(bn(b, "c.qnb"));
         hn.q = h->buf<bf16_t>("q");
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
-        STOPCHK();
-        launch_headnorm(hn, st);
-        h->launches++;
+        if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
+            at.q_raw = hn.x; at.ld_qraw = D; at.qn_w = hn.qn_w; at.qn_b = hn.qn_b;
+        } else {
+            STOPCHK();
+            launch_headnorm(hn, st);
+            h->launches++;
+        }
         at.q = hn.q;
         at.k = h->buf<bf16_t>("kc") + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
         at.vt = h->buf<bf16_t>("vct") + (size_t)b * h->B * h->H * h->DV * h->Lcp;
@@ -943,7 +952,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.epi > EPI_GEGLU || g.tile > 28) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
@@ -957,6 +966,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
+    a.q_raw = nullptr; a.ld_qraw = 0; a.qn_w = nullptr; a.qn_b = nullptr;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
     launch_attention(a, (hipStream_t)stream);
@@ -988,6 +998,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "tile_partial")) h->opt_tile_partial = value;
     else if (!strcmp(name, "tile_f32")) h->opt_tile_f32 = value;
     else if (!strcmp(name, "xcd_map")) h->opt_xcd_map = value;
+    else if (!strcmp(name, "slab_bf16")) h->opt_slab_bf16 = value;
+    else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
     else if (!strcmp(name, "tile_p18")) h->opt_tile_p18 = value;
     else if (!strcmp(name, "tile_p36")) h->opt_tile_p36 = value;
     else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;

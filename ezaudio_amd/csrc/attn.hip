@@ -62,8 +62,52 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     const uint8_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
 
     bf16x8 qf[NKS];
+    if (a.q_raw) {
+        // lane (r32, hi) holds d = 16 ks + 8 hi + e of query row q0 + r32: the whole head sits in the lane pair (lane, lane ^ 32)
+        int qr = q0 + r32;
+        if (qr >= a.Lq) qr = a.Lq - 1;   // padding rows: any valid row, the result is never stored
+        const float* src = a.q_raw + ((long)b * a.Lq + qr) * a.ld_qraw + h * DH + 8 * hi;
+        float v[NKS][8];
+        float s = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + 16 * ks);
+        for (int ks = 0; ks < NKS; ++ks) {
+            const bool ok = 16 * ks + 8 * hi < DH;   // DH is a multiple of 8: chunks are all-valid or all-padding
+            const float4 lo = ok ? *reinterpret_cast<const float4*>(src + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 hh = ok ? *reinterpret_cast<const float4*>(src + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[ks][0] = lo.x; v[ks][1] = lo.y; v[ks][2] = lo.z; v[ks][3] = lo.w;
+            v[ks][4] = hh.x; v[ks][5] = hh.y; v[ks][6] = hh.z; v[ks][7] = hh.w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[ks][e];
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.f / DH);
+        float q2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            if (16 * ks + 8 * hi < DH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; q2 += d * d; }
+            }
+        q2 += __shfl_xor(q2, 32, 64);
+        const float rstd = rsqrtf(q2 * (1.f / DH) + 1e-5f);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = 16 * ks + 8 * hi;
+            const bool ok = d0 < DH;
+            const int dw = ok ? d0 : 0;
+            union { bf16x8 v; uint32_t u[4]; } pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y0 = ok ? (v[ks][2 * e] - mean) * rstd * a.qn_w[dw + 2 * e] + a.qn_b[dw + 2 * e] : 0.f;
+                const float y1 = ok ? (v[ks][2 * e + 1] - mean) * rstd * a.qn_w[dw + 2 * e + 1] + a.qn_b[dw + 2 * e + 1] : 0.f;
+                pk.u[e] = pack_bf2(y0, y1);
+            }
+            qf[ks] = pk.v;
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + 16 * ks);
+    }
 
     // staging registers: NAMED scalars, not an array (hipcc demotes a register array that is live across the tile loop
     // to scratch); every thread issues all its loads unconditionally (chunk index clamped), only LDS writes are predicated

@@ -58,6 +58,7 @@ struct GemmArgs {
     // (hardware deals workgroups to XCDs round-robin), so each XCD's private 4 MB L2 sees only its box's slice of A and W.
     // Filled by launch_gemm (xcd_map: 0 = legacy 1 x 8 x 1, 1 = smallest per-XCD footprint).
     int xcd_map; int pm, pn, pz, bm, bn, bz;
+    int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 
@@ -68,13 +69,17 @@ struct AttnArgs {
     const uint8_t* kmask;  // nullable [B][Lk], 1 = attend
     bf16_t* out; int ldo;  // [B*Lq][ldo], head h occupies cols [h*dh, (h+1)*dh)
     int B, H, Lq, Lk, Lqp, Lkp, dh;
+    // optional fused query prologue (cross-attention): q_raw fp32 [B*Lq][ld_qraw] straight from the projection GEMM; the
+    // per-head LayerNorm (attention.py:141, shared affine [dh]) is applied while the MFMA operand is built (q unused)
+    const float* q_raw; int ld_qraw; const float* qn_w; const float* qn_b;
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
 
 struct RowArgs {
     // h_new = (mode SET) sum_s part_s + bias | (RES) h_in + gate * (sum_s part_s + bias) | (COPY) h_in
     const float* h_in; float* h_out;  // h_out nullable (not stored)
-    const float* part; int nsplit; long part_stride; int ld_part;
+    const float* part; int nsplit; long part_stride; int ld_part;  // strides in elements
+    int part_bf16;                       // slabs hold bf16 instead of fp32
     const float* bias;
     const float* gate; long gate_slot_stride;  // gate nullable -> 1; per-slot vector when stride != 0
     int mode;  // 0 COPY, 1 RES, 2 SET

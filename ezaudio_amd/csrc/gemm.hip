@@ -270,7 +270,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                             }
                         }
-                        *reinterpret_cast<float4*>(out + (long)row * a.ldo + col) = v;
+                        if (EPI == EPI_PARTIAL && a.part_bf16) {
+                            uint2 pk;
+                            pk.x = pack_bf2(v.x, v.y);
+                            pk.y = pack_bf2(v.z, v.w);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + (long)z * a.slab_stride + (long)row * a.ldo + col) = pk;
+                        } else {
+                            *reinterpret_cast<float4*>(out + (long)row * a.ldo + col) = v;
+                        }
                     }
                 }
         }

@@ -60,7 +60,18 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
                 if (gate) g = ld4(gate + c * 4);
 #pragma unroll
                 for (int sp = 0; sp < MAXS; ++sp)
-                    p[sp] = sp < a.nsplit ? ld4(a.part + sp * a.part_stride + (long)row * a.ld_part + c * 4) : zero;
+                    if (sp < a.nsplit) {
+                        const long e = sp * a.part_stride + (long)row * a.ld_part + c * 4;
+                        if (a.part_bf16) {
+                            const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.part) + e);
+                            p[sp] = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                                                __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+                        } else {
+                            p[sp] = ld4(a.part + e);
+                        }
+                    } else {
+                        p[sp] = zero;
+                    }
 #pragma unroll
                 for (int sp = 0; sp < MAXS; ++sp) { s.x += p[sp].x; s.y += p[sp].y; s.z += p[sp].z; s.w += p[sp].w; }
                 if (a.mode == 1) {
