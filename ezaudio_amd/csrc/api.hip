@@ -85,6 +85,7 @@ struct ezdit_handle {
     // tuning knobs (M <= 2048 rows); defaults from tests/bench_cold.py + tests/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
     // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
+    int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
@@ -343,12 +344,13 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
 // 3 workgroups per CU wins everywhere (occupancy beats ring depth); from M ~ 4000 the 128x128 8-wave tile is ahead.
 int tile_for(const ezdit_handle* h, int M, bool partial) {
     if (M <= 2048) return partial ? h->opt_tile_partial : h->opt_tile_f32;
-    return partial ? 5 : 7;
+    return partial ? h->opt_tile_partial_big : h->opt_tile_f32_big;
 }
 
 int pick_splitk(const ezdit_handle* h, int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = K / 64;
+    if (M > 2048 && h->opt_split_big > 0) return h->opt_split_big < nk ? h->opt_split_big : nk;
     if (tiles >= 256) return 1;
     int s = nk >= 72 ? h->opt_split72 : nk >= 36 ? h->opt_split36 : h->opt_split18;  // fewer slabs = less row-kernel traffic
     if (s > nk) s = nk;
@@ -730,7 +732,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU,
-             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 13 : 2));
+             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 13 : h->opt_geglu_big));
         STOPCHK();
         s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
@@ -1000,6 +1002,10 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "xcd_map")) h->opt_xcd_map = value;
     else if (!strcmp(name, "slab_bf16")) h->opt_slab_bf16 = value;
     else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
+    else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
+    else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;
+    else if (!strcmp(name, "geglu_big")) h->opt_geglu_big = value;
+    else if (!strcmp(name, "split_big")) h->opt_split_big = value;
     else if (!strcmp(name, "tile_p18")) h->opt_tile_p18 = value;
     else if (!strcmp(name, "tile_p36")) h->opt_tile_p36 = value;
     else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;

@@ -271,10 +271,12 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs a) {
 }
 
 // out[b][co][l] = bias[co] + sum_{ci,k} w[co][ci][k] * y[b][l+k-1][ci]      (fp32 FMA: this is the model output)
-// workgroup = 8 frames x all C channels of one batch element (B*L/8 workgroups); thread = 1 frame x C/32 channels
+// workgroup = 4 frames x all C (<= 128) output channels of one batch element; thread = one output channel x 2 frames: its
+// weight row [C][3] is read with 16-byte loads (12 floats = 4 input channels x 3 taps per step), activations are LDS
+// broadcasts (every lane of a wave reads the same word).
 __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
-    constexpr int TL = 8;
-    extern __shared__ float sy[];  // [(TL+2)][C+1]
+    constexpr int TL = 4;
+    extern __shared__ float sy[];  // [(TL+2)][C]
     const int C = a.C;
     const int ltiles = (a.L + TL - 1) / TL;
     const int b = blockIdx.x / ltiles;
@@ -282,21 +284,27 @@ __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
     for (int i = threadIdx.x; i < (TL + 2) * C; i += 256) {
         const int r = i / C, ci = i % C;
         const int l = l0 + r - 1;
-        sy[r * (C + 1) + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
+        sy[r * C + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
     }
     __syncthreads();
-    const int ll = threadIdx.x & 7;
-    const int cg = threadIdx.x >> 3;  // 32 groups
-    const int l = l0 + ll;
-    for (int co = cg; co < C; co += 32) {
-        float acc = a.b[co];
-        const float* wr = a.w + (long)co * C * 3;
-        for (int ci = 0; ci < C; ++ci) {
-            acc += wr[ci * 3 + 0] * sy[(ll + 0) * (C + 1) + ci];
-            acc += wr[ci * 3 + 1] * sy[(ll + 1) * (C + 1) + ci];
-            acc += wr[ci * 3 + 2] * sy[(ll + 2) * (C + 1) + ci];
+    const int ll = (threadIdx.x >> 7) * 2;
+    for (int co = threadIdx.x & 127; co < C; co += 128) {
+    float acc0 = a.b[co], acc1 = acc0;
+    const float* wr = a.w + (long)co * C * 3;
+    const float* s0 = sy + ll * C;
+    for (int ci = 0; ci < C; ci += 4) {
+        const float4 w0 = ld4(wr + ci * 3), w1 = ld4(wr + ci * 3 + 4), w2 = ld4(wr + ci * 3 + 8);
+        const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float y0 = s0[ci + e], y1 = s0[C + ci + e], y2 = s0[2 * C + ci + e], y3 = s0[3 * C + ci + e];
+            acc0 = fmaf(w[3 * e], y0, acc0); acc0 = fmaf(w[3 * e + 1], y1, acc0); acc0 = fmaf(w[3 * e + 2], y2, acc0);
+            acc1 = fmaf(w[3 * e], y1, acc1); acc1 = fmaf(w[3 * e + 1], y2, acc1); acc1 = fmaf(w[3 * e + 2], y3, acc1);
         }
-        if (l < a.L) a.out[((long)b * C + co) * a.L + l] = acc;
+    }
+    const int l = l0 + ll;
+    if (l < a.L) a.out[((long)b * C + co) * a.L + l] = acc0;
+    if (l + 1 < a.L) a.out[((long)b * C + co) * a.L + l + 1] = acc1;
     }
 }
 
@@ -528,8 +536,8 @@ void launch_assemble(const AssembleArgs& a, hipStream_t st) {
 }
 
 void launch_final_conv(const FinalConvArgs& a, hipStream_t st) {
-    const int ltiles = (a.L + 7) / 8;
-    const size_t sh = (size_t)10 * (a.C + 1) * sizeof(float);
+    const int ltiles = (a.L + 3) / 4;
+    const size_t sh = (size_t)6 * a.C * sizeof(float);
     hipLaunchKernelGGL(k_final_conv, dim3(a.B * ltiles), dim3(256), sh, st, a);
 }
 
