@@ -86,6 +86,8 @@ struct ezdit_handle {
     // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
+    int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
+    int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
@@ -251,7 +253,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         off += (size_t)rup((long)bytes, 256);
     };
     const long D = h->D, I = h->I, C = h->C, H = h->H;
-    const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 64), Lcp = rup(Lc, 64);  // attention stages 64-key tiles
+    const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 128), Lcp = rup(Lc, 128);  // attention stages 64- or 128-key tiles
     const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
     const int nblk = h->nblk;
     add("ints", 256 * sizeof(int));                       // [0] cur_step, [16..] row_slot (<= 240 rows)
@@ -309,9 +311,13 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
 // ------------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------------
+struct FuseResid {   // out = resid + gate * (A . W^T + bias) in the GEMM epilogue
+    const float* resid; int ldr; const float* gate; long gate_stride; const int* cur_step; const int* row_slot; int rows_per_b;
+};
 struct Ctx {
     ezdit_handle* h;
     hipStream_t st;
+    const FuseResid* fuse = nullptr;
 };
 
 void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const float* bias, void* out, int ldo, int M, int N,
@@ -336,6 +342,12 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.debug = 0;
     g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h->opt_xcd_map;
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
+    g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
+    if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
+        g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
+        g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
+        c.fuse = nullptr;
+    }
     launch_gemm(g, c.st);
     h->launches++;
 }
@@ -471,7 +483,7 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     h->ws_bytes = bytes;
     h->bufs = bufs;
     h->B = B; h->L = L; h->Lc = Lc; h->n_slots = n_slots > 0 ? n_slots : 1;
-    h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 64); h->Lcp = (int)rup(Lc, 64);
+    h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 128); h->Lcp = (int)rup(Lc, 128);
     h->Mc = B * Lc;
     h->ctx_ready = h->ts_ready = h->cond_ready = false;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -688,18 +700,28 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         h->launches++;
         AttnArgs at;
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
-        at.q_raw = nullptr; at.ld_qraw = 0; at.qn_w = nullptr; at.qn_b = nullptr;
+        at.q_raw = nullptr; at.ld_qraw = 0; at.qn_w = nullptr; at.qn_b = nullptr; at.nkh = h->opt_attn_nkh;
         at.out = h->buf<bf16_t>("ao"); at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
         launch_attention(at, st);
         h->launches++;
         STOPCHK();
-        int s = gemm_partial(c, at.out, h->ldD, bn(b, "wo"), M, D);
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
-        STOPCHK();
-        row(1, hcur, hA, s, h->w<float>(bn(b, "bo")), modv(b, 2), mod_slot, h->w<float>(bn(b, "n2w")), h->w<float>(bn(b, "n2b")), 0,
-            nullptr, nullptr, h->ldD);
+        int s = 0;
+        const bool fuse_res = h->opt_fuse_resid && M <= 2048;   // non-split GEMM with the gated residual in its epilogue
+        if (fuse_res) {
+            const FuseResid fr{hcur, D, modv(b, 2), mod_slot, cur, row_slot, h->L};
+            c.fuse = &fr;
+            gemm(c, at.out, h->ldD, bn(b, "wo"), h->w<float>(bn(b, "bo")), hA, D, M, D, EPI_F32, tile_for(h, M, false));
+            STOPCHK();
+            row(0, hA, nullptr, 0, nullptr, nullptr, 0, h->w<float>(bn(b, "n2w")), h->w<float>(bn(b, "n2b")), 0, nullptr, nullptr, h->ldD);
+        } else {
+            s = gemm_partial(c, at.out, h->ldD, bn(b, "wo"), M, D);
+            STOPCHK();
+            row(1, hcur, hA, s, h->w<float>(bn(b, "bo")), modv(b, 2), mod_slot, h->w<float>(bn(b, "n2w")), h->w<float>(bn(b, "n2b")), 0,
+                nullptr, nullptr, h->ldD);
+        }
         hcur = hA;
         // ---- cross attention (blocks.py:147-151) ----
         STOPCHK();
@@ -726,9 +748,17 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         launch_attention(at, st);
         h->launches++;
         STOPCHK();
-        s = gemm_partial(c, at.out, h->ldD, bn(b, "wo2"), M, D);
-        STOPCHK();
-        row(1, hA, hA, s, h->w<float>(bn(b, "bo2")), nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+        if (fuse_res) {
+            const FuseResid fr{hA, D, nullptr, 0, nullptr, nullptr, h->L};
+            c.fuse = &fr;
+            gemm(c, at.out, h->ldD, bn(b, "wo2"), h->w<float>(bn(b, "bo2")), hA, D, M, D, EPI_F32, tile_for(h, M, false));
+            STOPCHK();
+            row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+        } else {
+            s = gemm_partial(c, at.out, h->ldD, bn(b, "wo2"), M, D);
+            STOPCHK();
+            row(1, hA, hA, s, h->w<float>(bn(b, "bo2")), nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+        }
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU,
@@ -955,6 +985,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
     g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0;
+    g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.epi > EPI_GEGLU || g.tile > 28) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
@@ -968,7 +999,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
-    a.q_raw = nullptr; a.ld_qraw = 0; a.qn_w = nullptr; a.qn_b = nullptr;
+    a.q_raw = nullptr; a.ld_qraw = 0; a.qn_w = nullptr; a.qn_b = nullptr; a.nkh = h->opt_attn_nkh;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
     launch_attention(a, (hipStream_t)stream);
@@ -1002,6 +1033,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "xcd_map")) h->opt_xcd_map = value;
     else if (!strcmp(name, "slab_bf16")) h->opt_slab_bf16 = value;
     else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
+    else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
+    else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
     else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;
     else if (!strcmp(name, "geglu_big")) h->opt_geglu_big = value;

@@ -32,25 +32,32 @@ struct HeadGeom<64> { static constexpr int DQK = 64, DV = 64; };
 template <>
 struct HeadGeom<72> { static constexpr int DQK = 80, DV = 96; };
 
-template <int DH>
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+// NKH = key sub-blocks (of 32 keys) per staged tile = waves per query sub-block.  2: 64-key tiles, 4 waves.  4: 128-key tiles,
+// 8 waves -- twice the waves per CU (one prompt = one workgroup per CU, so a SIMD otherwise hosts a single wave and its
+// softmax VALU work never overlaps MFMAs) and half the tile-loop trips; needs Lkp % 128 == 0.
+template <int DH, int NKH>
+__global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
+    constexpr int NT = 128 * NKH;
+    constexpr int TK = 32 * NKH;   // keys per staged tile
     constexpr int DQK = HeadGeom<DH>::DQK;
     constexpr int DV = HeadGeom<DH>::DV;
     constexpr int NKS = DQK / 16;  // k-steps of the QK^T contraction
     constexpr int NDT = DV / 32;   // 32-row tiles of O^T
     constexpr int KSTR = DQK * 2 + 16;   // LDS row stride of a K row (bytes)
-    constexpr int VSTR = 64 * 2 + 8;     // LDS row stride of a V^T row (64 keys)
-    constexpr int KBYTES = 64 * KSTR, VBYTES = DV * VSTR;
+    constexpr int VSTR = TK * 2 + 8;     // LDS row stride of a V^T row (TK keys)
+    constexpr int KBYTES = TK * KSTR, VBYTES = DV * VSTR;
     constexpr int BUF = KBYTES + VBYTES;
-    constexpr int KCH = 64 * DQK * 2 / 16;   // 16-byte chunks of a K tile (contiguous in global memory)
-    constexpr int VCH = DV * 8;              // 16-byte chunks of a V^T tile (8 per row)
-    constexpr int KPT = (KCH + 255) / 256, VPT = (VCH + 255) / 256;
+    constexpr int KCH = TK * DQK * 2 / 16;   // 16-byte chunks of a K tile (contiguous in global memory)
+    constexpr int VCPR = TK / 8;             // 16-byte chunks per V^T row
+    constexpr int VCH = DV * VCPR;           // 16-byte chunks of a V^T tile
+    constexpr int KPT = (KCH + NT - 1) / NT, VPT = (VCH + NT - 1) / NT;
+    static_assert(KPT <= 3 && VPT <= 3, "staging registers");
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int qs = wave & 1, kh = wave >> 1;
+    const int qs = wave & 1, kh = wave >> 1;   // kh in [0, NKH)
     const int r32 = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * 64 + qs * 32;
@@ -113,30 +120,30 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     // to scratch); every thread issues all its loads unconditionally (chunk index clamped), only LDS writes are predicated
     uint4 k0 = {}, k1 = {}, k2 = {}, v0 = {}, v1 = {}, v2 = {};
     auto kchunk = [&](int i, int key0) -> uint4 {
-        int c = tid + 256 * i;
+        int c = tid + NT * i;
         c = c < KCH ? c : KCH - 1;
         return *reinterpret_cast<const uint4*>(Kg + (long)key0 * DQK * 2 + c * 16);
     };
     auto vchunk = [&](int i, int key0) -> uint4 {
-        int c = tid + 256 * i;
+        int c = tid + NT * i;
         c = c < VCH ? c : VCH - 1;
-        return *reinterpret_cast<const uint4*>(VTg + (long)(c >> 3) * a.Lkp + key0 + (c & 7) * 8);
+        return *reinterpret_cast<const uint4*>(VTg + (long)(c / VCPR) * a.Lkp + key0 + (c % VCPR) * 8);
     };
     auto kstore = [&](int i, char* kb, const uint4& val) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         if (c < KCH) *reinterpret_cast<uint4*>(kb + (c / (DQK / 8)) * KSTR + (c % (DQK / 8)) * 16) = val;
     };
     auto vstore = [&](int i, char* vb, const uint4& val) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         if (c < VCH) {
-            char* dst = vb + (c >> 3) * VSTR + (c & 7) * 16;
+            char* dst = vb + (c / VCPR) * VSTR + (c % VCPR) * 16;
             *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
             *reinterpret_cast<uint2*>(dst + 8) = make_uint2(val.z, val.w);
         }
     };
 #define LOAD_TILE(t)                                   \
     do {                                               \
-        const int key0_ = (t) * 64;                    \
+        const int key0_ = (t) * TK;                    \
         k0 = kchunk(0, key0_);                         \
         k1 = kchunk(1, key0_);                         \
         if constexpr (KPT > 2) k2 = kchunk(2, key0_);  \
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     constexpr float RESCALE_THR = 4.0f;  // log2 units: P <= 16
     const float c = 1.4426950408889634f * rsqrtf((float)DH);  // log2(e) / sqrt(dh)
 
-    const int ntiles = (a.Lk + 63) / 64;
+    const int ntiles = (a.Lk + TK - 1) / TK;
     LOAD_TILE(0);
     WRITE_TILE(0);
     __syncthreads();
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         if (t + 1 < ntiles) LOAD_TILE(t + 1);
         const char* kb = smem + (t & 1) * BUF;
         const char* vb = kb + KBYTES;
-        const int key0 = t * 64 + kh * 32;
+        const int key0 = t * TK + kh * 32;
         if (key0 < a.Lk) {  // wave-uniform: the whole 32-key sub-tile may lie beyond Lk
             // validity of this wave's 32 keys as one bit mask (bit j <-> key0 + j), built BEFORE the MFMAs
             const int kidx = key0 + r32;
@@ -248,29 +255,42 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         __syncthreads();
     }
 
-    // ---- merge the two key halves: (m, l, O) of kh = 1 -> LDS -> kh = 0 ----
+    // ---- merge the key sub-blocks: (m, l, O) of the waves kh >= 1 -> LDS -> kh = 0 (log-sum-exp merge) ----
 #pragma unroll
     for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[tt]));
-    float* xo = reinterpret_cast<float*>(smem);                       // [qs][NDT][16][64]
-    float* xml = reinterpret_cast<float*>(smem) + 2 * NDT * 16 * 64;  // [qs][2][32]
-    static_assert(2 * BUF >= (2 * NDT * 16 * 64 + 2 * 2 * 32) * 4, "exchange area must fit the staging buffers");
-    if (kh == 1) {
+    constexpr int XO = 2 * NDT * 16 * 64;                              // floats per partner: [qs][NDT][16][64]
+    float* xo = reinterpret_cast<float*>(smem);                        // [NKH-1][qs][NDT][16][64]
+    float* xml = reinterpret_cast<float*>(smem) + (NKH - 1) * XO;      // [NKH-1][qs][2][32]
+    static_assert(2 * BUF >= (NKH - 1) * (XO + 2 * 2 * 32) * 4, "exchange area must fit the staging buffers");
+    if (kh >= 1) {
+        float* xo_w = xo + (kh - 1) * XO;
+        float* xml_w = xml + (kh - 1) * (2 * 2 * 32);
 #pragma unroll
         for (int tt = 0; tt < NDT; ++tt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xo[((qs * NDT + tt) * 16 + r) * 64 + lane] = o[tt][r];
+            for (int r = 0; r < 16; ++r) xo_w[((qs * NDT + tt) * 16 + r) * 64 + lane] = o[tt][r];
         if (hi == 0) {
-            xml[(qs * 2 + 0) * 32 + r32] = m;
-            xml[(qs * 2 + 1) * 32 + r32] = lsum;
+            xml_w[(qs * 2 + 0) * 32 + r32] = m;
+            xml_w[(qs * 2 + 1) * 32 + r32] = lsum;
         }
     }
     __syncthreads();
-    if (kh == 1) return;
-    const float m2 = xml[(qs * 2 + 0) * 32 + r32], l2 = xml[(qs * 2 + 1) * 32 + r32];
-    const float mm = fmaxf(m, m2);
-    const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
-    const float inv = 1.f / (lsum * a1 + l2 * a2);
-    const float w1 = a1 * inv, w2 = a2 * inv;
+    if (kh >= 1) return;
+#pragma unroll
+    for (int j = 0; j < NKH - 1; ++j) {
+        const float* xo_r = xo + j * XO;
+        const float* xml_r = xml + j * (2 * 2 * 32);
+        const float m2 = xml_r[(qs * 2 + 0) * 32 + r32], l2 = xml_r[(qs * 2 + 1) * 32 + r32];
+        const float mm = fmaxf(m, m2);
+        const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
+        lsum = lsum * a1 + l2 * a2;
+        m = mm;
+#pragma unroll
+        for (int tt = 0; tt < NDT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[tt][r] = o[tt][r] * a1 + xo_r[((qs * NDT + tt) * 16 + r) * 64 + lane] * a2;
+    }
+    const float inv = 1.f / lsum;
 
     // lane holds O^T[d = 32t + (r&3) + 8*(r>>2) + 4*hi][q = q0 + r32]
     const int qrow = q0 + r32;
@@ -284,8 +304,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             if (d < DH) {
                 float v4[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v4[e] = o[tt][4 * g + e] * w1 + xo[((qs * NDT + tt) * 16 + 4 * g + e) * 64 + lane] * w2;
+                for (int e = 0; e < 4; ++e) v4[e] = o[tt][4 * g + e] * inv;
                 uint2 v;
                 v.x = pack_bf2(v4[0], v4[1]);
                 v.y = pack_bf2(v4[2], v4[3]);
@@ -301,6 +320,14 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 
 void launch_attention(const AttnArgs& a, hipStream_t st) {
     dim3 grid((a.Lq + 63) / 64, a.H, a.B);
-    if (a.dh == 64) hipLaunchKernelGGL((k_attn<64>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_attn<72>), grid, dim3(256), 0, st, a);
+    int nkh = a.nkh;
+    if (nkh != 2 && nkh != 4) nkh = (long)grid.x * grid.y * grid.z <= 512 ? 4 : 2;   // 0 = choose by grid size
+    if (a.Lkp % 128) nkh = 2;
+    if (a.dh == 64) {
+        if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a);
+    } else {
+        if (nkh == 4) hipLaunchKernelGGL((k_attn<72, 4>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<72, 2>), grid, dim3(256), 0, st, a);
+    }
 }

@@ -53,7 +53,9 @@ struct GemmArgs {
     // (t % conv_cpb) * 128, i.e. tap t/conv_cpb is the SAME activation rows shifted by a fixed number of rows.
     // conv_cpb = 0: plain GEMM (offset t * 128).
     int conv_cpb; long conv_tap_bytes;
-    const float* resid; int ldr;  // EPI_F32: out += resid[row][col] (residual connection), nullable
+    const float* resid; int ldr;  // EPI_F32: out = resid[row][col] + gate[col] * (acc + bias) (residual connection), nullable
+    // gate (nullable = 1): per-column vector of modulation slot (*cur_step + row_slot[row / rows_per_b]), as in RowArgs
+    const float* gate; long gate_slot_stride; const int* cur_step; const int* row_slot; int rows_per_b;
     // workgroup -> XCD placement: the (M tiles x N tiles x K splits) grid is cut into pm x pn x pz = 8 boxes, one per XCD
     // (hardware deals workgroups to XCDs round-robin), so each XCD's private 4 MB L2 sees only its box's slice of A and W.
     // Filled by launch_gemm (xcd_map: 0 = legacy 1 x 8 x 1, 1 = smallest per-XCD footprint).
@@ -72,6 +74,7 @@ struct AttnArgs {
     // optional fused query prologue (cross-attention): q_raw fp32 [B*Lq][ld_qraw] straight from the projection GEMM; the
     // per-head LayerNorm (attention.py:141, shared affine [dh]) is applied while the MFMA operand is built (q unused)
     const float* q_raw; int ld_qraw; const float* qn_w; const float* qn_b;
+    int nkh;   // key sub-blocks (waves) per query sub-block: 2 (64-key tiles), 4 (128-key tiles, Lkp % 128 == 0), 0 = auto
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
 

@@ -267,6 +267,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                             }
                             if (a.resid) {
                                 const float4 r = *reinterpret_cast<const float4*>(a.resid + (long)row * a.ldr + col);
+                                if (a.gate) {
+                                    const int slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[row / a.rows_per_b] : 0);
+                                    const float4 g = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
+                                    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+                                }
                                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                             }
                         }

@@ -124,16 +124,20 @@ def test_gemm_geglu_epilogue(lib, dev, tile):
     assert rel_l2(out.float().cpu().numpy(), ref.numpy()) < 4e-3  # one bf16 rounding of the output
 
 
+@pytest.mark.parametrize('nkh', [2, 4])   # 64-key tiles / 4 waves and 128-key tiles / 8 waves
 @pytest.mark.parametrize('size,Lq,Lk,masked', [('xs', 96, 96, False), ('xs64', 96, 96, False), ('xs', 500, 100, True), ('xs', 64, 20, True),
-                                               ('xs64', 500, 100, True), ('xs', 500, 500, False), ('xs64', 77, 500, False)])
-def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked):
+                                               ('xs64', 500, 100, True), ('xs', 500, 500, False), ('xs64', 77, 500, False),
+                                               ('xs', 300, 300, False)])
+def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked, nkh):
     m = get_model(size, 1)
     cfg = model_config(size)
     H, D = cfg['num_heads'], cfg['embed_dim']
     dh = D // H
     DQK, DV = (64, 64) if dh == 64 else (80, 96)
     B = 2
-    Lqp, Lkp = (Lq + 63) // 64 * 64, (Lk + 63) // 64 * 64
+    pad = 32 * nkh
+    Lqp, Lkp = (Lq + 63) // 64 * 64, (Lk + pad - 1) // pad * pad
+    assert lib.ezdit_set_option(m._h, b'attn_nkh', nkh) == 0
     g = torch.Generator().manual_seed(Lq * 7 + Lk)
     q = torch.randn(B, H, Lq, dh, generator=g).to(torch.bfloat16)
     k = torch.randn(B, H, Lk, dh, generator=g).to(torch.bfloat16)
@@ -154,6 +158,7 @@ def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked):
                                   md.data_ptr() if masked else None, out.data_ptr(), B, Lq, Lk, Lqp, Lkp, None)
     assert rc == 0
     torch.cuda.synchronize()
+    assert lib.ezdit_set_option(m._h, b'attn_nkh', 0) == 0
     s = (q.double() @ k.double().transpose(2, 3)) * dh ** -0.5
     s = s.masked_fill(~mask[:, None, None, :], float('-inf'))
     ref = (torch.softmax(s, -1) @ v.double()).transpose(1, 2).reshape(B * Lq, D)
