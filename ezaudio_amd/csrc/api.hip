@@ -352,8 +352,9 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     h->launches++;
 }
 
-// Tile / split-K heuristics from tests/bench_kernels.py on MI355X (profiles/): with M ~ 1000 rows the 128x64 tile at
-// 3 workgroups per CU wins everywhere (occupancy beats ring depth); from M ~ 4000 the 128x128 8-wave tile is ahead.
+// Tile / split-K heuristics: measured in situ on MI355X with tests/ab_sweep.py (one knob flipped on the live sampler) and
+// tests/bench_cold.py (cold weights, freshly written activations); DESIGN.md section 4 has the numbers.  Every choice can be
+// overridden through ezdit_set_option, which is what those harnesses do.
 int tile_for(const ezdit_handle* h, int M, bool partial) {
     if (M <= 2048) return partial ? h->opt_tile_partial : h->opt_tile_f32;
     return partial ? h->opt_tile_partial_big : h->opt_tile_f32_big;
