@@ -59,6 +59,8 @@ PROTOTYPES = {
     'ezdit_sampler_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(EzditDdimCoef), C.c_int,
                                       C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     'ezdit_sampler_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'ezdit_cfg_ddim_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
     'ezvae_gemm': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     'ezvae_snake_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),

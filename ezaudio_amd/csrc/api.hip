@@ -942,11 +942,27 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
     CfgDdimArgs a;
     a.pred = pred; a.latents = h->latents; a.noise = h->noise;
     a.coef = h->buf<float>("coef"); a.cur_step = h->buf<int>("ints");
+    for (float& v : a.hc) v = 0.f;
     a.guidance_scale = h->gscale; a.guidance_rescale = h->grescale;
     a.P = h->P; a.n = h->C * h->L;
     launch_cfg_ddim(a, h->buf<float>("cfgpart"), st);
     launch_set_int(h->buf<int>("ints"), 1, 1, st);
     h->launches += 2;
+    return EZDIT_OK;
+}
+
+// A2 + A3 + S of SURVEY.md section 8a as ONE stand-alone operator (src/inference.py:88-100): what a caller that keeps the
+// reference's Python loop binds in place of `rescale_noise_cfg` + `scheduler.step`.
+int ezdit_cfg_ddim_step(const float* pred, float* latents, const float* noise, const ezdit_ddim_coef* coef, float guidance_scale,
+                        float guidance_rescale, int P, int n, float* scratch, ezdit_stream stream) {
+    if (!pred || !latents || !coef || P < 1 || n < 2) return fail(EZDIT_E_INVALID, "bad argument");
+    if (guidance_scale > 0.f && guidance_rescale > 0.f && !scratch) return fail(EZDIT_E_INVALID, "guidance_rescale needs %d scratch floats", P * 256);
+    CfgDdimArgs a;
+    a.pred = pred; a.latents = latents; a.noise = noise; a.coef = nullptr; a.cur_step = nullptr;
+    a.hc[0] = coef->sa; a.hc[1] = coef->sb; a.hc[2] = coef->c_x0; a.hc[3] = coef->c_dir; a.hc[4] = coef->sigma;
+    a.guidance_scale = guidance_scale; a.guidance_rescale = guidance_rescale;
+    a.P = P; a.n = n;
+    launch_cfg_ddim(a, scratch, (hipStream_t)stream);
     return EZDIT_OK;
 }
 

@@ -150,7 +150,8 @@ struct CfgDdimArgs {
     float* latents;      // [P][C][L] in/out
     const float* noise;  // [n_steps][P][C][L] or null
     const float* coef;   // [n_steps][8] (sa, sb, c_x0, c_dir, sigma, 0,0,0)
-    const int* cur_step;
+    const int* cur_step; // null: standalone step, coefficients in hc[], noise is this step's slice
+    float hc[5];         // (sa, sb, c_x0, c_dir, sigma) when cur_step is null
     float guidance_scale, guidance_rescale;  // guidance_scale <= 0: no CFG
     int P, n;            // n = C*L elements per sample
 };

@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void k_cfg_stats(CfgDdimArgs a, float* partial
 __global__ __launch_bounds__(256) void k_cfg_apply(CfgDdimArgs a, const float* partial) {
     const int p = blockIdx.y, blk = blockIdx.x;
     const int n = a.n;
-    const int step = *a.cur_step;
-    const float* cf = a.coef + step * 8;
+    const int step = a.cur_step ? *a.cur_step : 0;
+    const float* cf = a.cur_step ? a.coef + step * 8 : a.hc;
     const float sa = cf[0], sb = cf[1], cx0 = cf[2], cdir = cf[3], sigma = cf[4];
     const bool cfg = a.guidance_scale > 0.f;
     const bool rescale = cfg && a.guidance_rescale > 0.f;

@@ -83,23 +83,25 @@ class DDIMScheduler:
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         return a_t, a_prev
 
+    def _coef(self, t, eta):
+        a_t, a_prev = self._scalars(t)
+        b_t = 1 - a_t
+        variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
+        sigma = eta * variance ** 0.5
+        # With zero terminal SNR and eta = 1 the radicand is 0 in exact arithmetic at t = 999 (alpha_bar_t = 0 =>
+        # sigma^2 = 1 - alpha_bar_prev) and +-6e-8 in fp32: the reference (diffusers) takes sqrt of whichever sign
+        # the host's rounding produced (NaN for e.g. 25 steps).  Clamp at 0: identical whenever the reference is
+        # finite, finite where it is not.
+        c_dir = torch.clamp(1 - a_prev - sigma ** 2, min=0.0) ** 0.5
+        return tuple(float(v) for v in (a_t ** 0.5, b_t ** 0.5, a_prev ** 0.5, c_dir, sigma))
+
     def ddim_coefficients(self, eta):
-        """[(sa, sb, c_x0, c_dir, sigma)] per step, float32, for ezdit_sampler_begin."""
-        out = []
-        for t in self.timesteps:
-            a_t, a_prev = self._scalars(t)
-            b_t = 1 - a_t
-            variance = ((1 - a_prev) / b_t) * (1 - a_t / a_prev)
-            sigma = eta * variance ** 0.5
-            # With zero terminal SNR and eta = 1 the radicand is 0 in exact arithmetic at t = 999 (alpha_bar_t = 0 =>
-            # sigma^2 = 1 - alpha_bar_prev) and +-6e-8 in fp32: the reference (diffusers) takes sqrt of whichever sign
-            # the host's rounding produced (NaN for e.g. 25 steps).  Clamp at 0: identical whenever the reference is
-            # finite, finite where it is not.
-            c_dir = torch.clamp(1 - a_prev - sigma ** 2, min=0.0) ** 0.5
-            out.append(tuple(float(v) for v in (a_t ** 0.5, b_t ** 0.5, a_prev ** 0.5, c_dir, sigma)))
-        return out
+        """[(sa, sb, c_x0, c_dir, sigma)] per step, float32, for ezdit_sampler_begin / ezdit_cfg_ddim_step."""
+        return [self._coef(t, eta) for t in self.timesteps]
 
     def step(self, model_output, timestep, sample, eta=0.0, generator=None, variance_noise=None, **unused):
+        if sample.is_cuda:   # the reference's own loop driving this scheduler on the GPU: one HIP launch, no torch math
+            return self._step_hip(model_output, timestep, sample, eta, generator, variance_noise)
         a_t, a_prev = self._scalars(timestep)
         b_t = 1 - a_t
         x0 = (a_t ** 0.5) * sample - (b_t ** 0.5) * model_output
@@ -113,6 +115,24 @@ class DDIMScheduler:
                                              dtype=model_output.dtype)
             prev = prev + sigma * variance_noise
         return types.SimpleNamespace(prev_sample=prev)
+
+    def _step_hip(self, model_output, timestep, sample, eta, generator, variance_noise):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        coef = _lib.EzditDdimCoef(*self._coef(timestep, eta))
+        pred = model_output.contiguous().float()
+        prev = sample.contiguous().float().clone()
+        noise = None
+        if eta > 0:
+            noise = variance_noise if variance_noise is not None else torch.randn(
+                model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+            noise = noise.contiguous().float()
+        P = prev.shape[0]
+        st = torch.cuda.current_stream(prev.device).cuda_stream
+        _lib.check(lib.ezdit_cfg_ddim_step(pred.data_ptr(), prev.data_ptr(), noise.data_ptr() if noise is not None else None,
+                                           C.byref(coef), 0.0, 0.0, P, prev[0].numel(), None, C.c_void_p(st)))
+        return types.SimpleNamespace(prev_sample=prev.to(sample.dtype))
 
     def add_noise(self, original_samples, noise, timesteps):
         ac = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)

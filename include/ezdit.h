@@ -149,6 +149,13 @@ typedef struct {
     float sigma;       /* eta * sqrt(variance) */
 } ezdit_ddim_coef;
 
+/* ONE stand-alone CFG + guidance-rescale + DDIM update (src/inference.py:88-100 `rescale_noise_cfg` + `scheduler.step`), for
+ * callers that keep their own Python loop: dev_pred fp32 [2P][n] (rows [0,P) conditional, [P,2P) unconditional; [P][n] when
+ * guidance_scale <= 0), dev_latents fp32 [P][n] updated in place, dev_noise fp32 [P][n] for THIS step or NULL, coef by value
+ * (host), n = C*L elements per sample, dev_scratch >= P*256 floats (needed when guidance_rescale > 0).  No handle needed. */
+int ezdit_cfg_ddim_step(const float* dev_pred, float* dev_latents, const float* dev_noise, const ezdit_ddim_coef* coef,
+                        float guidance_scale, float guidance_rescale, int P, int n, float* dev_scratch, ezdit_stream stream);
+
 /* dev_latents fp32 [P,C,L] is updated in place each step; dev_noise fp32 [n_steps,P,C,L] or NULL
  * (eta == 0); coefs is a HOST array of n_steps entries (copied into the workspace);
  * guidance_scale <= 0 disables CFG (B = P, src/inference.py:94-96), otherwise B = 2P with rows

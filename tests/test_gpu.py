@@ -292,3 +292,45 @@ def test_fused_cfg_ddim_step_against_oracle_loop(lib, dev):
     # both loops call the SAME bf16 denoiser; fp32 rounding differences in CFG/DDIM (<1e-6) flip bf16 roundings inside the
     # next forward, so trajectories separate at the 1e-3 level after a dozen steps (measured 1.0e-3)
     assert rel_l2(lat.cpu().numpy(), tr[steps - 1]) < 5e-3, meta2
+
+
+# ---------------------------------------------------------------------------------------------------
+# stand-alone CFG + rescale + DDIM operator (SURVEY.md section 8b minimum export set) and the scheduler.step() that uses it
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('gs,gr,eta', [(5.0, 0.75, 1.0), (3.5, 0.0, 0.0), (0.0, 0.0, 1.0)])
+def test_cfg_ddim_step_operator_against_oracle(lib, dev, gs, gr, eta):
+    import ctypes as C
+    from ezaudio_amd import DDIMScheduler, _lib
+    from oracle.sampler import cfg_combine, rescale_noise_cfg
+    from oracle.ddim import DDIMOracle
+    P, Cc, L = 3, 128, 500
+    n = Cc * L
+    g = torch.Generator().manual_seed(5)
+    rows = 2 * P if gs > 0 else P
+    pred = torch.randn(rows, Cc, L, generator=g) * 1.3
+    lat = torch.randn(P, Cc, L, generator=g)
+    noise = torch.randn(P, Cc, L, generator=g)
+    sch = DDIMScheduler(**DIFF)
+    sch.set_timesteps(50)
+    t = int(sch.timesteps[7])
+    coef = _lib.EzditDdimCoef(*sch._coef(t, eta))
+    pd, ld, nd = pred.to(dev), lat.clone().to(dev), noise.to(dev)
+    scratch = torch.zeros(P * 256, device=dev)
+    rc = lib.ezdit_cfg_ddim_step(pd.data_ptr(), ld.data_ptr(), nd.data_ptr() if eta > 0 else None, C.byref(coef), gs, gr, P, n,
+                                 scratch.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    o = DDIMOracle(**DIFF)
+    o.set_timesteps(50)
+    if gs > 0:
+        v = cfg_combine(pred[:P].numpy(), pred[P:].numpy(), gs)
+        if gr > 0:
+            v = rescale_noise_cfg(v, pred[:P].numpy(), gr)
+    else:
+        v = pred.numpy()
+    ref = o.step(v, t, lat.numpy(), eta=eta, noise=noise.numpy() if eta > 0 else None)
+    assert rel_l2(ld.cpu().numpy(), ref) < 5e-6
+    # DDIMScheduler.step on CUDA tensors goes through the same operator (the reference's loop calls it once per step)
+    v_t = torch.from_numpy(np.asarray(v, dtype=np.float32)).to(dev)
+    out = sch.step(v_t, t, lat.to(dev), eta=eta, variance_noise=noise.to(dev) if eta > 0 else None).prev_sample
+    assert rel_l2(out.cpu().numpy(), ref) < 5e-6
