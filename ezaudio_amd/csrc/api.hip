@@ -87,6 +87,7 @@ struct ezdit_handle {
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
+    int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
@@ -702,6 +703,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         AttnArgs at;
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
         at.q_raw = nullptr; at.ld_qraw = 0; at.qn_w = nullptr; at.qn_b = nullptr; at.nkh = h->opt_attn_nkh;
+        at.xu = nullptr; at.ldu = 0; at.xw = nullptr; at.ldw = 0; at.xw_rows = 0; at.xK = 0;
         at.out = h->buf<bf16_t>("ao"); at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
@@ -726,19 +728,29 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hcur = hA;
         // ---- cross attention (blocks.py:147-151) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, tile_for(h, M, false));
+        // one prompt: the cross-attention kernel also computes its own q = LN_head(u . Wq^T) (8-wave form, Lcp % 128 == 0)
+        const bool fuse_q2 = h->opt_fuse_q2 && (long)h->B * h->H * ((h->L + 63) / 64) <= 512 && h->Lcp % 128 == 0;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = D;
         hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
         hn.qn_w = h->w<float>(bn(b, "c.qnw")); hn.qn_b = h->w<float>(bn(b, "c.qnb"));
         hn.q = h->buf<bf16_t>("q");
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
-        if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
-            at.q_raw = hn.x; at.ld_qraw = D; at.qn_w = hn.qn_w; at.qn_b = hn.qn_b;
+        at.xu = nullptr; at.nkh = h->opt_attn_nkh;
+        if (fuse_q2) {
+            const std::string wq = bn(b, "wq2");
+            at.xu = u; at.ldu = h->ldD; at.xw = h->w<bf16_t>(wq); at.ldw = h->pld(wq);
+            at.xw_rows = (int)h->params[h->pidx.at(wq)].rows_pad; at.xK = at.ldw;
+            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4;
         } else {
-            STOPCHK();
-            launch_headnorm(hn, st);
-            h->launches++;
+            gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, tile_for(h, M, false));
+            if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
+                at.q_raw = hn.x; at.ld_qraw = D; at.qn_w = hn.qn_w; at.qn_b = hn.qn_b;
+            } else {
+                STOPCHK();
+                launch_headnorm(hn, st);
+                h->launches++;
+            }
         }
         at.q = hn.q;
         at.k = h->buf<bf16_t>("kc") + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
@@ -1005,7 +1017,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
-    if (g.epi > EPI_GEGLU || g.tile > 28) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
+    if (g.epi > EPI_GEGLU || g.tile > 30) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     launch_gemm(g, (hipStream_t)stream);
     return EZDIT_OK;
@@ -1017,6 +1029,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     AttnArgs a;
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
     a.q_raw = nullptr; a.ld_qraw = 0; a.qn_w = nullptr; a.qn_b = nullptr; a.nkh = h->opt_attn_nkh;
+    a.xu = nullptr; a.ldu = 0; a.xw = nullptr; a.ldw = 0; a.xw_rows = 0; a.xK = 0;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
     launch_attention(a, (hipStream_t)stream);
@@ -1051,6 +1064,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "slab_bf16")) h->opt_slab_bf16 = value;
     else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
+    else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
     else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;

@@ -52,7 +52,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int VCH = DV * VCPR;           // 16-byte chunks of a V^T tile
     constexpr int KPT = (KCH + NT - 1) / NT, VPT = (VCH + NT - 1) / NT;
     static_assert(KPT <= 3 && VPT <= 3, "staging registers");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    // fused projection (NKH == 4): 3-deep ring of [64 rows of x | DN rows of W] K tiles, then 4 partial [64][DS] fp32 tiles
+    constexpr int DN = DV >= 96 ? 96 : 64;    // W rows staged per K tile (32-row MFMA fragments covering dh)
+    constexpr int DS = DQK;                   // columns kept of each partial
+    constexpr int PSTAGE = (64 + DN) * 128, PRING = 3 * PSTAGE;
+    constexpr int PRED = 4 * 64 * DS * 4, PQS = 64 * DQK * 2;
+    constexpr int SMEM = NKH == 4 ? (2 * BUF > PRED + PQS ? (2 * BUF > PRING ? 2 * BUF : PRING) : (PRED + PQS > PRING ? PRED + PQS : PRING)) : 2 * BUF;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,7 +75,105 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     const uint8_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
 
     bf16x8 qf[NKS];
-    if (a.q_raw) {
+    if (NKH == 4 && a.xu) {
+        if constexpr (NKH == 4) {
+            // ---- phase 1: Q_raw[64][dh] = X[64 rows][K] . W_h[dh][K]^T.  wave = (mh, kq): rows 32 mh.., k-step kq of every K tile
+            constexpr int FN = DN / 32;
+            const int mh = wave & 1, kq = wave >> 1;
+            const int rowb = b * a.Lq;
+            uint32_t aoff[1], boff[(DN * 8 + NT - 1) / NT];
+            stage_offsets<64, NT>(aoff, a.ldu, rowb + blockIdx.x * 64, rowb + a.Lq - 1, tid);
+            stage_offsets<DN, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            const char* gA = reinterpret_cast<const char*>(a.xu);
+            const char* gW = reinterpret_cast<const char*>(a.xw);
+            const int nt = a.xK / 64;
+            auto stage = [&](int t) {
+                char* dst = smem + (t % 3) * PSTAGE + wave_u * 1024;
+                stage_tile<64, NT>(gA + (long)t * 128, aoff, dst, tid);
+                stage_tile<DN, NT>(gW + (long)t * 128, boff, dst + 64 * 128, tid);
+            };
+            // loads per tile of this wave: 1 (x) + 1 or 2 (W: the second pass covers chunks [NT, DN * 8))
+            const bool two = (DN * 8 > NT) && (wave_u * 64 + NT < DN * 8);
+            stage(0);
+            if (nt > 1) stage(1);
+            f32x16 acc[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            const uint32_t fo = r32 * 128 + (((2 * kq + hi) ^ ((r32 >> 1) & 7)) << 4);
+            for (int t = 0; t < nt; ++t) {
+                if (t + 1 < nt) {   // tile t + 1 may stay in flight
+                    if (two) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                if (t + 2 < nt) stage(t + 2);
+                const char* cT = smem + (t % 3) * PSTAGE;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(cT + fo + mh * 4096);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(cT + 64 * 128 + fo + j * 4096);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[j]));
+            __syncthreads();   // the ring is dead: it becomes the reduction area
+            // lane owns row 32 mh + r32 and columns 32 j + 8 g + 4 hi + {0..3}
+            float* red = reinterpret_cast<float*>(smem);   // [kq][64][DS]
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = 32 * j + 8 * g + 4 * hi;
+                    if (col < DS)
+                        *reinterpret_cast<float4*>(red + ((kq * 64 + 32 * mh + r32) * DS + col)) =
+                            make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+                }
+            __syncthreads();
+            // ---- phase 1b: sum the 4 partials, per-head LayerNorm (attention.py:141), bf16 -> Qs[64][DQK]; 8 threads per row
+            {
+                constexpr int CP = DH / 8;   // columns per thread
+                bf16_t* qs_l = reinterpret_cast<bf16_t*>(smem + PRED);
+                const int row = tid >> 3, part = tid & 7;
+                float v[CP];
+                float s1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < CP; ++e) {
+                    const int col = part * CP + e;
+                    v[e] = red[(0 * 64 + row) * DS + col] + red[(1 * 64 + row) * DS + col] + red[(2 * 64 + row) * DS + col] +
+                           red[(3 * 64 + row) * DS + col];
+                    s1 += v[e];
+                }
+                s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+                const float mean = s1 * (1.f / DH);
+                float s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < CP; ++e) { const float d = v[e] - mean; s2 += d * d; }
+                s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+                const float rstd = rsqrtf(s2 * (1.f / DH) + 1e-5f);
+#pragma unroll
+                for (int e = 0; e < CP; ++e) {
+                    const int col = part * CP + e;
+                    qs_l[row * DQK + col] = f2bf((v[e] - mean) * rstd * a.qn_w[col] + a.qn_b[col]);
+                }
+                if (DQK > DH && part == 0)
+                    for (int col = DH; col < DQK; ++col) qs_l[row * DQK + col] = 0;
+            }
+            __syncthreads();
+            {
+                const bf16_t* qs_l = reinterpret_cast<const bf16_t*>(smem + PRED);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qs_l + (32 * qs + r32) * DQK + 16 * ks + 8 * hi);
+            }
+            __syncthreads();   // Qs and the reduction area are dead: the K / V staging buffers may overwrite them
+        }
+    } else if (a.q_raw) {
         // lane (r32, hi) holds d = 16 ks + 8 hi + e of query row q0 + r32: the whole head sits in the lane pair (lane, lane ^ 32)
         int qr = q0 + r32;
         if (qr >= a.Lq) qr = a.Lq - 1;   // padding rows: any valid row, the result is never stored
@@ -323,6 +427,7 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
     int nkh = a.nkh;
     if (nkh != 2 && nkh != 4) nkh = (long)grid.x * grid.y * grid.z <= 512 ? 4 : 2;   // 0 = choose by grid size
     if (a.Lkp % 128) nkh = 2;
+    if (a.xu && nkh != 4) return;   // the fused projection exists in the 8-wave form only (callers check Lkp % 128 == 0)
     if (a.dh == 64) {
         if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a);

@@ -37,6 +37,39 @@ enum GemmEpi {
     EPI_GEGLU = 2     // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
 };
 
+// ---- LDS-DMA staging of a bf16 operand tile with K = 64 (one 128-byte LDS row per tile row), shared by gemm.hip and attn.hip ----
+constexpr int BK = 64;
+
+// Per-thread byte offsets of the 16-byte chunks this thread stages for one operand tile (K offset excluded): computed
+// ONCE per workgroup.  Chunk q of the tile = (row q>>3, 16-byte slot q&7); the slot is filled from global chunk
+// slot ^ ((row>>1)&7) (source-side swizzle, see header).  In the K loop a load is then  uniform base (SGPR) + this 32-bit
+// offset (VGPR): no per-load VALU address arithmetic.
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_offsets(uint32_t (&off)[(ROWS * 8 + NT - 1) / NT], int ld, int row0, int max_row, int tid) {
+#pragma unroll
+    for (int i = 0; i < (ROWS * 8 + NT - 1) / NT; ++i) {
+        const int q = i * NT + tid;
+        const int row = q >> 3;
+        const int c = q & 7;
+        int grow = row0 + row;
+        grow = grow < max_row ? grow : max_row;
+        const int gc = c ^ ((row >> 1) & 7);
+        off[i] = (uint32_t)(grow * ld + gc * 8) * 2u;
+    }
+}
+
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_tile(const char* __restrict__ gbase /* uniform, K offset applied */,
+                                           const uint32_t (&off)[(ROWS * 8 + NT - 1) / NT], char* lds_wave /* uniform */, int tid) {
+#pragma unroll
+    for (int i = 0; i < (ROWS * 8 + NT - 1) / NT; ++i) {
+        if ((ROWS * 8) % NT != 0 && i * NT + tid >= ROWS * 8) break;  // ragged last pass (768-thread configs)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off[i]),
+                                         (__attribute__((address_space(3))) void*)(lds_wave + i * NT * 16), 16, 0, 0);
+    }
+}
+
+
 struct GemmArgs {
     const bf16_t* A; int lda;   // [M][lda] bf16, row-major, K contiguous, zero padded to K_pad
     const bf16_t* W; int ldw;   // [wrows][ldw] bf16 (nn.Linear layout: out x in), rows >= N zero padded
@@ -75,6 +108,10 @@ struct AttnArgs {
     // per-head LayerNorm (attention.py:141, shared affine [dh]) is applied while the MFMA operand is built (q unused)
     const float* q_raw; int ld_qraw; const float* qn_w; const float* qn_b;
     int nkh;   // key sub-blocks (waves) per query sub-block: 2 (64-key tiles), 4 (128-key tiles, Lkp % 128 == 0), 0 = auto
+    // optional fused query PROJECTION (cross-attention, 8-wave form only): q_raw = xu[rows][K] . xw[h*dh .. +dh][K]^T is computed
+    // by the workgroup itself (bf16 MFMA, K split over 4 wave groups, reduced through LDS), then normalised as above.
+    // xu bf16 [B*Lq][ldu], xw bf16 [xw_rows][ldw] (nn.Linear layout), xK multiple of 64.  q and q_raw unused.
+    const bf16_t* xu; int ldu; const bf16_t* xw; int ldw; int xw_rows; int xK;
 };
 void launch_attention(const AttnArgs& a, hipStream_t st);
 

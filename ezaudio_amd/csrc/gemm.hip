@@ -23,37 +23,6 @@
 
 namespace {
 
-constexpr int BK = 64;
-
-// Per-thread byte offsets of the 16-byte chunks this thread stages for one operand tile (K offset excluded): computed
-// ONCE per workgroup.  Chunk q of the tile = (row q>>3, 16-byte slot q&7); the slot is filled from global chunk
-// slot ^ ((row>>1)&7) (source-side swizzle, see header).  In the K loop a load is then  uniform base (SGPR) + this 32-bit
-// offset (VGPR): no per-load VALU address arithmetic.
-template <int ROWS, int NT>
-__device__ __forceinline__ void stage_offsets(uint32_t (&off)[(ROWS * 8 + NT - 1) / NT], int ld, int row0, int max_row, int tid) {
-#pragma unroll
-    for (int i = 0; i < (ROWS * 8 + NT - 1) / NT; ++i) {
-        const int q = i * NT + tid;
-        const int row = q >> 3;
-        const int c = q & 7;
-        int grow = row0 + row;
-        grow = grow < max_row ? grow : max_row;
-        const int gc = c ^ ((row >> 1) & 7);
-        off[i] = (uint32_t)(grow * ld + gc * 8) * 2u;
-    }
-}
-
-template <int ROWS, int NT>
-__device__ __forceinline__ void stage_tile(const char* __restrict__ gbase /* uniform, K offset applied */,
-                                           const uint32_t (&off)[(ROWS * 8 + NT - 1) / NT], char* lds_wave /* uniform */, int tid) {
-#pragma unroll
-    for (int i = 0; i < (ROWS * 8 + NT - 1) / NT; ++i) {
-        if ((ROWS * 8) % NT != 0 && i * NT + tid >= ROWS * 8) break;  // ragged last pass (768-thread configs)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + off[i]),
-                                         (__attribute__((address_space(3))) void*)(lds_wave + i * NT * 16), 16, 0, 0);
-    }
-}
-
 // exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
 // fp32-rounding class and far below the bf16 rounding of the result): ~14 VALU instead of ~40 for erff -- the GEGLU
 // epilogue evaluates it 16x per lane and the kernel is instruction-issue bound.
@@ -352,6 +321,8 @@ void launch_t(const GemmArgs& a0, hipStream_t st) {
 //   26  128x128  4x4    4     128 KB
 //   27  256x128  8x2    2      96 KB  16 waves
 //   28  128x256  4x4    2      96 KB  16 waves
+//   29  128x288  2x3    3     156 KB  6 waves, wave tile 64x96: 40 % fewer LDS fragment reads than the 4x3 form
+//   30  128x288  2x3    2     104 KB
 template <int EPI>
 void launch_e(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
@@ -387,6 +358,8 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
         case 26: launch_t<128, 128, 4, 4, 4, EPI>(a, st); return;
         case 27: launch_t<256, 128, 8, 2, 2, EPI>(a, st); return;
         case 28: launch_t<128, 256, 4, 4, 2, EPI>(a, st); return;
+        case 29: launch_t<128, 288, 2, 3, 3, EPI>(a, st); return;
+        case 30: launch_t<128, 288, 2, 3, 2, EPI>(a, st); return;
         default: break;
     }
     launch_t<128, 64, 4, 1, 2, EPI>(a, st);
