@@ -1017,7 +1017,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
-    if (g.epi > EPI_GEGLU || g.tile > 30) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
+    if (g.epi > EPI_GEGLU || g.tile > 32) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     launch_gemm(g, (hipStream_t)stream);
     return EZDIT_OK;

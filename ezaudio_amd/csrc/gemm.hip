@@ -323,6 +323,8 @@ void launch_t(const GemmArgs& a0, hipStream_t st) {
 //   28  128x256  4x4    2      96 KB  16 waves
 //   29  128x288  2x3    3     156 KB  6 waves, wave tile 64x96: 40 % fewer LDS fragment reads than the 4x3 form
 //   30  128x288  2x3    2     104 KB
+//   31  128x192  4x2    3     120 KB  8 waves, wave tile 32x96: N = 1152 -> 6 x 8 = 48 tiles, split-K 5 fills 240 CUs
+//   32  128x192  4x2    2      80 KB
 template <int EPI>
 void launch_e(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
@@ -360,6 +362,8 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
         case 28: launch_t<128, 256, 4, 4, 2, EPI>(a, st); return;
         case 29: launch_t<128, 288, 2, 3, 3, EPI>(a, st); return;
         case 30: launch_t<128, 288, 2, 3, 2, EPI>(a, st); return;
+        case 31: launch_t<128, 192, 4, 2, 3, EPI>(a, st); return;
+        case 32: launch_t<128, 192, 4, 2, 2, EPI>(a, st); return;
         default: break;
     }
     launch_t<128, 64, 4, 1, 2, EPI>(a, st);

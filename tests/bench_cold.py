@@ -19,7 +19,7 @@ NAMES = {0: '128x128 2x2 r4', 1: '128x64 2x2 r3', 2: '128x128 2x2 r2', 3: '128x6
          6: '128x64 4x1 r2', 7: '128x128 4x2 r2', 8: '256x128 r2', 9: '128x128 4x2 r3', 12: '128x288 r2', 13: '128x288 r3',
          14: '128x64 4x1 r3', 15: '128x64 4x1 r4', 16: '64x64 r4', 17: '64x128 r3', 18: '128x64 4x1 r6', 19: '64x64 r8',
          20: '128x64 4x1 r5', 21: '64x64 r5', 22: '128x128 16w r3', 23: '128x128 16w r2', 24: '128x64 8w r3', 25: '128x64 8w r4',
-         26: '128x128 16w r4', 27: '256x128 16w r2', 28: '128x256 16w r2', 29: '128x288 6w r3', 30: '128x288 6w r2'}
+         26: '128x128 16w r4', 27: '256x128 16w r2', 28: '128x256 16w r2', 29: '128x288 6w r3', 30: '128x288 6w r2', 31: '128x192 8w r3', 32: '128x192 8w r2'}
 
 
 def run(name, configs, iters=192, pad=0):
@@ -71,8 +71,8 @@ def run(name, configs, iters=192, pad=0):
 which = [a for a in sys.argv[1:] if not a.startswith('pad=') and a != 'warm'] or ['proj', 'mlpout', 'qkv', 'q2', 'skip', 'geglu']
 pads = [int(a[4:]) for a in sys.argv[1:] if a.startswith('pad=')] or [0]
 W16 = [(22, 1), (22, 2), (22, 3), (23, 2), (23, 3), (26, 3), (26, 2), (24, 1), (24, 2), (25, 1), (25, 2), (24, 3)]
-SHORT = {'proj': [(5, 2), (9, 3), (4, 3), (15, 1)] + W16, 'skip': [(5, 2), (9, 3), (4, 3)] + W16 + [(22, 4), (26, 4)],
-         'mlpout': [(5, 4), (9, 3), (4, 3)] + W16 + [(22, 4), (26, 4), (27, 6), (27, 4)],
+SHORT = {'proj': [(9, 3), (31, 3), (31, 4), (31, 5), (32, 4), (32, 5)], 'xproj': [(5, 2), (9, 3), (4, 3), (15, 1)] + W16, 'skip': [(9, 3), (31, 4), (31, 5), (31, 3), (32, 5)], 'xskip': [(5, 2), (9, 3), (4, 3)] + W16 + [(22, 4), (26, 4)],
+         'mlpout': [(9, 3), (31, 4), (31, 5), (31, 6), (32, 5), (31, 3)], 'xmlpout': [(5, 4), (9, 3), (4, 3)] + W16 + [(22, 4), (26, 4), (27, 6), (27, 4)],
          'qkv': [(14, 1), (9, 1), (22, 1), (23, 1), (26, 1), (24, 1), (25, 1), (27, 1), (28, 1)], 'q2': [(14, 1), (15, 1), (22, 1), (26, 1), (24, 1), (25, 1)],
          'geglu': [(12, 1), (13, 1), (29, 1), (30, 1), (9, 1)]}
 for w in which:
