@@ -87,6 +87,7 @@ struct ezdit_handle {
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
+    int opt_wt = 0;                                                                       // write-through (sc1) output stores
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
@@ -343,6 +344,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.debug = 0;
     g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h->opt_xcd_map;
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
+    g.wt = h->opt_wt;
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
         g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
@@ -643,7 +645,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         r.skip = skip; r.cn = cnp;
         r.u = lg ? u : nullptr; r.ld_u = ld_u;
         r.M = M; r.D = D; r.L = h->L;
-        r.cur_step = cur; r.row_slot = row_slot;
+        r.cur_step = cur; r.row_slot = row_slot; r.wt = h->opt_wt;
         launch_row(r, st);
         h->launches++;
     };
@@ -1013,7 +1015,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0;
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
@@ -1065,6 +1067,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
+    else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
     else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;

@@ -22,6 +22,18 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// write-through stores (sc1): the line does not stay dirty in this XCD's L2, so the end-of-kernel write-back that the next
+// kernel's launch waits for has nothing left to flush (every kernel here is consumed by all XCDs of the next one)
+__device__ __forceinline__ void st16_wt(void* p, float4 v) {
+    f32x4 x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ void st8_wt(void* p, uint2 v) {
+    u32x2_t x = {v.x, v.y};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -93,6 +105,7 @@ struct GemmArgs {
     // (hardware deals workgroups to XCDs round-robin), so each XCD's private 4 MB L2 sees only its box's slice of A and W.
     // Filled by launch_gemm (xcd_map: 0 = legacy 1 x 8 x 1, 1 = smallest per-XCD footprint).
     int xcd_map; int pm, pn, pz, bm, bn, bz;
+    int wt;                       // output stores are write-through (sc1)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
@@ -130,6 +143,7 @@ struct RowArgs {
     bf16_t* u; int ld_u;
     int M, D, L;           // rows, width, rows per batch element
     const int* cur_step; const int* row_slot;
+    int wt;                // output stores are write-through (sc1)
 };
 void launch_row(const RowArgs& a, hipStream_t st);
 

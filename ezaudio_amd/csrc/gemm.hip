@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                         uint2 o;
                         o.x = pack_bf2(v0 * gelu_erf(g0), v1 * gelu_erf(g1));
                         o.y = pack_bf2(v2 * gelu_erf(g2), v3 * gelu_erf(g3));
-                        *reinterpret_cast<uint2*>(out + (long)row * a.ldo + oc) = o;
+                        if (a.wt) st8_wt(out + (long)row * a.ldo + oc, o); else *reinterpret_cast<uint2*>(out + (long)row * a.ldo + oc) = o;
                     }
                 }
         }
@@ -248,9 +248,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                             uint2 pk;
                             pk.x = pack_bf2(v.x, v.y);
                             pk.y = pack_bf2(v.z, v.w);
-                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + (long)z * a.slab_stride + (long)row * a.ldo + col) = pk;
+                            bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (long)z * a.slab_stride + (long)row * a.ldo + col;
+                            if (a.wt) st8_wt(dst, pk); else *reinterpret_cast<uint2*>(dst) = pk;
                         } else {
-                            *reinterpret_cast<float4*>(out + (long)row * a.ldo + col) = v;
+                            float* dst = out + (long)row * a.ldo + col;
+                            if (a.wt) st16_wt(dst, v); else *reinterpret_cast<float4*>(dst) = v;
                         }
                     }
                 }

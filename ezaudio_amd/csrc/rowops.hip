@@ -15,11 +15,11 @@ namespace {
 constexpr int RJ = 2;  // float4 chunks per thread of the 256-thread row kernel: D <= 2048
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, float d) {
+__device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, float d, int wt = 0) {
     uint2 v;
     v.x = pack_bf2(a, b);
     v.y = pack_bf2(c, d);
-    *reinterpret_cast<uint2*>(p) = v;
+    if (wt) st8_wt(p, v); else *reinterpret_cast<uint2*>(p) = v;
 }
 
 __device__ __forceinline__ float block_sum4(float v, float* red) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
                 }
             }
             x[j] = v;
-            if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)row * D + c * 4) = v;
+            if (a.h_out) { if (a.wt) st16_wt(a.h_out + (long)row * D + c * 4, v); else *reinterpret_cast<float4*>(a.h_out + (long)row * D + c * 4) = v; }
         }
     }
     if (!a.u) return;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
             if (c < nc) {
                 const float4 g = ld4(lg + c * 4), cc = ld4(lc + c * 4);
                 st_bf4(urow + c * 4, (x[j].x - mean) * rstd * g.x + cc.x, (x[j].y - mean) * rstd * g.y + cc.y,
-                       (x[j].z - mean) * rstd * g.z + cc.z, (x[j].w - mean) * rstd * g.w + cc.w);
+                       (x[j].z - mean) * rstd * g.z + cc.z, (x[j].w - mean) * rstd * g.w + cc.w, a.wt);
             }
         }
         for (int i = D + tid; i < a.ld_u; i += 256) urow[i] = 0;
