@@ -98,8 +98,8 @@ def cpu_baseline(cfg, sd, text, text_mask, uncond, uncond_mask, L, n_eval=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200, help='timed denoising steps (the 50-step sampler loop is repeated)')
+    ap.add_argument('--warmup', type=int, default=50, help='untimed steps before (hipGraph capture, clocks)')
     ap.add_argument('--size', default='xl')
     ap.add_argument('--prompts', type=int, default=1, help='prompts per GPU (each is a cond+uncond pair)')
     ap.add_argument('--ddim-steps', type=int, default=50)
@@ -249,10 +249,10 @@ def main():
         }
         if a.size == 'xl' and P == 1 and not a.controlnet and L == 500:
             # HBM-side bytes per denoising step from two separate rocprofv3 --pmc passes of this same command
-            # (profiles/r01_c_pmc_{fetch,write}_size.txt): FETCH_SIZE 5.577 GB raw, doubled per the gfx950 correction of
-            # MI355X_MICROARCH.md (16-byte/lane streaming reads are tallied at half), + WRITE_SIZE 3.22 GB (uncalibrated).
-            res['roofline']['traffic'] = 2 * 5.5773e9 + 3.22e9
-            res['roofline']['traffic_unit'] = 'bytes per step (offline PMC passes, see profiles/r01_c_*)'
+            # (profiles/r01_h_pmc_{fetch,write}_size.txt): FETCH_SIZE 4.646 GB raw, doubled per the gfx950 correction of
+            # MI355X_MICROARCH.md (16-byte/lane streaming reads are tallied at half), + WRITE_SIZE 2.486 GB (uncalibrated).
+            res['roofline']['traffic'] = 2 * 4.6464e9 + 2.4863e9
+            res['roofline']['traffic_unit'] = 'bytes per step (offline PMC passes, see profiles/r01_h_*)'
         try:
             res['roofline']['dominant_kernel'] = dominant_kernel_probe(unet, cfg, B * L, smp.stream)
         except Exception as e:  # the probe must never cost the headline number
