@@ -309,7 +309,9 @@ __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// y[s][j] = act(x[s][:] . W[j][:] + b[j]); one wave per output feature j, all n slots.
+// y[s][j] = act(x[s][:] . W[j][:] + b[j]); one wave per output feature j and per chunk of LIN_SC slots (blockIdx.y): the
+// slots of a call are the denoising timesteps (50..100), so chunking them is what fills the GPU for the small layers.
+constexpr int LIN_SC = 4;
 __global__ __launch_bounds__(256) void k_linear_f32(const float* __restrict__ x, const int* __restrict__ ts, int x_mode,
                                                     const float* __restrict__ W, const float* __restrict__ bias,
                                                     float* __restrict__ y, int n, int N, int K, int act, long y_stride) {
@@ -318,7 +320,8 @@ __global__ __launch_bounds__(256) void k_linear_f32(const float* __restrict__ x,
     if (j >= N) return;
     const float* wr = W + (long)j * K;
     const float bj = bias ? bias[j] : 0.f;
-    for (int s = 0; s < n; ++s) {
+    const int s_end = min(n, ((int)blockIdx.y + 1) * LIN_SC);
+    for (int s = blockIdx.y * LIN_SC; s < s_end; ++s) {
         float acc = 0.f;
         for (int k = lane; k < K; k += 64) {
             float xv;
@@ -543,7 +546,7 @@ void launch_final_conv(const FinalConvArgs& a, hipStream_t st) {
 
 void launch_linear_f32(const float* x, const int* ts, int x_mode, const float* W, const float* b, float* y,
                        int n, int N, int K, int act, long y_stride, hipStream_t st) {
-    hipLaunchKernelGGL(k_linear_f32, dim3((N + 3) / 4), dim3(256), 0, st, x, ts, x_mode, W, b, y, n, N, K, act, y_stride);
+    hipLaunchKernelGGL(k_linear_f32, dim3((N + 3) / 4, (n + LIN_SC - 1) / LIN_SC), dim3(256), 0, st, x, ts, x_mode, W, b, y, n, N, K, act, y_stride);
 }
 
 void launch_mod_finalize(const ModFinalizeArgs& a, hipStream_t st) {
