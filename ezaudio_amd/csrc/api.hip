@@ -731,7 +731,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // ---- cross attention (blocks.py:147-151) ----
         STOPCHK();
         // one prompt: the cross-attention kernel also computes its own q = LN_head(u . Wq^T) (8-wave form, Lcp % 128 == 0)
-        const bool fuse_q2 = h->opt_fuse_q2 && (long)h->B * h->H * ((h->L + 63) / 64) <= 512 && h->Lcp % 128 == 0;
+        const bool fuse_q2 = h->opt_fuse_q2 && ((long)h->B * h->H * ((h->L + 63) / 64) <= 512 || h->opt_fuse_q2 == 2) && h->Lcp % 128 == 0;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = D;
         hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
