@@ -87,6 +87,7 @@ struct ezdit_handle {
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
+    int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 0;                                                                       // write-through (sc1) output stores
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
@@ -320,6 +321,7 @@ struct Ctx {
     ezdit_handle* h;
     hipStream_t st;
     const FuseResid* fuse = nullptr;
+    const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
 };
 
 void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const float* bias, void* out, int ldo, int M, int N,
@@ -346,6 +348,8 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
+    memset(&g.hn, 0, sizeof g.hn);
+    if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
         g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
         g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
@@ -688,8 +692,6 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         }
         // ---- self attention (blocks.py:136-141) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32,
-             (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("qkv"); hn.ldx = 3 * D;
@@ -699,9 +701,17 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hn.rope_cos = h->buf<float>("rope_cos"); hn.rope_sin = h->buf<float>("rope_sin");
         hn.q = h->buf<bf16_t>("q"); hn.k = h->buf<bf16_t>("k"); hn.vt = h->buf<bf16_t>("vt");
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
-        STOPCHK();
-        launch_headnorm(hn, st);
-        h->launches++;
+        if (h->opt_fuse_qkv && h->dh == 72 && D % 288 == 0) {
+            // head-norm + RoPE + V^T inside the projection GEMM (64x288 tiles = 4 whole heads): no fp32 q|k|v round trip, one launch less
+            c.hn = &hn;
+            gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, nullptr, 0, M, 3 * D, EPI_QKV, 0);
+        } else {
+            gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32,
+                 (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
+            STOPCHK();
+            launch_headnorm(hn, st);
+            h->launches++;
+        }
         AttnArgs at;
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
         at.q_raw = nullptr; at.ld_qraw = 0; at.qn_w = nullptr; at.qn_b = nullptr; at.nkh = h->opt_attn_nkh;
@@ -1015,7 +1025,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0;
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
@@ -1068,6 +1078,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
+    else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
     else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;

@@ -46,7 +46,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
-    EPI_GEGLU = 2     // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
+    EPI_GEGLU = 2,    // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
+    EPI_QKV = 3       // fused q|k|v projection (head_dim 72, tile 64x288 = 4 whole heads): per-head LayerNorm + RoPE of q / k and
+                      // V -> V^T straight into the attention layouts through LDS (GemmArgs.hn); nothing is written to `out`
 };
 
 // ---- LDS-DMA staging of a bf16 operand tile with K = 64 (one 128-byte LDS row per tile row), shared by gemm.hip and attn.hip ----
@@ -82,6 +84,15 @@ __device__ __forceinline__ void stage_tile(const char* __restrict__ gbase /* uni
 }
 
 
+struct HeadNormArgs {
+    const float* x; int ldx;  // fp32 [M][ldx]; q cols [0,D), k cols [D,2D), v cols [2D,3D) (as selected)
+    int q_col, k_col, v_col;  // starting column of each part, -1 = absent
+    const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // [dh]
+    const float* rope_cos; const float* rope_sin;  // [max_len][dh/2] or null (no RoPE)
+    bf16_t* q; bf16_t* k; bf16_t* vt;  // [B][H][Lp][DQK], [B][H][Lp][DQK], [B][H][DV][Lp]
+    int B, H, L, Lp, dh;
+};
+
 struct GemmArgs {
     const bf16_t* A; int lda;   // [M][lda] bf16, row-major, K contiguous, zero padded to K_pad
     const bf16_t* W; int ldw;   // [wrows][ldw] bf16 (nn.Linear layout: out x in), rows >= N zero padded
@@ -106,6 +117,7 @@ struct GemmArgs {
     // Filled by launch_gemm (xcd_map: 0 = legacy 1 x 8 x 1, 1 = smallest per-XCD footprint).
     int xcd_map; int pm, pn, pz, bm, bn, bz;
     int wt;                       // output stores are write-through (sc1)
+    HeadNormArgs hn;              // EPI_QKV only (x / ldx / *_col unused)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
@@ -147,14 +159,6 @@ struct RowArgs {
 };
 void launch_row(const RowArgs& a, hipStream_t st);
 
-struct HeadNormArgs {
-    const float* x; int ldx;  // fp32 [M][ldx]; q cols [0,D), k cols [D,2D), v cols [2D,3D) (as selected)
-    int q_col, k_col, v_col;  // starting column of each part, -1 = absent
-    const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // [dh]
-    const float* rope_cos; const float* rope_sin;  // [max_len][dh/2] or null (no RoPE)
-    bf16_t* q; bf16_t* k; bf16_t* vt;  // [B][H][Lp][DQK], [B][H][Lp][DQK], [B][H][DV][Lp]
-    int B, H, L, Lp, dh;
-};
 void launch_headnorm(const HeadNormArgs& a, hipStream_t st);
 
 struct AssembleArgs {

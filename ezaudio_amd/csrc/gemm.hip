@@ -186,7 +186,104 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     // lane owns ONE output row (m = lane & 31) and, per register group g, FOUR CONSECUTIVE output columns
     // n = 32j + 8g + 4*(lane>>5) + {0..3}: every store is 16 bytes (fp32) or 8 bytes (bf16) per lane instead of 4.
     const int row_in = lane & 31;
-    if constexpr (EPI == EPI_GEGLU) {
+    if constexpr (EPI == EPI_QKV) {
+        // ---- fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection): the tile holds FOUR WHOLE heads
+        // of q, of k or of v (BN = 288 = 4 x 72, and D is a multiple of 288), staged through LDS so that head boundaries
+        // need not coincide with MFMA fragments.  attention.py:137-142, rotary.py:6-18.
+        static_assert(BN == 288 && BM == 64 && FM == 1, "EPI_QKV is built for the 64x288 tile");
+        constexpr int DH = 72, DQK = 80, DV = 96, PITCH = BN + 4;
+        float* tile = reinterpret_cast<float*>(smem);            // [BM][PITCH] fp32, reuses the ring
+        static_assert(BM * PITCH * 4 <= NS * STAGE_BYTES, "epilogue tile must fit the ring");
+        __syncthreads();                                          // every wave is done with the last K tile
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * TN + j * 32 + 8 * g + 4 * hi;
+                *reinterpret_cast<float4*>(tile + (wm * TM + row_in) * PITCH + col) =
+                    make_float4(acc[0][j][4 * g], acc[0][j][4 * g + 1], acc[0][j][4 * g + 2], acc[0][j][4 * g + 3]);
+            }
+        __syncthreads();
+        const HeadNormArgs& hn = a.hn;
+        const int D = hn.H * DH;
+        const int part = col0 / D;                 // 0 q, 1 k, 2 v
+        const int head0 = (col0 % D) / DH;         // first of the 4 heads of this tile
+        if (part < 2) {
+            // 4 lanes per (row, head): each owns 18 contiguous channels; LN via two xor-shuffles, RoPE partner (i +- 36) in lane ^ 2
+            constexpr int E = DH / 4;
+            const float* w = part == 0 ? hn.qn_w : hn.kn_w;
+            const float* bb = part == 0 ? hn.qn_b : hn.kn_b;
+            bf16_t* dstbase = part == 0 ? hn.q : hn.k;
+            for (int it = tid; it < BM * 4 * 4; it += NT) {
+                const int sub = it & 3, hh = (it >> 2) & 3, r = it >> 4;
+                const int m = row0 + r;
+                const bool ok = m < a.M;
+                const int mm = ok ? m : a.M - 1;
+                const int b = mm / hn.L, l = mm % hn.L;
+                const float* src = tile + r * PITCH + hh * DH + sub * E;
+                float v[E];
+#pragma unroll
+                for (int i = 0; i < E / 2; ++i) {
+                    const float2 t2 = *reinterpret_cast<const float2*>(src + 2 * i);
+                    v[2 * i] = t2.x; v[2 * i + 1] = t2.y;
+                }
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < E; ++i) s1 += v[i];
+                s1 += __shfl_xor(s1, 1, 64);
+                s1 += __shfl_xor(s1, 2, 64);
+                const float mean = s1 * (1.f / DH);
+                float q2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < E; ++i) { const float d = v[i] - mean; q2 += d * d; }
+                q2 += __shfl_xor(q2, 1, 64);
+                q2 += __shfl_xor(q2, 2, 64);
+                const float rstd = rsqrtf(q2 * (1.f / DH) + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < E; ++i) v[i] = (v[i] - mean) * rstd * w[sub * E + i] + bb[sub * E + i];
+                if (hn.rope_cos) {
+                    const float* cs = hn.rope_cos + (long)l * (DH / 2) + (sub & 1) * E;
+                    const float* sn = hn.rope_sin + (long)l * (DH / 2) + (sub & 1) * E;
+                    const float sign = (sub & 2) ? 1.f : -1.f;
+#pragma unroll
+                    for (int i = 0; i < E; ++i) {
+                        const float other = __shfl_xor(v[i], 2, 64);
+                        v[i] = v[i] * cs[i] + sign * other * sn[i];
+                    }
+                }
+                if (ok) {
+                    bf16_t* dst = dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + sub * E;
+#pragma unroll
+                    for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
+                }
+            }
+        } else {
+            // V^T[b][h][d][l]: consecutive lanes take consecutive ROW PAIRS (l, l + 1) of one channel d -> contiguous 4-byte stores
+            // (row0, L and Lp are even, so a pair never straddles a batch element and is 4-byte aligned)
+            if ((hn.L & 1) == 0) {
+                for (int it = tid; it < (BM / 2) * BN; it += NT) {
+                    const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * 72 + d
+                    const int m = row0 + r;
+                    if (m < a.M) {
+                        const int b = m / hn.L, l = m % hn.L;
+                        const int hh = cc / DH, d = cc % DH;
+                        *reinterpret_cast<uint32_t*>(hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l) =
+                            pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
+                    }
+                }
+            } else {
+                for (int it = tid; it < BM * BN; it += NT) {
+                    const int r = it % BM, cc = it / BM;
+                    const int m = row0 + r;
+                    if (m < a.M) {
+                        const int b = m / hn.L, l = m % hn.L;
+                        const int hh = cc / DH, d = cc % DH;
+                        hn.vt[(((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l] = f2bf(tile[r * PITCH + cc]);
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_GEGLU) {
         // W rows are interleaved in groups of 8 (8 value rows, then their 8 gate rows): in the C layout above the
         // value of inner index c sits in register group g (even) and its gate in group g + 1 of the SAME lane.
         bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
@@ -374,6 +471,7 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
+    if (a.epi == EPI_QKV) { launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st); return; }   // the only tile that holds whole heads
     if (a.epi == EPI_GEGLU) launch_e<EPI_GEGLU>(a, st);
     else if (a.epi == EPI_PARTIAL) launch_e<EPI_PARTIAL>(a, st);
     else launch_e<EPI_F32>(a, st);

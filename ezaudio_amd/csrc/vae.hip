@@ -12,6 +12,7 @@
 // The layer sequence itself is host code (ezaudio_amd/vae.py): it runs once per call, not per denoising step.
 #include "../../include/ezdit.h"
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -102,7 +103,7 @@ int ezvae_gemm(const void* A, int lda, const void* W, int ldw, int wrows, const 
     GemmArgs g;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = wrows; g.bias = bias;
     g.out = out; g.ldo = ldo; g.slab_stride = 0; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_F32; g.tile = tile;
-    g.debug = 0; g.conv_cpb = conv_cpb; g.conv_tap_bytes = conv_tap_bytes; g.resid = resid; g.ldr = ldr; g.xcd_map = 1; g.part_bf16 = 0; g.wt = 0;
+    g.debug = 0; g.conv_cpb = conv_cpb; g.conv_tap_bytes = conv_tap_bytes; g.resid = resid; g.ldr = ldr; g.xcd_map = 1; g.part_bf16 = 0; g.wt = 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     launch_gemm(g, (hipStream_t)stream);
     return EZDIT_OK;
