@@ -701,8 +701,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hn.rope_cos = h->buf<float>("rope_cos"); hn.rope_sin = h->buf<float>("rope_sin");
         hn.q = h->buf<bf16_t>("q"); hn.k = h->buf<bf16_t>("k"); hn.vt = h->buf<bf16_t>("vt");
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
-        if (h->opt_fuse_qkv && h->dh == 72 && D % 288 == 0) {
-            // head-norm + RoPE + V^T inside the projection GEMM (64x288 tiles = 4 whole heads): no fp32 q|k|v round trip, one launch less
+        if (h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64) && D % (4 * h->dh) == 0) {
+            // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
             c.hn = &hn;
             gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, nullptr, 0, M, 3 * D, EPI_QKV, 0);
         } else {

@@ -47,7 +47,7 @@ enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
     EPI_GEGLU = 2,    // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
-    EPI_QKV = 3       // fused q|k|v projection (head_dim 72, tile 64x288 = 4 whole heads): per-head LayerNorm + RoPE of q / k and
+    EPI_QKV = 3       // fused q|k|v projection (tile 64 x 4 whole heads: 64x288 for head_dim 72, 64x256 for 64): per-head LayerNorm + RoPE of q / k and
                       // V -> V^T straight into the attention layouts through LDS (GemmArgs.hn); nothing is written to `out`
 };
 

@@ -188,10 +188,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int row_in = lane & 31;
     if constexpr (EPI == EPI_QKV) {
         // ---- fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection): the tile holds FOUR WHOLE heads
-        // of q, of k or of v (BN = 288 = 4 x 72, and D is a multiple of 288), staged through LDS so that head boundaries
+        // of q, of k or of v (BN = 4 x head_dim, and D is a multiple of BN), staged through LDS so that head boundaries
         // need not coincide with MFMA fragments.  attention.py:137-142, rotary.py:6-18.
-        static_assert(BN == 288 && BM == 64 && FM == 1, "EPI_QKV is built for the 64x288 tile");
-        constexpr int DH = 72, DQK = 80, DV = 96, PITCH = BN + 4;
+        static_assert((BN == 288 || BN == 256) && BM == 64 && FM == 1, "EPI_QKV is built for 64 x (4 heads) tiles");
+        constexpr int DH = BN / 4, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
         float* tile = reinterpret_cast<float*>(smem);            // [BM][PITCH] fp32, reuses the ring
         static_assert(BM * PITCH * 4 <= NS * STAGE_BYTES, "epilogue tile must fit the ring");
         __syncthreads();                                          // every wave is done with the last K tile
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         const int part = col0 / D;                 // 0 q, 1 k, 2 v
         const int head0 = (col0 % D) / DH;         // first of the 4 heads of this tile
         if (part < 2) {
-            // 4 lanes per (row, head): each owns 18 contiguous channels; LN via two xor-shuffles, RoPE partner (i +- 36) in lane ^ 2
+            // 4 lanes per (row, head): each owns DH / 4 contiguous channels; LN via two xor-shuffles, RoPE partner (i +- DH/2) in lane ^ 2
             constexpr int E = DH / 4;
             const float* w = part == 0 ? hn.qn_w : hn.kn_w;
             const float* bb = part == 0 ? hn.qn_b : hn.kn_b;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             // (row0, L and Lp are even, so a pair never straddles a batch element and is 4-byte aligned)
             if ((hn.L & 1) == 0) {
                 for (int it = tid; it < (BM / 2) * BN; it += NT) {
-                    const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * 72 + d
+                    const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * DH + d
                     const int m = row0 + r;
                     if (m < a.M) {
                         const int b = m / hn.L, l = m % hn.L;
@@ -471,7 +471,11 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
-    if (a.epi == EPI_QKV) { launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st); return; }   // the only tile that holds whole heads
+    if (a.epi == EPI_QKV) {   // tiles that hold four whole heads: 64x288 (head_dim 72, 6 waves) or 64x256 (head_dim 64, 8 waves)
+        if (a.hn.dh == 72) launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
+        else launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
+        return;
+    }
     if (a.epi == EPI_GEGLU) launch_e<EPI_GEGLU>(a, st);
     else if (a.epi == EPI_PARTIAL) launch_e<EPI_PARTIAL>(a, st);
     else launch_e<EPI_F32>(a, st);
