@@ -87,6 +87,7 @@ struct ezdit_handle {
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
+    int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 0;                                                                       // write-through (sc1) output stores
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
@@ -704,7 +705,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64) && D % (4 * h->dh) == 0) {
             // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
             c.hn = &hn;
-            gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, nullptr, 0, M, 3 * D, EPI_QKV, 0);
+            gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, nullptr, 0, M, 3 * D, EPI_QKV, h->opt_qkv_waves9);
         } else {
             gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32,
                  (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
@@ -1079,6 +1080,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
+    else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
     else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;

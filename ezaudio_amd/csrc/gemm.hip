@@ -190,19 +190,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         // ---- fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection): the tile holds FOUR WHOLE heads
         // of q, of k or of v (BN = 4 x head_dim, and D is a multiple of BN), staged through LDS so that head boundaries
         // need not coincide with MFMA fragments.  attention.py:137-142, rotary.py:6-18.
-        static_assert((BN == 288 || BN == 256) && BM == 64 && FM == 1, "EPI_QKV is built for 64 x (4 heads) tiles");
+        static_assert((BN == 288 || BN == 256) && BM == 64, "EPI_QKV is built for 64 x (4 heads) tiles");
         constexpr int DH = BN / 4, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
         float* tile = reinterpret_cast<float*>(smem);            // [BM][PITCH] fp32, reuses the ring
         static_assert(BM * PITCH * 4 <= NS * STAGE_BYTES, "epilogue tile must fit the ring");
         __syncthreads();                                          // every wave is done with the last K tile
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = wn * TN + j * 32 + 8 * g + 4 * hi;
-                *reinterpret_cast<float4*>(tile + (wm * TM + row_in) * PITCH + col) =
-                    make_float4(acc[0][j][4 * g], acc[0][j][4 * g + 1], acc[0][j][4 * g + 2], acc[0][j][4 * g + 3]);
-            }
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = wn * TN + j * 32 + 8 * g + 4 * hi;
+                    *reinterpret_cast<float4*>(tile + (wm * TM + i * 32 + row_in) * PITCH + col) =
+                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                }
         __syncthreads();
         const HeadNormArgs& hn = a.hn;
         const int D = hn.H * DH;
@@ -472,7 +474,7 @@ void launch_e(const GemmArgs& a, hipStream_t st) {
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.epi == EPI_QKV) {   // tiles that hold four whole heads: 64x288 (head_dim 72, 6 waves) or 64x256 (head_dim 64, 8 waves)
-        if (a.hn.dh == 72) launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
+        if (a.hn.dh == 72) { if (a.tile == 1) launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st); else launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st); }
         else launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
         return;
     }

@@ -60,7 +60,7 @@ for name, vals in sweeps:
             ok = bool(torch.isfinite(smp.latents).all())
         except Exception as e:  # noqa: BLE001
             ms, ok = float('nan'), repr(e)
-        print(f'{name}={v}: {ms:.3f} ms/step finite={ok}', flush=True)
+        print(f'{name}={v}: {ms:.3f} ms/step finite={ok} |latents|={float(smp.latents.abs().mean()):.6f}', flush=True)
     setopt(name, vals[0])       # first value listed is the one to restore (list the default first)
 
 for combo in combos:
