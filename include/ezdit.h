@@ -201,8 +201,14 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t
 int ezdit_last_launch_count(const ezdit_handle* h);
 /* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
 int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
-/* tuning knobs (A/B measurements): "prefetch" 0/1 (Infinity-Cache weight prefetch on a side stream),
- * "geglu_tile" (GEMM tile configuration id for the GEGLU GEMM, -1 = heuristic). */
+/* Tuning / A-B knobs (tests/ab_sweep.py flips them on a live sampler; a captured graph is dropped and re-captured).  Defaults
+ * are the measured best on MI355X; none changes results beyond fp rounding.  Unknown names return EZDIT_E_INVALID.
+ *   GEMM tile ids (csrc/gemm.hip table): tile_partial, tile_f32, tile_qkv, tile_p18 / tile_p36 / tile_p72 (per K depth),
+ *     geglu_tile, and for > 2048 rows tile_partial_big, tile_f32_big, geglu_big; split-K: split18 / split36 / split72, split_big
+ *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1 (write-through stores)
+ *   fuse_qkv 0/1 (head-norm + RoPE + V^T in the QKV GEMM epilogue), qkv_waves9 0/1, fuse_q2 0/1/2 (cross-attention computes its
+ *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
+ *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 
 #ifdef __cplusplus
