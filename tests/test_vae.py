@@ -277,3 +277,46 @@ def test_public_api_text_to_audio_and_editing_end_to_end(tmp_path, monkeypatch):
     keep = np.ones(len(src), bool)
     keep[round(0.2 * 24000):round(0.6 * 24000)] = False
     assert np.array_equal(edited[keep], (src / (np.abs(src).max() + 1e-9))[keep])      # outside the re-synthesised chunk: untouched
+
+
+@pytest.mark.gpu
+def test_public_api_controlnet_text_plus_energy_to_audio(tmp_path, monkeypatch):
+    """api/controlnet.py:113-160 end to end: reference recording -> energy curve -> ControlNet + backbone sampler -> VAE -> waveform."""
+    import sys
+    import types
+    import yaml
+    import torch
+    import ezaudio_amd
+    from ezaudio_amd import api as A
+    from ezaudio_amd.config import load_yaml_with_includes
+    from oracle.controlnet import CN_DEFAULT, make_controlnet_state_dict
+    from oracle.weights import make_state_dict, model_config
+    base = os.path.join(os.path.dirname(ezaudio_amd.__file__), 'configs', 'controlnet', 'energy_l.yml')
+    params = load_yaml_with_includes(base)
+    cfg = model_config('xs')
+    params['model'] = dict(cfg)
+    yml = tmp_path / 'mini_cn.yml'
+    with open(yml, 'w') as f:
+        yaml.safe_dump(params, f)
+    monkeypatch.setitem(A.controlnet_configs, 'mini_energy', {'path': str(tmp_path / 'none.pt'), 'url': '', 'config': str(yml)})
+    ae, _, _ = _mini_autoencoder()
+    sd = {k: torch.from_numpy(v) for k, v in make_state_dict(cfg, 1).items()}
+    csd = {k: torch.from_numpy(v) for k, v in make_controlnet_state_dict(cfg, CN_DEFAULT, 1).items()}
+    ez = A.EzAudio_ControlNet('mini_energy', autoencoder=ae, tokenizer=_Tok(), text_encoder=_Enc(cfg['context_dim']), state_dict=sd,
+                              controlnet_state_dict=csd)
+    ref = (0.3 * uniform_pm1('cn_ref', 24000 * 3, 9)).astype(np.float32)          # a 3 s reference recording
+    ref[24000:36000] *= 0.05                                                       # with a quiet second in the middle
+    monkeypatch.setitem(sys.modules, 'librosa', types.SimpleNamespace(load=lambda f, sr: (ref.copy(), sr)))
+    sr, audio = ez.generate_audio('a dog barking', 'unused.wav', ddim_steps=20, random_seed=3)
+    # the mini VAE up-samples 8x instead of 480x, so the 500 latent frames give 4000 samples; the API trims to len(ref) at most
+    assert sr == 24000 and audio.ndim == 1 and audio.shape[0] == 500 * 8 and np.isfinite(audio).all() and audio.std() > 0
+    sr, again = ez.generate_audio('a dog barking', 'unused.wav', ddim_steps=20, random_seed=3)
+    assert np.array_equal(audio, again)
+    # conditioning_scale 0 must remove the ControlNet's influence entirely: same result as the plain backbone sampler
+    sr, off = ez.generate_audio('a dog barking', 'unused.wav', ddim_steps=20, random_seed=3, conditioning_scale=0)
+    assert not np.array_equal(off, audio)
+    plain = A.EzAudio.__new__(A.EzAudio)
+    plain.__dict__.update(autoencoder=ez.autoencoder, unet=ez.unet, tokenizer=ez.tokenizer, text_encoder=ez.text_encoder,
+                          noise_scheduler=ez.noise_scheduler, params=ez.params, device=ez.device)
+    sr, base_audio = plain.generate_audio('a dog barking', length=10, guidance_scale=3.5, guidance_rescale=0, ddim_steps=20, random_seed=3)
+    assert rel_l2(off, base_audio) < 1e-5
