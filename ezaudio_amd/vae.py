@@ -31,6 +31,24 @@ def _fold_weight_norm(g, v):
     return (g.double() * v64 / nrm).float()
 
 
+def pack_conv_weight(w):
+    """Conv1d weight [Co, Ci, K] -> GEMM operand [Co][K * Ci] (tap-major): with token-major activations and `halo` zero rows in
+    front, out[l][co] = sum_{tap, ci} x[l + tap * dilation][ci] * W[co][tap * Ci + ci] -- K tile t of the GEMM reads the
+    activation rows shifted by (t // (Ci / 64)) * dilation (GemmArgs.conv_*).  A strided conv (k = 2s, stride s) uses the same
+    matrix on the buffer viewed as [T / s + 1][s * Ci]."""
+    co, ci, k = w.shape
+    return w.permute(0, 2, 1).reshape(co, k * ci).contiguous()
+
+
+def pack_conv_transpose_weight(w, s):
+    """ConvTranspose1d weight [Ci, Co, 2s] (stride s, padding ceil(s / 2)) -> GEMM operand [s * Co][2 * Ci]:
+    out[q][r * Co + co] = x[q] . w[:, co, r] + x[q - 1] . w[:, co, r + s]; read as [(L + 1) s][Co] and shifted by the padding
+    this IS the up-sampled sequence."""
+    ci, co, k = w.shape
+    assert k == 2 * s
+    return w.reshape(ci, co, 2, s).permute(3, 1, 2, 0).reshape(s * co, 2 * ci).contiguous()
+
+
 class _OobleckNet:
     """Buffers, launches and the ResidualUnit shared by decoder and encoder."""
 
@@ -58,8 +76,7 @@ class _OobleckNet:
             b = sd[name + '.bias'].to(self.device)
             used.add(name + '.bias')
         co, ci, k = w.shape
-        wm = w.permute(0, 2, 1).reshape(co, k * ci).contiguous()                   # [Co][tap][Ci]
-        return dict(w=wm.to(self.device, torch.bfloat16), b=b, co=co, ci=ci, k=k)
+        return dict(w=pack_conv_weight(w).to(self.device, torch.bfloat16), b=b, co=co, ci=ci, k=k)
 
     def _pack_snake(self, sd, used, name):
         used.update({name + '.alpha', name + '.beta'})
@@ -135,11 +152,8 @@ class OobleckDecoder(_OobleckNet):
             w = _fold_weight_norm(sd[name + '.weight_g'], sd[name + '.weight_v'])      # [Ci, Co, 2s]
             used.update({name + '.weight_g', name + '.weight_v', name + '.bias'})
             ci, co, k = w.shape
-            assert k == 2 * s
-            # out[q][r*Co + co] = x[q] . w[:, co, r] + x[q-1] . w[:, co, r + s]
-            wm = w.reshape(ci, co, 2, s).permute(3, 1, 2, 0).reshape(s * co, 2 * ci).contiguous()
             b = sd[name + '.bias'].repeat(s).to(self.device)
-            return dict(w=wm.to(self.device, torch.bfloat16), b=b, co=co, ci=ci, s=s)
+            return dict(w=pack_conv_transpose_weight(w, s).to(self.device, torch.bfloat16), b=b, co=co, ci=ci, s=s)
 
         n = len(self.strides)
         w = {'conv_in': self._pack_conv(sd, used, 'layers.0'), 'blocks': []}

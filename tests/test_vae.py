@@ -72,6 +72,55 @@ def test_oracle_ops_against_torch_functional():
     np.testing.assert_allclose(V.snake_beta(x, al, be), ref.numpy(), rtol=1e-5, atol=1e-6)
 
 
+def _tap_gemm(xh, W, M, K, cpb, tap_rows):
+    """numpy model of ezvae_gemm's addressing on a token-major [rows][C] buffer: K tile t (64 wide) of output row m reads
+    xh[m + (t // cpb) * tap_rows][(t % cpb) * 64 : +64]."""
+    C = xh.shape[1]
+    out = np.zeros((M, W.shape[0]), dtype=np.float64)
+    for t in range(K // 64):
+        tap, sub = divmod(t, cpb)
+        rows = np.arange(M) + tap * tap_rows
+        out += xh[rows][:, sub * 64:(sub + 1) * 64].astype(np.float64) @ W[:, t * 64:(t + 1) * 64].astype(np.float64).T
+    return out
+
+
+def test_conv_as_gemm_algebra_of_the_hip_path():
+    """The weight re-layouts and halo / tap addressing that ezaudio_amd/vae.py feeds to the GEMM, checked in numpy against
+    nn.Conv1d / ConvTranspose1d semantics (oracle ops): dilated k7, transposed k = 2s, strided k = 2s."""
+    import torch
+    from ezaudio_amd.vae import pack_conv_transpose_weight, pack_conv_weight
+    Ci, Co, L = 64, 128, 37
+    x = uniform_pm1('agx', Ci * L, 1).reshape(1, Ci, L)
+    xt = x[0].T                                                        # token-major [L][Ci]
+    for d in (1, 3, 9):
+        w = uniform_pm1(f'agw{d}', Co * Ci * 7, 2).reshape(Co, Ci, 7)
+        W = pack_conv_weight(torch.from_numpy(w)).numpy()
+        xh = np.zeros((L + 6 * d, Ci), np.float32); xh[3 * d:3 * d + L] = xt
+        got = _tap_gemm(xh, W, L, 7 * Ci, Ci // 64, d)
+        np.testing.assert_allclose(got.T[None], V.conv1d(x, w, None, padding=3 * d, dilation=d), rtol=1e-4, atol=1e-5)
+    for s in (2, 4, 6, 10):
+        wt = uniform_pm1(f'agt{s}', Ci * Co * 2 * s, 3).reshape(Ci, Co, 2 * s)
+        W = pack_conv_transpose_weight(torch.from_numpy(wt), s).numpy()
+        xh = np.zeros((L + 2, Ci), np.float32); xh[1:1 + L] = xt        # [x[-1] = 0 | x | x[L] = 0]
+        # A pointer = row of x[0]; tap 1 = the previous row (tap_rows = -1); M = L + 1 output rows
+        out = np.zeros((L + 1, s * Co))
+        for q in range(L + 1):
+            out[q] = W[:, :Ci].astype(np.float64) @ xh[1 + q] + W[:, Ci:].astype(np.float64) @ xh[q]
+        p = -(-s // 2)
+        up = out.reshape((L + 1) * s, Co)[p:p + L * s]
+        np.testing.assert_allclose(up.T[None], V.conv_transpose1d(x, wt, None, stride=s, padding=p), rtol=1e-4, atol=1e-5)
+        # strided conv (encoder): halo p in front, buffer viewed as [T / s + 1][s * Ci], plain GEMM with K = 2 s Ci
+        T = 4 * s + 3                                                  # not a multiple of the stride
+        xs = uniform_pm1(f'ags{s}', Ci * T, 4).reshape(1, Ci, T)
+        wd = uniform_pm1(f'agd{s}', Co * Ci * 2 * s, 5).reshape(Co, Ci, 2 * s)
+        Wd = pack_conv_weight(torch.from_numpy(wd)).numpy()
+        buf = np.zeros((T + 2 * p, Ci), np.float32); buf[p:p + T] = xs[0].T
+        flat = np.concatenate([buf.reshape(-1), np.zeros(s * Ci, np.float32)])
+        Lo = T // s
+        got = np.stack([Wd.astype(np.float64) @ flat[q * s * Ci:q * s * Ci + 2 * s * Ci] for q in range(Lo)])
+        np.testing.assert_allclose(got.T[None], V.conv1d(xs, wd, None, stride=s, padding=p), rtol=1e-4, atol=1e-5)
+
+
 def test_decoder_rejects_unbuilt_recipes():
     from ezaudio_amd.vae import OobleckDecoder
     for kw in (dict(use_snake=False), dict(final_tanh=True), dict(out_channels=2), dict(use_nearest_upsample=True),
