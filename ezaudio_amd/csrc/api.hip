@@ -82,7 +82,7 @@ struct ezdit_handle {
     hipStream_t pf_stream = nullptr;   // side stream of the weight prefetcher
     std::vector<hipEvent_t> pf_events;  // fork/join events (one pair per use so capture sees distinct nodes)
     int prefetch = 0;      // measured -12 % on MI355X (profiles/): the side stream disturbs the GEMMs more than warm weights help
-    // tuning knobs (M <= 2048 rows); defaults from tests/bench_cold.py + tests/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
+    // tuning knobs (M <= 2048 rows); defaults from tools/bench_cold.py + tools/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
     // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
@@ -360,8 +360,8 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const floa
     h->launches++;
 }
 
-// Tile / split-K heuristics: measured in situ on MI355X with tests/ab_sweep.py (one knob flipped on the live sampler) and
-// tests/bench_cold.py (cold weights, freshly written activations); DESIGN.md section 4 has the numbers.  Every choice can be
+// Tile / split-K heuristics: measured in situ on MI355X with tools/ab_sweep.py (one knob flipped on the live sampler) and
+// tools/bench_cold.py (cold weights, freshly written activations); DESIGN.md section 4 has the numbers.  Every choice can be
 // overridden through ezdit_set_option, which is what those harnesses do.
 int tile_for(const ezdit_handle* h, int M, bool partial) {
     if (M <= 2048) return partial ? h->opt_tile_partial : h->opt_tile_f32;

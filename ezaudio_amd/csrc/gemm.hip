@@ -415,7 +415,7 @@ void launch_t(const GemmArgs& a0, hipStream_t st) {
 //   19  64x64    2x2    8     128 KB
 //   20  128x64   4x1    5     120 KB
 //   21  64x64    2x2    5      80 KB  2 workgroups / CU
-//   22  128x128  4x4    3      96 KB  16 waves: scratch/ingest2.hip shows L2 -> LDS ingest per CU scales with the number of
+//   22  128x128  4x4    3      96 KB  16 waves: a round-1 ingest microbenchmark showed L2 -> LDS ingest per CU scales with the number of
 //   23  128x128  4x4    2      64 KB  waves issuing loads (4: 39, 8: 70, 16: 95 GB/s), not with the depth per wave
 //   24  128x64   4x2    3      72 KB  8 waves
 //   25  128x64   4x2    4      96 KB

@@ -63,7 +63,7 @@ class _OobleckNet:
         self.c_mults = [1] + list(c_mults)
         self.strides = list(strides)
         self.ratio = int(np.prod(self.strides))
-        self.tile = 6      # 128x64 tiles: best of tests/bench_vae.py at 10 s (M up to 120000, N = 128..5120)
+        self.tile = 6      # 128x64 tiles: best of tools/bench_vae.py at 10 s (M up to 120000, N = 128..5120)
         self._w = None
         self._bufs = {}
 

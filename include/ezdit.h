@@ -201,7 +201,7 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t
 int ezdit_last_launch_count(const ezdit_handle* h);
 /* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
 int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
-/* Tuning / A-B knobs (tests/ab_sweep.py flips them on a live sampler; a captured graph is dropped and re-captured).  Defaults
+/* Tuning / A-B knobs (tools/ab_sweep.py flips them on a live sampler; a captured graph is dropped and re-captured).  Defaults
  * are the measured best on MI355X; none changes results beyond fp rounding.  Unknown names return EZDIT_E_INVALID.
  *   GEMM tile ids (csrc/gemm.hip table): tile_partial, tile_f32, tile_qkv, tile_p18 / tile_p36 / tile_p72 (per K depth),
  *     geglu_tile, and for > 2048 rows tile_partial_big, tile_f32_big, geglu_big; split-K: split18 / split36 / split72, split_big

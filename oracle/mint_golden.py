@@ -54,12 +54,12 @@ def build_reference(cfg, seed):
 
 
 def mint_forward(name, size, L, Lc, timesteps, seed_w, seed_in, n_valid=(12, 1), with_gt=False,
-                 cn_skips=False, out_dir='tests/golden'):
+                 cn_skips=False, B=2, out_dir='tests/golden'):
     import torch
     from .weights import model_config, make_inputs, uniform_pm1
     cfg = model_config(size)
     m, _ = build_reference(cfg, seed_w)
-    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, n_valid=n_valid, seed=seed_in, with_gt=with_gt)
+    inp = make_inputs(cfg, B=B, L=L, Lc=Lc, n_valid=n_valid, seed=seed_in, with_gt=with_gt)
     outs = {}
     torch.set_num_threads(os.cpu_count())
     with torch.no_grad():
@@ -81,7 +81,7 @@ def mint_forward(name, size, L, Lc, timesteps, seed_w, seed_in, n_valid=(12, 1),
                             context_mask=torch.from_numpy(inp['ctx_mask']), cls_token=None, **kw)
             outs[f'pred_t{t}'] = pred.numpy().astype(np.float32)
     meta = dict(size=size, L=L, Lc=Lc, seed_w=seed_w, seed_in=seed_in, n_valid=list(n_valid),
-                with_gt=with_gt, cn_skips=cn_skips, timesteps=list(timesteps))
+                with_gt=with_gt, cn_skips=cn_skips, timesteps=list(timesteps), B=B)
     path = os.path.join(out_dir, f'dit_{name}.npz')
     np.savez(path, meta=np.array(repr(meta)), **outs)
     print('wrote', path, {k: (v.shape, float(v.std())) for k, v in outs.items()})
@@ -133,8 +133,10 @@ class _OracleScheduler:
         return types.SimpleNamespace(prev_sample=torch.from_numpy(out))
 
 
-def mint_controlnet(name, size, L, Lc, t, seed_w, seed_in, scale=1.0, out_dir='tests/golden'):
-    """Reference DiTControlNet residuals + the backbone's prediction with them (src/inference_controlnet.py:89-99)."""
+def mint_controlnet(name, size, L, Lc, t, seed_w, seed_in, scale=1.0, row_stride=1, out_dir='tests/golden'):
+    """Reference DiTControlNet residuals + the backbone's prediction with them (src/inference_controlnet.py:89-99).
+    `t` may be a list of timesteps (keys then carry a `_t<t>` suffix); `row_stride` > 1 keeps every row_stride-th token row
+    of each residual (the full set is 14 x 4.6 MB per timestep at XL width)."""
     import torch
     from .controlnet import CN_DEFAULT, make_controlnet_state_dict
     from .weights import model_config, make_inputs, uniform_pm1
@@ -155,18 +157,27 @@ def mint_controlnet(name, size, L, Lc, t, seed_w, seed_in, scale=1.0, out_dir='t
     cn.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=False)
     inp = make_inputs(cfg, B=2, L=L, Lc=Lc, n_valid=(7, 1), seed=seed_in)
     cond = (0.5 + 0.5 * uniform_pm1('in.cond', 2 * 2 * L, seed_in)).reshape(2, 1, 2 * L)
-    with torch.no_grad():
-        x257, _ = m(torch.from_numpy(inp['x'].copy()), torch.tensor(t), None, forward_model=False)
-        skips = cn(x257, torch.tensor(t), torch.from_numpy(inp['ctx']), context_mask=torch.from_numpy(inp['ctx_mask']),
-                   cls_token=None, condition=torch.from_numpy(cond), conditioning_scale=scale)
-        res = [s_.numpy().copy() for s_ in skips]
-        pred = m.model(x257, torch.tensor(t), torch.from_numpy(inp['ctx']), context_mask=torch.from_numpy(inp['ctx_mask']),
-                       cls_token=None, controlnet_skips=list(skips))
-    meta = dict(size=size, L=L, Lc=Lc, t=t, seed_w=seed_w, seed_in=seed_in, scale=scale)
+    torch.set_num_threads(os.cpu_count())
+    ts = list(t) if isinstance(t, (list, tuple)) else [t]
+    multi = isinstance(t, (list, tuple))
+    arrs = {}
+    for tt in ts:
+        sfx = f'_t{tt}' if multi else ''
+        with torch.no_grad():
+            x257, _ = m(torch.from_numpy(inp['x'].copy()), torch.tensor(tt), None, forward_model=False)
+            skips = cn(x257, torch.tensor(tt), torch.from_numpy(inp['ctx']), context_mask=torch.from_numpy(inp['ctx_mask']),
+                       cls_token=None, condition=torch.from_numpy(cond), conditioning_scale=scale)
+            res = [s_.numpy().copy() for s_ in skips]
+            pred = m.model(x257, torch.tensor(tt), torch.from_numpy(inp['ctx']), context_mask=torch.from_numpy(inp['ctx_mask']),
+                           cls_token=None, controlnet_skips=list(skips))
+        arrs['pred' + sfx] = pred.numpy().astype(np.float32)
+        for i, r in enumerate(res):
+            arrs[f'res{i}{sfx}'] = np.ascontiguousarray(r[:, ::row_stride]).astype(np.float32)
+        print('minted', name, tt, pred.shape, float(pred.std()), [round(float(r.std()), 4) for r in res], flush=True)
+    meta = dict(size=size, L=L, Lc=Lc, t=t, seed_w=seed_w, seed_in=seed_in, scale=scale, row_stride=row_stride)
     path = os.path.join(out_dir, f'{name}.npz')
-    np.savez(path, meta=np.array(repr(meta)), pred=pred.numpy().astype(np.float32),
-             **{f'res{i}': r.astype(np.float32) for i, r in enumerate(res)})
-    print('wrote', path, pred.shape, float(pred.std()), [float(r.std()) for r in res])
+    np.savez(path, meta=np.array(repr(meta)), **arrs)
+    print('wrote', path)
 
 
 DIFF = dict(num_train_timesteps=1000, beta_schedule='scaled_linear', beta_start=0.00085, beta_end=0.012,
@@ -309,6 +320,13 @@ JOBS = {
     'smp_xs':    (mint_sampler, dict(size='xs', L=96, Lc=20, steps=50, seed_w=1, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
     'smp_xs_e0': (mint_sampler, dict(size='xs', L=96, Lc=20, steps=20, seed_w=1, seed_in=22, guidance_scale=3.5, guidance_rescale=0.0, eta=0.0, with_gt=True)),
     'smp_s':     (mint_sampler, dict(size='s', L=500, Lc=100, steps=50, seed_w=1234, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
+    # BASELINE.json configs #2 / #3: the shipped L and XL models through the reference's unmodified 50-step inference() loop
+    'smp_l':     (mint_sampler, dict(size='l', L=500, Lc=100, steps=50, seed_w=1234, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
+    'smp_xl':    (mint_sampler, dict(size='xl', L=500, Lc=100, steps=50, seed_w=1234, seed_in=21, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0)),
+    # config #4's per-GPU shape: 4 prompts = 8 denoiser rows (M = 4000 token rows) at XL width
+    'xl_b8':     (mint_forward, dict(size='xl', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=14, n_valid=(12, 1, 30, 1, 5, 1, 100, 1), B=8)),
+    # config #5: XL width + the energy_l.yml controlnet section, 10 s latent; residual rows sampled every 25 tokens
+    'cn_xl':     (mint_controlnet, dict(size='xl', L=500, Lc=100, t=[979, 499], seed_w=1234, seed_in=33, scale=1.0, row_stride=25)),
 }
 
 

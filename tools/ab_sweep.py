@@ -1,4 +1,4 @@
-"""In-situ A/B of the GEMM tuning knobs on the real sampler (diagnostic): python tests/ab_sweep.py [size] [prompts] name=v1,v2 ..."""
+"""In-situ A/B of the GEMM tuning knobs on the real sampler (diagnostic): python tools/ab_sweep.py [size] [prompts] name=v1,v2 ..."""
 import ctypes as C
 import sys
 import time

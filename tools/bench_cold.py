@@ -1,6 +1,6 @@
 """GEMM micro-benchmark under in-situ conditions (diagnostic): every launch reads a weight matrix that is cold in every
 cache (pool > Infinity Cache), an activation that a different kernel has just written, and follows a different kernel.
-    python tests/bench_cold.py [shape ...]      shapes: proj skip mlpout qkv geglu q2"""
+    python tools/bench_cold.py [shape ...]      shapes: proj skip mlpout qkv geglu q2"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """GPU micro-benchmarks of the kernel families through the C ABI test hooks (not a pytest).
-    python tests/bench_kernels.py gemm|attn|all"""
+    python tools/bench_kernels.py gemm|attn|all"""
 import ctypes as C
 import os
 import sys

@@ -1,4 +1,4 @@
-"""VAE decoder / encoder timing on the GPU (diagnostic, not a test): python tests/bench_vae.py [L]"""
+"""VAE decoder / encoder timing on the GPU (diagnostic, not a test): python tools/bench_vae.py [L]"""
 import sys
 import time
 

@@ -1,6 +1,6 @@
 """GPU diagnostic (not a pytest): stage-by-stage comparison of the HIP forward against the numpy oracle's
 taps for a small config, using the ezdit_debug_stop_after hook.  Prints rel-L2 per stage so one gpurun call
-localises a wrong kernel.   python tests/diag_forward.py [xs|xs64|s|s64] [L]"""
+localises a wrong kernel.   python tools/diag_forward.py [xs|xs64|s|s64] [L]"""
 import ctypes as C
 import os
 import sys

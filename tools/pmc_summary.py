@@ -1,4 +1,4 @@
-"""Sum rocprofv3 --pmc counter_collection CSVs per kernel name.  python scripts/pmc_summary.py <csv> [steps]"""
+"""Sum rocprofv3 --pmc counter_collection CSVs per kernel name.  python tools/pmc_summary.py <csv> [steps]"""
 import collections
 import csv
 import re

@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per kernel name x grid: calls, total, avg, % of GPU time.
-    python scripts/rocpd_summary.py gpurun_out/prof/r1_results.db [> profiles/...txt]"""
+    python tools/rocpd_summary.py gpurun_out/prof/r1_results.db [> profiles/...txt]"""
 import re
 import sqlite3
 import sys
