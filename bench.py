@@ -5,14 +5,20 @@
 One "step" = one pass of the hot path: CFG denoiser evaluation (cond + uncond rows) + CFG combine +
 guidance rescale + DDIM update for every prompt of the batch.  Weights are random-init of
 the named architecture, inputs are synthetic T5 embeddings and seeded noise (no network here).
-N > 1: launched by torch.distributed.run, one rank per GPU; prompts are sharded (weak scaling: `--prompts`
-per GPU), there is no collective inside the step loop, and finished latents are all-gathered once over
-RCCL at the end of the timed region.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU over RCCL (torch.distributed backend "nccl").  Either launch it under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in the environment) or just
+call `python bench.py --gpus N`: without a launcher environment the script re-executes itself under
+torch.distributed.run on 127.0.0.1 with a free port.  Prompts are sharded (weak scaling: `--prompts` per GPU), there is
+no collective inside the step loop, and finished latents are all-gathered once at the end of the timed region.
+Single-prompt N > 1 is therefore N independent replicas + one gather (no CFG-split mode exists: DESIGN.md section 6.2).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -76,23 +82,74 @@ def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
                 note='back-to-back launches, includes launch gaps')
 
 
-def cpu_baseline(cfg, sd, text, text_mask, uncond, uncond_mask, L, n_eval=2):
-    """The numpy fp32 oracle (a port of the reference's CPU path) timed on this box's host cores on a bounded
-    sample: n_eval CFG denoiser evaluations of the same workload."""
-    from oracle.dit import DiTOracle
-    o = DiTOracle(cfg, {k: v.numpy() for k, v in sd.items()}, np.float32)
+def relaunch_command(n_gpus, argv, port=None):
+    """The torch.distributed.run command line `python bench.py --gpus N` turns itself into when no launcher started it."""
+    if port is None:
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n_gpus}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.join(ROOT, 'bench.py')] + list(argv)
+
+
+def host_cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cfg, sd, text, text_mask, uncond, uncond_mask, L, budget_s=20.0):
+    """The reference's CPU path -- fp32, PyTorch eager, every host core -- timed on THIS box on a bounded
+    sample of the same workload.  /root/reference does not travel to the GPU box, so the timed implementation is
+    oracle/torch_ref.py, a restatement on the same aten operators; profiles/ref_cpu_baseline.json (tools/ref_cpu_baseline.py,
+    build container) holds the unmodified reference timed next to it (ratio ~1.0) and is attached for provenance."""
+    from oracle.torch_ref import DiTTorchRef
+    torch.set_num_threads(os.cpu_count())
+    o = DiTTorchRef(cfg, {k: v for k, v in sd.items()})
     x = np.random.default_rng(0).standard_normal((2, cfg['out_chans'], L)).astype(np.float32)
     ctx = np.concatenate([text[:1], uncond[:1]], 0)
     msk = np.concatenate([text_mask[:1], uncond_mask[:1]], 0)
-    o.forward(x[:, :, :64], 499, ctx, msk)  # warm up BLAS threads
-    t0 = time.perf_counter()
-    for _ in range(n_eval):
+    o.forward(x, 499, ctx, msk)                       # warm-up (thread pool, allocator)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 25):
+        t0 = time.perf_counter()
         o.forward(x, 499, ctx, msk)
-    dt = (time.perf_counter() - t0) / n_eval
-    return dict(value=1.0 / dt, unit='steps/s', cores=os.cpu_count(), kind='port',
-                sample=f'{n_eval} CFG denoiser evaluations (B=2 rows, L={L}, Lc={ctx.shape[1]}) of the numpy fp32 oracle '
-                       f'(oracle/dit.py, multi-threaded BLAS); CFG/DDIM update excluded (negligible)',
-                seconds_per_step=dt)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    res = dict(value=1.0 / med, unit='steps/s', cores=os.cpu_count(), kind='port', cpu_model=host_cpu_model(),
+               torch_threads=torch.get_num_threads(),
+               sample=f'{len(times)} CFG denoiser evaluations (B=2 rows, L={L}, Lc={ctx.shape[1]}), median; fp32 PyTorch eager on the '
+                      f'aten operators the reference modules call (oracle/torch_ref.py); CFG/DDIM update excluded (negligible)',
+               seconds_per_step=med, min_seconds_per_step=times[0])
+    ref_json = os.path.join(ROOT, 'profiles', 'ref_cpu_baseline.json')
+    if os.path.exists(ref_json):
+        with open(ref_json) as f:
+            r = json.load(f)
+        res['reference_on_build_box'] = {'steps_per_s': r['reference']['steps_per_s'], 'cores': r['host']['cores'],
+                                         'cpu_model': r['host']['cpu_model'], 'port_time_ratio': r['port']['time_ratio_vs_reference'],
+                                         'kind': 'reference', 'source': 'profiles/ref_cpu_baseline.json (tools/ref_cpu_baseline.py)'}
+    return res
+
+
+def measured_traffic():
+    """HBM-side bytes per step from profiles/*_pmc_step.json (scripts/pmc_step.sh), only if it was measured on THIS tree's kernels."""
+    from ezaudio_amd.build import source_hash
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith('_pmc_step.json'):
+            with open(os.path.join(pdir, f)) as fh:
+                d = json.load(fh)
+            if d.get('src_hash') == source_hash():
+                best = (f, d)
+    return best
 
 
 def main():
@@ -105,6 +162,7 @@ def main():
     ap.add_argument('--ddim-steps', type=int, default=50)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-probe', action='store_true', help='skip the dominant-kernel probe (profiling passes)')
     ap.add_argument('--no-prefetch', action='store_true', help='A/B: disable the Infinity-Cache weight prefetcher')
     ap.add_argument('--geglu-tile', type=int, default=-1)
     ap.add_argument('--opt', action='append', default=[], help='name=value tuning knob passed to ezdit_set_option')
@@ -116,8 +174,11 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+        if 'RANK' not in os.environ and a.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)
+            env = dict(os.environ)
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            raise SystemExit(subprocess.call(relaunch_command(a.gpus, sys.argv[1:]), env=env))
         a.gpus = world
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -243,20 +304,25 @@ def main():
                        'prompts_per_gpu': P, 'rows_per_gpu': B, 'latent_frames': L, 'hipgraph': use_graph,
                        'kernel_launches_per_step': unet.last_launch_count},
             'loop_steps_per_s_per_gpu': steps_per_s,
+            'distributed': {'world_size': (dist.get_world_size() if dist else 1), 'backend': (dist.get_backend() if dist else None),
+                            'mode': 'prompt-sharded replicas, one all-gather of the finished latents; no collective in the step loop'},
             'roofline': {'bound': 'mfma', 'kernel': 'whole denoising step (all kernels of the DiT forward + CFG/DDIM)',
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                          'flops_per_step': fl, 'event_ms_per_step': ev_ms / a.steps, 'traffic': None},
         }
         if a.size == 'xl' and P == 1 and not a.controlnet and L == 500:
-            # HBM-side bytes per denoising step from two separate rocprofv3 --pmc passes of this same command
-            # (profiles/r01_h_pmc_{fetch,write}_size.txt): FETCH_SIZE 4.646 GB raw, doubled per the gfx950 correction of
-            # MI355X_MICROARCH.md (16-byte/lane streaming reads are tallied at half), + WRITE_SIZE 2.486 GB (uncalibrated).
-            res['roofline']['traffic'] = 2 * 4.6464e9 + 2.4863e9
-            res['roofline']['traffic_unit'] = 'bytes per step (offline PMC passes, see profiles/r01_h_*)'
-        try:
-            res['roofline']['dominant_kernel'] = dominant_kernel_probe(unet, cfg, B * L, smp.stream)
-        except Exception as e:  # the probe must never cost the headline number
-            res['roofline']['dominant_kernel'] = {'error': repr(e)}
+            mt = measured_traffic()
+            if mt is not None:   # separate rocprofv3 --pmc passes of this same command, on THIS tree's kernels (else: null)
+                res['roofline']['traffic'] = mt[1]['traffic_bytes_per_step']
+                res['roofline']['traffic_unit'] = 'HBM-side bytes per step'
+                res['roofline']['traffic_source'] = f'profiles/{mt[0]} (src_hash {mt[1]["src_hash"]}; FETCH_SIZE x2 + WRITE_SIZE)'
+                res['roofline']['traffic_over_weights'] = mt[1]['traffic_bytes_per_step'] / float(unet._blob.numel())
+                res['roofline']['mfma_busy_frac_pmc'] = mt[1].get('mfma_busy_frac')
+        if not a.no_probe:
+            try:
+                res['roofline']['dominant_kernel'] = dominant_kernel_probe(unet, cfg, B * L, smp.stream)
+            except Exception as e:  # the probe must never cost the headline number
+                res['roofline']['dominant_kernel'] = {'error': repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, sd, text.numpy(), text_mask.numpy(), uncond.numpy(), uncond_mask.numpy(), L)
         print(json.dumps(res))

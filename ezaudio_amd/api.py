@@ -46,8 +46,10 @@ class EzAudio:
             try:
                 urllib.request.urlretrieve(url, local_path, reporthook=progress_bar)
                 print(f"Downloaded checkpoint to {local_path}")
-            except Exception as e:  # the reference prints and continues; torch.load then fails
-                print(f"Error downloading checkpoint: {e}")
+            except Exception as e:
+                # the reference prints and continues (api/ezaudio.py:61-62), which only moves the failure to a confusing
+                # torch.load on a missing file: fail here, naming the URL
+                raise RuntimeError(f'could not download {url} to {local_path}: {e}') from e
         else:
             print(f"Checkpoint already exists at {local_path}")
         return local_path
@@ -82,7 +84,7 @@ class EzAudio:
         gt, gt_mask = None, None
         if text == '':
             guidance_scale = None
-            print('empyt input')
+            print('empty input')
         if randomize_seed:
             random_seed = random.randint(0, MAX_SEED)
         pred = inference(self.autoencoder, self.unet, gt, gt_mask, self.tokenizer, self.text_encoder, self.params,
@@ -99,7 +101,7 @@ class EzAudio:
         neg_text = None
         if text == '':
             guidance_scale = None
-            print('empyt input')
+            print('empty input')
         sr = self.params['autoencoder']['sr']
         latent_sr = self.params['autoencoder']['latent_sr']
         mask_end = mask_start + mask_length
@@ -143,7 +145,7 @@ class EzAudio_ControlNet(EzAudio):
         self.device = device
         config_name = controlnet_configs[model_name]['config']
         if ckpt_path is None and state_dict is None:
-            ckpt_path = self.download_ckpt(controlnet_configs['l'])
+            ckpt_path = self.download_ckpt(controlnet_configs['model'])
         if controlnet_path is None and controlnet_state_dict is None:
             controlnet_path = self.download_ckpt(controlnet_configs[model_name])
         if vae_path is None and autoencoder is None:

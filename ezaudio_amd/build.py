@@ -18,6 +18,19 @@ SOURCES = ['gemm.hip', 'attn.hip', 'rowops.hip', 'api.hip', 'vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
+def source_hash():
+    """sha256 over the kernel sources + the ABI header: profiles record it so a stale measurement is never quoted for a newer tree."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h')))
+    files.append(os.path.join(HERE, '..', 'include', 'ezdit.h'))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):

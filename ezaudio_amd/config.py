@@ -39,13 +39,13 @@ def load_yaml_with_includes(yaml_file):
         return yaml.load(f, Loader=_Loader)
 
 
-# ControlNet registry, same names as api/controlnet.py:20-27
+# ControlNet registry: same keys, paths and URLs as api/controlnet.py:20-27
 controlnet_configs = {
+    'model': {'path': 'ckpts/s3/ezaudio_s3_l.pt',
+              'url': 'https://huggingface.co/OpenSound/EzAudio/resolve/main/ckpts/s3/ezaudio_s3_l.pt'},
     'energy': {'path': 'ckpts/controlnet/s3_l_energy.pt',
-               'url': 'https://huggingface.co/OpenSound/EzAudio-ControlNet/resolve/main/s3_l_energy.pt',
+               'url': 'https://huggingface.co/OpenSound/EzAudio/resolve/main/ckpts/controlnet/s3_l_energy.pt',
                'config': os.path.join(CONFIG_DIR, 'controlnet', 'energy_l.yml')},
-    'l': {'path': 'ckpts/s3/ezaudio_s3_l.pt',
-          'url': 'https://huggingface.co/OpenSound/EzAudio/resolve/main/ckpts/s3/ezaudio_s3_l.pt'},
     'vae': configs['vae'],
 }
 

@@ -13,11 +13,10 @@
 #include <string>
 #include <vector>
 
-namespace {
+static thread_local std::string g_err;
 
-thread_local std::string g_err;
-
-int fail(int code, const char* fmt, ...) {
+// sets the thread-local message behind ezdit_last_error() and returns `code` (shared with vae.hip through common.h)
+int ez_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -26,6 +25,9 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+#define fail ez_fail
+
+namespace {
 
 #define HIPCHK(expr)                                                                            \
     do {                                                                                        \
@@ -40,6 +42,20 @@ struct Buf {  // one carved workspace region
 };
 
 }  // namespace
+
+struct WRef {   // one bf16 weight matrix of the blob, resolved once at ezdit_bind_weights
+    const bf16_t* W = nullptr; int ld = 0; int rows = 0;
+};
+struct BlkW {   // per-block parameters used on the per-step path (no string / map work inside ezdit_forward)
+    const float *bskip, *aqnw, *aqnb, *aknw, *aknb, *bo, *n2w, *n2b, *cqnw, *cqnb, *bo2, *b1, *b2, *snw, *snb, *zb;
+    WRef wskip, wqkv, wo, wq2, wo2, w1, w2, zw;
+};
+struct WsPtrs {  // workspace regions used on the per-step path, resolved once at ezdit_bind_workspace
+    int* ints; float *rope_cos, *rope_sin, *coef, *cfgpart;
+    bf16_t* ape; float *h, *skips; bf16_t* u; float* qkv; bf16_t *q, *k, *vt, *ao, *act; float *part, *y, *pred;
+    uint8_t* kmask; bf16_t *kc, *vct; float *mod, *modf;
+    float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
+};
 
 struct ezdit_handle {
     ezdit_config cfg;
@@ -75,7 +91,9 @@ struct ezdit_handle {
     bool is_cn = false;          // ControlNet variant (cfg.controlnet)
     int c0 = 0, c0m = 0, c1 = 0; // condition-embed channel counts
     ezdit_handle* cn = nullptr;  // ControlNet attached to this backbone's sampler
-    float cn_scale = 1.0f;       // conditioning_scale applied to ControlNet residuals
+    float cn_scale = 1.0f;       // conditioning_scale of the ATTACHED ControlNet (fused sampler only)
+    float fwd_cn_scale = 1.0f;   // scale ezdit_forward applies to caller-provided residuals (ezdit_set_cn_scale; default 1)
+    std::vector<ezdit_handle*> cn_users;  // backbones whose sampler has this ControlNet attached (cleared on destroy)
     const float* ext_mask_embed = nullptr;
     int geglu_tile = -1;  // tuning override (tests/bench)
     size_t step_weights_end = 0;
@@ -93,9 +111,22 @@ struct ezdit_handle {
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
+    int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
+    int opt_row_variant = 1;                                                              // row kernel: 0 = one workgroup per row, 1 = one wave per row
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
+    int steps_done = 0;  // host mirror of the device step counter (ezdit_sampler_run bounds check)
+    int device = -1;     // device that was current at ezdit_create
+    std::vector<BlkW> blk;
+    WRef w_pe, w_fin;
+    const float *b_pe = nullptr, *b_fin = nullptr, *w_mask_embed = nullptr, *w_fin_cw = nullptr, *w_fin_cb = nullptr;
+    WsPtrs p;
+    WRef wref(const std::string& name) const {
+        const ezdit_param_info_t& pi = params[pidx.at(name)];
+        WRef r; r.W = reinterpret_cast<const bf16_t*>(wblob + pi.offset); r.ld = (int)pi.ld; r.rows = (int)pi.rows_pad;
+        return r;
+    }
 
     template <typename T>
     const T* w(const std::string& name) const {
@@ -256,7 +287,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         if (out) (*out)[name] = b;
         off += (size_t)rup((long)bytes, 256);
     };
-    const long D = h->D, I = h->I, C = h->C, H = h->H;
+    const long D = h->D, C = h->C, H = h->H;
     const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 128), Lcp = rup(Lc, 128);  // attention stages 64- or 128-key tiles
     const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
     const int nblk = h->nblk;
@@ -323,41 +354,56 @@ struct Ctx {
     hipStream_t st;
     const FuseResid* fuse = nullptr;
     const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
+    // first launch failure of this call (hipGetLastError after EVERY launch: a rejected launch -- LDS limit, bad grid,
+    // unsupported fused configuration -- must surface as an error code, never as stale numbers)
+    hipError_t err = hipSuccess;
+    int rc = EZDIT_OK;
+    const char* where = nullptr;
+    void launched(const char* what, int launch_rc = 0) {
+        h->launches++;
+        if (launch_rc != 0 && rc == EZDIT_OK) { rc = launch_rc; where = what; }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess && err == hipSuccess) { err = e; where = what; }
+    }
+    bool bad() const { return err != hipSuccess || rc != EZDIT_OK; }
+    int result() const {
+        if (rc != EZDIT_OK) return fail(rc, "%s: configuration not supported by the HIP kernels", where ? where : "?");
+        if (err != hipSuccess) return fail(EZDIT_E_HIP, "launch of %s failed: %s", where ? where : "?", hipGetErrorString(err));
+        return EZDIT_OK;
+    }
 };
 
-void gemm(Ctx& c, const bf16_t* A, int lda, const std::string& wname, const float* bias, void* out, int ldo, int M, int N,
+void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, void* out, int ldo, int M, int N,
           int epi, int tile, int splitk = 1, long slab = 0) {
     ezdit_handle* h = c.h;
     GemmArgs g;
+    memset(&g, 0, sizeof g);
     g.A = A;
     g.lda = lda;
-    g.W = h->w<bf16_t>(wname);
-    g.ldw = h->pld(wname);
-    g.wrows = (int)h->params[h->pidx.at(wname)].rows_pad;
+    g.W = w.W;
+    g.ldw = w.ld;
+    g.wrows = w.rows;
     g.bias = bias;
     g.out = out;
     g.ldo = ldo;
     g.slab_stride = slab;
     g.M = M;
     g.N = N;
-    g.K = g.ldw;
+    g.K = w.ld;
     g.splitk = splitk;
     g.epi = epi;
     g.tile = tile;
-    g.debug = 0;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h->opt_xcd_map;
+    g.xcd_map = h->opt_xcd_map;
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
-    g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
-    memset(&g.hn, 0, sizeof g.hn);
+    g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
         g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
         g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
         c.fuse = nullptr;
     }
-    launch_gemm(g, c.st);
-    h->launches++;
+    c.launched("k_gemm", launch_gemm(g, c.st));
 }
 
 // Tile / split-K heuristics: measured in situ on MI355X with tools/ab_sweep.py (one knob flipped on the live sampler) and
@@ -380,9 +426,9 @@ int pick_splitk(const ezdit_handle* h, int M, int N, int K) {
 }
 
 // residual GEMM: part = A . W^T as split-K slabs (reduced by the row kernel that follows)
-int gemm_partial(Ctx& c, const bf16_t* A, int lda, const std::string& wname, int M, int N) {
+int gemm_partial(Ctx& c, const bf16_t* A, int lda, const WRef& w, int M, int N) {
     ezdit_handle* h = c.h;
-    const int K = h->pld(wname);
+    const int K = w.ld;
     const int s = pick_splitk(h, M, N, K);
     int tile = tile_for(h, M, true);
     if (M <= 2048) {
@@ -390,8 +436,47 @@ int gemm_partial(Ctx& c, const bf16_t* A, int lda, const std::string& wname, int
         const int o = nk >= 72 ? h->opt_tile_p72 : nk >= 36 ? h->opt_tile_p36 : h->opt_tile_p18;
         if (o >= 0) tile = o;
     }
-    gemm(c, A, lda, wname, nullptr, h->buf<float>("part"), h->D, M, N, EPI_PARTIAL, tile, s, (long)h->Mp * h->D);
+    gemm(c, A, lda, w, nullptr, h->p.part, h->D, M, N, EPI_PARTIAL, tile, s, (long)h->Mp * h->D);
     return s;
+}
+
+void resolve_weights(ezdit_handle* h) {
+    h->blk.assign(h->nblk, BlkW{});
+    for (int b = 0; b < h->nblk; ++b) {
+        BlkW& k = h->blk[b];
+        k.aqnw = h->w<float>(bn(b, "a.qnw")); k.aqnb = h->w<float>(bn(b, "a.qnb"));
+        k.aknw = h->w<float>(bn(b, "a.knw")); k.aknb = h->w<float>(bn(b, "a.knb"));
+        k.cqnw = h->w<float>(bn(b, "c.qnw")); k.cqnb = h->w<float>(bn(b, "c.qnb"));
+        k.bo = h->w<float>(bn(b, "bo")); k.bo2 = h->w<float>(bn(b, "bo2")); k.b2 = h->w<float>(bn(b, "b2"));
+        k.n2w = h->w<float>(bn(b, "n2w")); k.n2b = h->w<float>(bn(b, "n2b"));
+        k.b1 = h->w<float>(bn(b, "b1"));
+        k.wqkv = h->wref(bn(b, "wqkv")); k.wo = h->wref(bn(b, "wo")); k.wq2 = h->wref(bn(b, "wq2"));
+        k.wo2 = h->wref(bn(b, "wo2")); k.w1 = h->wref(bn(b, "w1")); k.w2 = h->wref(bn(b, "w2"));
+        if (!h->is_cn && b > h->nhalf) {
+            k.snw = h->w<float>(bn(b, "snw")); k.snb = h->w<float>(bn(b, "snb"));
+            k.wskip = h->wref(bn(b, "wskip")); k.bskip = h->w<float>(bn(b, "bskip"));
+        }
+        if (h->is_cn) { k.zw = h->wref(bn(b, "zw")); k.zb = h->w<float>(bn(b, "zb")); }
+    }
+    h->w_pe = h->wref("pe.w"); h->b_pe = h->w<float>("pe.b");
+    if (!h->is_cn) {
+        h->w_fin = h->wref("fin.w"); h->b_fin = h->w<float>("fin.b");
+        h->w_fin_cw = h->w<float>("fin.cw"); h->w_fin_cb = h->w<float>("fin.cb");
+        h->w_mask_embed = h->w<float>("mask_embed");
+    }
+}
+
+void resolve_workspace(ezdit_handle* h) {
+    WsPtrs& p = h->p;
+    memset(&p, 0, sizeof p);
+    p.ints = h->buf<int>("ints"); p.rope_cos = h->buf<float>("rope_cos"); p.rope_sin = h->buf<float>("rope_sin");
+    p.coef = h->buf<float>("coef"); p.cfgpart = h->buf<float>("cfgpart");
+    p.ape = h->buf<bf16_t>("ape"); p.h = h->buf<float>("h"); p.skips = h->buf<float>("skips"); p.u = h->buf<bf16_t>("u");
+    p.qkv = h->buf<float>("qkv"); p.q = h->buf<bf16_t>("q"); p.k = h->buf<bf16_t>("k"); p.vt = h->buf<bf16_t>("vt");
+    p.ao = h->buf<bf16_t>("ao"); p.act = h->buf<bf16_t>("act"); p.part = h->buf<float>("part"); p.y = h->buf<float>("y");
+    p.pred = h->buf<float>("pred"); p.kmask = h->buf<uint8_t>("kmask"); p.kc = h->buf<bf16_t>("kc"); p.vct = h->buf<bf16_t>("vct");
+    p.mod = h->buf<float>("mod"); p.modf = h->buf<float>("modf");
+    if (h->is_cn) { p.cembed = h->buf<float>("cembed"); p.cnres = h->buf<float>("cnres"); p.skipbf = h->buf<bf16_t>("skipbf"); }
 }
 
 }  // namespace
@@ -445,12 +530,24 @@ int ezdit_create(const ezdit_config* cfg, ezdit_handle** out) {
     h->ldPE = (int)rup(h->Cin, 64);
     h->ldCtx = (int)rup(h->Cctx, 64);
     build_params(h);
+    (void)hipGetDevice(&h->device);
     *out = h;
     return EZDIT_OK;
 }
 
+static void drop_graph(ezdit_handle* h) {
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+}
+
 int ezdit_destroy(ezdit_handle* h) {
     if (!h) return EZDIT_OK;
+    for (ezdit_handle* u : h->cn_users)   // a backbone must not keep a dangling pointer to this ControlNet
+        if (u->cn == h) { u->cn = nullptr; u->cn_scale = 1.0f; drop_graph(u); }
+    if (h->cn) {
+        auto& v = h->cn->cn_users;
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == h) { v.erase(v.begin() + i); break; }
+    }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (auto& e : h->pf_events) (void)hipEventDestroy(e);
@@ -472,6 +569,7 @@ int ezdit_bind_weights(ezdit_handle* h, const void* blob, size_t bytes) {
     if (bytes < h->param_bytes) return fail(EZDIT_E_INVALID, "weight blob %zu < required %zu bytes", bytes, h->param_bytes);
     h->wblob = reinterpret_cast<const char*>(blob);
     h->ctx_ready = h->ts_ready = false;
+    resolve_weights(h);
     return EZDIT_OK;
 }
 
@@ -494,6 +592,8 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     h->B = B; h->L = L; h->Lc = Lc; h->n_slots = n_slots > 0 ? n_slots : 1;
     h->M = B * L; h->Mp = (int)rup(h->M, 128); h->Lp = (int)rup(L, 128); h->Lcp = (int)rup(Lc, 128);
     h->Mc = B * Lc;
+    resolve_workspace(h);
+    h->steps_done = 0;
     h->ctx_ready = h->ts_ready = h->cond_ready = false;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
@@ -519,9 +619,9 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
     else HIPCHK(hipMemsetAsync(km, 1, Mc, c.st));
     // context_embed: Linear -> SiLU -> Linear  (udit.py:94-97)
     launch_cast_bf16(ctx, h->Cctx, h->buf<bf16_t>("ctx_bf"), h->ldCtx, Mc, h->Cctx, 0, c.st);
-    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, "ce.w1", h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
+    gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, h->wref("ce.w1"), h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
     launch_cast_bf16(h->buf<float>("c1"), D, h->buf<bf16_t>("c1b"), h->ldD, Mc, D, 1, c.st);
-    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, "ce.w2", h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
+    gemm(c, h->buf<bf16_t>("c1b"), h->ldD, h->wref("ce.w2"), h->w<float>("ce.b2"), h->buf<float>("c2"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
     for (int b = 0; b < h->nblk; ++b) {
         // norm_context (blocks.py:150) -> to_k / to_v -> head LayerNorm on k (attention.py:128-142)
         RowArgs r;
@@ -534,7 +634,7 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
         r.ld_u = h->ldD;
         r.M = Mc; r.D = D; r.L = h->Lc;
         launch_row(r, c.st);
-        gemm(c, h->buf<bf16_t>("cu"), h->ldD, bn(b, "wkv2"), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, tile_for(h, Mc, false));
+        gemm(c, h->buf<bf16_t>("cu"), h->ldD, h->wref(bn(b, "wkv2")), nullptr, h->buf<float>("ckv"), 2 * D, Mc, 2 * D, EPI_F32, tile_for(h, Mc, false));
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
         hn.x = h->buf<float>("ckv"); hn.ldx = 2 * D;
@@ -544,7 +644,9 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
         hn.vt = h->buf<bf16_t>("vct") + (size_t)b * h->B * h->H * h->DV * h->Lcp;
         hn.B = h->B; hn.H = h->H; hn.L = h->Lc; hn.Lp = h->Lcp; hn.dh = h->dh;
         launch_headnorm(hn, c.st);
+        c.launched("k_headnorm");
     }
+    if (c.bad()) return c.result();
     h->ctx_ready = true;
     return EZDIT_OK;
 }
@@ -593,6 +695,11 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
     }
     m.n = n; m.nblk = nblk; m.D = D;
     launch_mod_finalize(m, st);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(EZDIT_E_HIP, "time-path launch failed: %s", hipGetErrorString(e));
+    }
+    h->steps_done = 0;
     h->ts_ready = true;
     h->n_ts = n;
     h->per_row = per_row;
@@ -602,38 +709,43 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
 int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream) {
     if (!h || !h->ws) return fail(EZDIT_E_STATE, "bind workspace first");
     if (step < 0 || step >= h->n_slots) return fail(EZDIT_E_INVALID, "step %d out of range", step);
-    launch_set_int(h->buf<int>("ints"), step, 0, (hipStream_t)stream);
+    launch_set_int(h->p.ints, step, 0, (hipStream_t)stream);
+    h->steps_done = step;
     return EZDIT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------
+// cn_scale multiplies the ControlNet residuals `cn` (conditioning_scale, controlnet.py:313): the fused sampler passes the
+// attached ControlNet's scale, ezdit_forward passes 1 (the caller's residuals are already scaled, as DiTControlNet.forward returns them)
 static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
-                        const float* const* cn, int n_cn, float* out, hipStream_t st) {
+                        const float* const* cn, int n_cn, float cn_scale, float* out, hipStream_t st) {
     const bool cn_mode = h->is_cn;  // ControlNet: in-blocks only, then one zero-Linear per skip (controlnet.py:303-315)
     Ctx c{h, st};
+    const WsPtrs& p = h->p;
     const int D = h->D, M = h->M, nblk = h->nblk, nhalf = h->nhalf, Mp = h->Mp;
-    const int* cur = h->buf<int>("ints");
+    const int* cur = p.ints;
     const int* row_slot = h->per_row ? cur + 16 : nullptr;
-    float* hA = h->buf<float>("h");
-    float* skips = h->buf<float>("skips");
-    bf16_t* u = h->buf<bf16_t>("u");
-    float* part = h->buf<float>("part");
-    const float* mod = h->buf<float>("mod");
+    float* hA = p.h;
+    float* skips = p.skips;
+    bf16_t* u = p.u;
+    float* part = p.part;
+    const float* mod = p.mod;
     const long mod_slot = (long)nblk * 6 * D;
     h->launches = 0;
-#define STOPCHK() do { if (h->debug_stop > 0 && h->launches >= h->debug_stop) return EZDIT_OK; } while (0)
+    (void)hipGetLastError();   // a stale error of an earlier, unrelated call must not be blamed on this one
+#define STOPCHK() do { if (c.bad()) return c.result(); if (h->debug_stop > 0 && h->launches >= h->debug_stop) return EZDIT_OK; } while (0)
 
     // A4 + A5: input assembly and patch embed (Conv1d k=1 == per-token Linear)
     AssembleArgs as;
     as.x = x; as.x_rows = x_rows; as.in_ch = in_ch;
-    as.gt = gt; as.gt_mask = gt_mask; as.mask_embed = cn_mode ? h->ext_mask_embed : h->w<float>("mask_embed");
-    as.out = h->buf<bf16_t>("ape"); as.ldo = h->ldPE;
+    as.gt = gt; as.gt_mask = gt_mask; as.mask_embed = cn_mode ? h->ext_mask_embed : h->w_mask_embed;
+    as.out = p.ape; as.ldo = h->ldPE;
     as.B = h->B; as.C = h->C; as.L = h->L;
     STOPCHK();
     launch_assemble(as, st);
-    h->launches++;
+    c.launched("k_assemble");
     STOPCHK();
-    gemm(c, h->buf<bf16_t>("ape"), h->ldPE, "pe.w", h->w<float>("pe.b"), hA, D, M, D, EPI_F32, tile_for(h, M, false));
+    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, tile_for(h, M, false));
 
     const float* part_src = part;
     auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
@@ -644,22 +756,23 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         r.h_in = h_in; r.h_out = h_out;
         r.part = part_src; r.nsplit = nsplit; r.part_stride = (long)Mp * D; r.ld_part = D;
         r.part_bf16 = (part_src == part) ? h->opt_slab_bf16 : 0;
-        r.cn_scale = h->cn_scale;
+        r.cn_scale = cn_scale;
         r.bias = bias; r.gate = gate; r.gate_slot_stride = gate_stride; r.mode = mode;
         r.ln_g = lg; r.ln_c = lc; r.ln_slot_stride = ln_stride;
         r.skip = skip; r.cn = cnp;
         r.u = lg ? u : nullptr; r.ld_u = ld_u;
         r.M = M; r.D = D; r.L = h->L;
         r.cur_step = cur; r.row_slot = row_slot; r.wt = h->opt_wt;
+        r.variant = h->opt_row_variant;
         launch_row(r, st);
-        h->launches++;
+        c.launched("k_row");
     };
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
 
     // LN1 of block 0 on the patch embedding (ControlNet: x = patch_embed(x) + controlnet_pre(condition) first, :263-266)
     STOPCHK();
     if (cn_mode) {
-        part_src = h->buf<float>("cembed");
+        part_src = p.cembed;
         row(1, hA, hA, 1, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
         part_src = part;
     } else {
@@ -677,51 +790,57 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hipEvent_t ev = h->pf_events[n_fork++];
         (void)hipEventRecord(ev, st);
         (void)hipStreamWaitEvent(h->pf_stream, ev, 0);
-        launch_prefetch(h->wblob + beg, end - beg, h->buf<unsigned>("sink"), h->pf_stream);
+        launch_prefetch(h->wblob + beg, end - beg, reinterpret_cast<unsigned*>(h->buf<unsigned>("sink")), h->pf_stream);
+    };
+    auto join_prefetch = [&]() {   // mandatory inside a capture (an unjoined side stream invalidates it); cheap otherwise
+        if (!use_pf || n_fork == 0) return;
+        hipEvent_t ev = h->pf_events[n_fork++];
+        (void)hipEventRecord(ev, h->pf_stream);
+        (void)hipStreamWaitEvent(st, ev, 0);
     };
     prefetch_block(0);
     for (int b = 0; b < nblk; ++b) {
+        const BlkW& w = h->blk[b];
         const bool is_in = b < nhalf, is_out = b > nhalf;
         prefetch_block(b + 1);
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            const int s = gemm_partial(c, u, h->ld2D, bn(b, "wskip"), M, D);
+            const int s = gemm_partial(c, u, h->ld2D, w.wskip, M, D);
             STOPCHK();
-            row(2, nullptr, hA, s, h->w<float>(bn(b, "bskip")), nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
+            row(2, nullptr, hA, s, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
         // ---- self attention (blocks.py:136-141) ----
         STOPCHK();
         HeadNormArgs hn;
         memset(&hn, 0, sizeof hn);
-        hn.x = h->buf<float>("qkv"); hn.ldx = 3 * D;
+        hn.x = p.qkv; hn.ldx = 3 * D;
         hn.q_col = 0; hn.k_col = D; hn.v_col = 2 * D;
-        hn.qn_w = h->w<float>(bn(b, "a.qnw")); hn.qn_b = h->w<float>(bn(b, "a.qnb"));
-        hn.kn_w = h->w<float>(bn(b, "a.knw")); hn.kn_b = h->w<float>(bn(b, "a.knb"));
-        hn.rope_cos = h->buf<float>("rope_cos"); hn.rope_sin = h->buf<float>("rope_sin");
-        hn.q = h->buf<bf16_t>("q"); hn.k = h->buf<bf16_t>("k"); hn.vt = h->buf<bf16_t>("vt");
+        hn.qn_w = w.aqnw; hn.qn_b = w.aqnb;
+        hn.kn_w = w.aknw; hn.kn_b = w.aknb;
+        hn.rope_cos = p.rope_cos; hn.rope_sin = p.rope_sin;
+        hn.q = p.q; hn.k = p.k; hn.vt = p.vt;
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
         if (h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64) && D % (4 * h->dh) == 0) {
             // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
             c.hn = &hn;
-            gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, nullptr, 0, M, 3 * D, EPI_QKV, h->opt_qkv_waves9);
+            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, h->opt_qkv_waves9);
         } else {
-            gemm(c, u, h->ldD, bn(b, "wqkv"), nullptr, h->buf<float>("qkv"), 3 * D, M, 3 * D, EPI_F32,
+            gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32,
                  (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
             STOPCHK();
             launch_headnorm(hn, st);
-            h->launches++;
+            c.launched("k_headnorm");
         }
         AttnArgs at;
+        memset(&at, 0, sizeof at);
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
-        at.q_raw = nullptr; at.ld_qraw = 0; at.qn_w = nullptr; at.qn_b = nullptr; at.nkh = h->opt_attn_nkh;
-        at.xu = nullptr; at.ldu = 0; at.xw = nullptr; at.ldw = 0; at.xw_rows = 0; at.xK = 0;
-        at.out = h->buf<bf16_t>("ao"); at.ldo = h->ldD;
+        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd;
+        at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
-        launch_attention(at, st);
-        h->launches++;
+        c.launched("k_attn (self)", launch_attention(at, st));
         STOPCHK();
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
         int s = 0;
@@ -729,14 +848,13 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (fuse_res) {
             const FuseResid fr{hcur, D, modv(b, 2), mod_slot, cur, row_slot, h->L};
             c.fuse = &fr;
-            gemm(c, at.out, h->ldD, bn(b, "wo"), h->w<float>(bn(b, "bo")), hA, D, M, D, EPI_F32, tile_for(h, M, false));
+            gemm(c, at.out, h->ldD, w.wo, w.bo, hA, D, M, D, EPI_F32, tile_for(h, M, false));
             STOPCHK();
-            row(0, hA, nullptr, 0, nullptr, nullptr, 0, h->w<float>(bn(b, "n2w")), h->w<float>(bn(b, "n2b")), 0, nullptr, nullptr, h->ldD);
+            row(0, hA, nullptr, 0, nullptr, nullptr, 0, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         } else {
-            s = gemm_partial(c, at.out, h->ldD, bn(b, "wo"), M, D);
+            s = gemm_partial(c, at.out, h->ldD, w.wo, M, D);
             STOPCHK();
-            row(1, hcur, hA, s, h->w<float>(bn(b, "bo")), modv(b, 2), mod_slot, h->w<float>(bn(b, "n2w")), h->w<float>(bn(b, "n2b")), 0,
-                nullptr, nullptr, h->ldD);
+            row(1, hcur, hA, s, w.bo, modv(b, 2), mod_slot, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         }
         hcur = hA;
         // ---- cross attention (blocks.py:147-151) ----
@@ -744,60 +862,58 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // one prompt: the cross-attention kernel also computes its own q = LN_head(u . Wq^T) (8-wave form, Lcp % 128 == 0)
         const bool fuse_q2 = h->opt_fuse_q2 && ((long)h->B * h->H * ((h->L + 63) / 64) <= 512 || h->opt_fuse_q2 == 2) && h->Lcp % 128 == 0;
         memset(&hn, 0, sizeof hn);
-        hn.x = h->buf<float>("qkv"); hn.ldx = D;
+        hn.x = p.qkv; hn.ldx = D;
         hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
-        hn.qn_w = h->w<float>(bn(b, "c.qnw")); hn.qn_b = h->w<float>(bn(b, "c.qnb"));
-        hn.q = h->buf<bf16_t>("q");
+        hn.qn_w = w.cqnw; hn.qn_b = w.cqnb;
+        hn.q = p.q;
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
         at.xu = nullptr; at.nkh = h->opt_attn_nkh;
         if (fuse_q2) {
-            const std::string wq = bn(b, "wq2");
-            at.xu = u; at.ldu = h->ldD; at.xw = h->w<bf16_t>(wq); at.ldw = h->pld(wq);
-            at.xw_rows = (int)h->params[h->pidx.at(wq)].rows_pad; at.xK = at.ldw;
+            at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
+            at.xw_rows = w.wq2.rows; at.xK = at.ldw;
             at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4;
         } else {
-            gemm(c, u, h->ldD, bn(b, "wq2"), nullptr, h->buf<float>("qkv"), D, M, D, EPI_F32, tile_for(h, M, false));
+            gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
                 at.q_raw = hn.x; at.ld_qraw = D; at.qn_w = hn.qn_w; at.qn_b = hn.qn_b;
             } else {
                 STOPCHK();
                 launch_headnorm(hn, st);
-                h->launches++;
+                c.launched("k_headnorm");
             }
         }
         at.q = hn.q;
-        at.k = h->buf<bf16_t>("kc") + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
-        at.vt = h->buf<bf16_t>("vct") + (size_t)b * h->B * h->H * h->DV * h->Lcp;
-        at.kmask = h->buf<uint8_t>("kmask");
+        at.k = p.kc + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
+        at.vt = p.vct + (size_t)b * h->B * h->H * h->DV * h->Lcp;
+        at.kmask = p.kmask;
         at.Lk = h->Lc; at.Lkp = h->Lcp;
         STOPCHK();
-        launch_attention(at, st);
-        h->launches++;
+        c.launched("k_attn (cross)", launch_attention(at, st));
         STOPCHK();
         if (fuse_res) {
             const FuseResid fr{hA, D, nullptr, 0, nullptr, nullptr, h->L};
             c.fuse = &fr;
-            gemm(c, at.out, h->ldD, bn(b, "wo2"), h->w<float>(bn(b, "bo2")), hA, D, M, D, EPI_F32, tile_for(h, M, false));
+            gemm(c, at.out, h->ldD, w.wo2, w.bo2, hA, D, M, D, EPI_F32, tile_for(h, M, false));
             STOPCHK();
             row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         } else {
-            s = gemm_partial(c, at.out, h->ldD, bn(b, "wo2"), M, D);
+            s = gemm_partial(c, at.out, h->ldD, w.wo2, M, D);
             STOPCHK();
-            row(1, hA, hA, s, h->w<float>(bn(b, "bo2")), nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+            row(1, hA, hA, s, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         }
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
-        gemm(c, u, h->ldD, bn(b, "w1"), h->w<float>(bn(b, "b1")), h->buf<bf16_t>("act"), h->ldI, M, 2 * h->I, EPI_GEGLU,
+        gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU,
              h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 13 : h->opt_geglu_big));
         STOPCHK();
-        s = gemm_partial(c, h->buf<bf16_t>("act"), h->ldI, bn(b, "w2"), M, D);
+        s = gemm_partial(c, p.act, h->ldI, w.w2, M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
-        const float* b2 = h->w<float>(bn(b, "b2"));
+        const float* b2 = w.b2;
         if (cn_mode && b == nblk - 1) {
             STOPCHK();
             row(1, hA, skips + (size_t)b * Mp * D, s, b2, modv(b, 5), mod_slot, nullptr, nullptr, 0, nullptr, nullptr, h->ldD);
         } else if (b == nblk - 1) {
-            const float* mf = h->buf<float>("modf");
+            const float* mf = p.modf;
             STOPCHK();
             row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, mf, mf + D, 2L * D, nullptr, nullptr, h->ldD);
         } else if (b + 1 > nhalf) {
@@ -805,8 +921,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             const float* skip = skips + (size_t)(nhalf - 1 - j) * Mp * D;
             const float* cnp = (cn && n_cn > 0) ? cn[n_cn - 1 - j] : nullptr;
             STOPCHK();
-            row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, h->w<float>(bn(b + 1, "snw")), h->w<float>(bn(b + 1, "snb")), 0, skip, cnp,
-                h->ld2D);
+            row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
             STOPCHK();
@@ -817,29 +932,25 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     if (cn_mode) {
         // controlnet_skips[i] = zero_Linear_i(skip_i) (* conditioning_scale, applied by the consumer)  controlnet.py:311-313
         for (int i = 0; i < nblk; ++i) {
-            launch_cast_bf16(skips + (size_t)i * Mp * D, D, h->buf<bf16_t>("skipbf"), h->ldD, M, D, 0, st);
-            h->launches++;
-            gemm(c, h->buf<bf16_t>("skipbf"), h->ldD, bn(i, "zw"), h->w<float>(bn(i, "zb")),
-                 h->buf<float>("cnres") + (size_t)i * Mp * D, D, M, D, EPI_F32, tile_for(h, M, false));
+            launch_cast_bf16(skips + (size_t)i * Mp * D, D, p.skipbf, h->ldD, M, D, 0, st);
+            c.launched("k_cast_bf16");
+            gemm(c, p.skipbf, h->ldD, h->blk[i].zw, h->blk[i].zb, p.cnres + (size_t)i * Mp * D, D, M, D, EPI_F32, tile_for(h, M, false));
         }
-        return EZDIT_OK;
+        join_prefetch();
+        return c.result();
     }
     // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
     STOPCHK();
-    gemm(c, u, h->ldD, "fin.w", h->w<float>("fin.b"), h->buf<float>("y"), h->C, M, h->C, EPI_F32, tile_for(h, M, false));
+    gemm(c, u, h->ldD, h->w_fin, h->b_fin, p.y, h->C, M, h->C, EPI_F32, tile_for(h, M, false));
     FinalConvArgs fc;
-    fc.y = h->buf<float>("y"); fc.ldy = h->C;
-    fc.w = h->w<float>("fin.cw"); fc.b = h->w<float>("fin.cb");
+    fc.y = p.y; fc.ldy = h->C;
+    fc.w = h->w_fin_cw; fc.b = h->w_fin_cb;
     fc.out = out; fc.B = h->B; fc.C = h->C; fc.L = h->L;
     STOPCHK();
     launch_final_conv(fc, st);
-    h->launches++;
-    if (use_pf) {  // join the side stream (mandatory inside a capture; cheap otherwise)
-        hipEvent_t ev = h->pf_events[n_fork++];
-        (void)hipEventRecord(ev, h->pf_stream);
-        (void)hipStreamWaitEvent(st, ev, 0);
-    }
-    return EZDIT_OK;
+    c.launched("k_final_conv");
+    join_prefetch();
+    return c.result();
 }
 
 int ezdit_forward(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
@@ -853,7 +964,9 @@ int ezdit_forward(ezdit_handle* h, const float* x, int in_ch, int x_rows, const 
     if (in_ch == h->C && (x_rows <= 0 || h->B % x_rows)) return fail(EZDIT_E_INVALID, "x_rows %d does not divide B %d", x_rows, h->B);
     if ((gt == nullptr) != (gt_mask == nullptr)) return fail(EZDIT_E_INVALID, "gt and gt_mask must be given together");
     if (n_cn != 0 && n_cn != h->nhalf) return fail(EZDIT_E_INVALID, "n_cn %d: expected 0 or %d", n_cn, h->nhalf);
-    return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, cn_skips, n_cn, out, (hipStream_t)stream);
+    // the caller's residuals are already multiplied by conditioning_scale (DiTControlNet.forward returns them scaled,
+    // controlnet.py:313); a scale left on the handle by the fused sampler must not be applied a second time
+    return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, cn_skips, n_cn, h->fwd_cn_scale, out, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -881,6 +994,10 @@ int ezdit_prepare_condition(ezdit_handle* h, const float* cond, int Lcond, ezdit
     a.Cin = h->c1; a.cin_valid = h->c1; a.Cout = h->D; a.Lin = h->L; a.Lout = h->L; a.ksize = 1; a.stride = 1; a.pad = 0; a.act = 0;
     a.out_token_major = 1;
     launch_conv1d(a, st);
+    {
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(EZDIT_E_HIP, "condition-embed launch failed: %s", hipGetErrorString(e));
+    }
     h->cond_ready = true;
     return EZDIT_OK;
 }
@@ -895,7 +1012,7 @@ int ezdit_controlnet_forward(ezdit_handle* h, const float* x, int in_ch, int x_r
     if (in_ch == h->C && !mask_embed) return fail(EZDIT_E_INVALID, "in_ch = C needs the backbone's mask_embed");
     if (in_ch == h->C && (x_rows <= 0 || h->B % x_rows)) return fail(EZDIT_E_INVALID, "x_rows %d does not divide B %d", x_rows, h->B);
     h->ext_mask_embed = mask_embed;
-    return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, nullptr, 0, nullptr, (hipStream_t)stream);
+    return forward_impl(h, x, in_ch, x_rows, gt, gt_mask, nullptr, 0, 1.0f, nullptr, (hipStream_t)stream);
 }
 
 int ezdit_controlnet_residuals(ezdit_handle* h, const float** out, int n) {
@@ -908,6 +1025,11 @@ int ezdit_controlnet_residuals(ezdit_handle* h, const float** out, int n) {
 int ezdit_sampler_attach_controlnet(ezdit_handle* h, ezdit_handle* cn, float conditioning_scale) {
     if (!h || h->is_cn) return fail(EZDIT_E_INVALID, "first argument must be a backbone handle");
     if (cn && !cn->is_cn) return fail(EZDIT_E_INVALID, "second argument must be a ControlNet handle");
+    if (h->cn && h->cn != cn) {
+        auto& v = h->cn->cn_users;
+        for (size_t i = 0; i < v.size(); ++i) if (v[i] == h) { v.erase(v.begin() + i); break; }
+    }
+    if (cn && h->cn != cn) cn->cn_users.push_back(h);
     h->cn = cn;
     h->cn_scale = cn ? conditioning_scale : 1.0f;
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
@@ -917,7 +1039,7 @@ int ezdit_sampler_attach_controlnet(ezdit_handle* h, ezdit_handle* cn, float con
 
 int ezdit_set_cn_scale(ezdit_handle* h, float scale) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
-    h->cn_scale = scale;
+    h->fwd_cn_scale = scale;
     return EZDIT_OK;
 }
 
@@ -939,7 +1061,8 @@ int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noi
     }
     HIPCHK(hipMemcpyAsync(h->buf<float>("coef"), cf.data(), cf.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
-    launch_set_int(h->buf<int>("ints"), 0, 0, st);
+    launch_set_int(h->p.ints, 0, 0, st);
+    h->steps_done = 0;
     h->latents = latents; h->noise = noise; h->P = P; h->n_steps = n_steps;
     h->gscale = guidance_scale; h->grescale = guidance_rescale;
     h->s_gt = gt; h->s_gt_mask = gt_mask;
@@ -949,30 +1072,32 @@ int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noi
 }
 
 static int sampler_step(ezdit_handle* h, hipStream_t st) {
-    float* pred = h->buf<float>("pred");
+    float* pred = h->p.pred;
     const float* cnp[64];
     int n_cn = 0;
     if (h->cn) {  // src/inference_controlnet.py:89-99: ControlNet on the same assembled input, then the backbone with its skips
         ezdit_handle* cn = h->cn;
         if (cn->B != h->B || cn->L != h->L || cn->nhalf != h->nhalf || cn->D != h->D || !cn->ctx_ready || !cn->ts_ready || !cn->cond_ready)
             return fail(EZDIT_E_STATE, "attached ControlNet is not prepared for this shape (bind/context/timesteps/condition)");
-        cn->ext_mask_embed = h->w<float>("mask_embed");
-        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, nullptr, st);
+        cn->ext_mask_embed = h->w_mask_embed;
+        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, st);
         if (rc0) return rc0;
         n_cn = cn->nhalf;
-        for (int i = 0; i < n_cn; ++i) cnp[i] = cn->buf<float>("cnres") + (size_t)i * cn->Mp * cn->D;
+        for (int i = 0; i < n_cn; ++i) cnp[i] = cn->p.cnres + (size_t)i * cn->Mp * cn->D;
     }
-    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, pred, st);
+    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st);
     if (rc) return rc;
     CfgDdimArgs a;
     a.pred = pred; a.latents = h->latents; a.noise = h->noise;
-    a.coef = h->buf<float>("coef"); a.cur_step = h->buf<int>("ints");
+    a.coef = h->p.coef; a.cur_step = h->p.ints;
     for (float& v : a.hc) v = 0.f;
     a.guidance_scale = h->gscale; a.guidance_rescale = h->grescale;
     a.P = h->P; a.n = h->C * h->L;
-    launch_cfg_ddim(a, h->buf<float>("cfgpart"), st);
-    launch_set_int(h->buf<int>("ints"), 1, 1, st);
-    h->launches += 2;
+    a.step_inc = h->p.ints; a.done = reinterpret_cast<unsigned*>(h->p.ints + 8);
+    launch_cfg_ddim(a, h->p.cfgpart, st);   // its last kernel also advances the device step counter
+    h->launches += (h->gscale > 0.f && h->grescale > 0.f) ? 2 : 1;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of k_cfg_* failed: %s", hipGetErrorString(e));
     return EZDIT_OK;
 }
 
@@ -987,6 +1112,7 @@ int ezdit_cfg_ddim_step(const float* pred, float* latents, const float* noise, c
     a.hc[0] = coef->sa; a.hc[1] = coef->sb; a.hc[2] = coef->c_x0; a.hc[3] = coef->c_dir; a.hc[4] = coef->sigma;
     a.guidance_scale = guidance_scale; a.guidance_rescale = guidance_rescale;
     a.P = P; a.n = n;
+    a.step_inc = nullptr; a.done = nullptr;
     launch_cfg_ddim(a, scratch, (hipStream_t)stream);
     return EZDIT_OK;
 }
@@ -995,11 +1121,17 @@ int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream
     if (!h || !h->latents) return fail(EZDIT_E_STATE, "ezdit_sampler_begin first");
     if (!h->ctx_ready || !h->ts_ready) return fail(EZDIT_E_STATE, "prepare context and timesteps first");
     if (h->per_row) return fail(EZDIT_E_STATE, "sampler needs ezdit_prepare_timesteps(per_row = 0)");
+    // the device-side step counter selects the modulation slot, the DDIM coefficients and the noise slice: running past the
+    // prepared steps would index all three out of bounds
+    if (n < 0 || h->steps_done + n > h->n_steps || h->steps_done + n > h->n_ts)
+        return fail(EZDIT_E_STATE, "run of %d steps from step %d exceeds the %d prepared steps (ezdit_set_step rewinds)", n,
+                    h->steps_done, h->n_steps < h->n_ts ? h->n_steps : h->n_ts);
     hipStream_t st = (hipStream_t)stream;
     if (!use_graph) {
         for (int i = 0; i < n; ++i) {
             int rc = sampler_step(h, st);
             if (rc) return rc;
+            h->steps_done++;
         }
         return EZDIT_OK;
     }
@@ -1009,12 +1141,12 @@ int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream
         int rc = sampler_step(h, st);
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(st, &g);
-        if (rc) return rc;
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (e != hipSuccess) return fail(EZDIT_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
         h->graph = g;
         HIPCHK(hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0));
     }
-    for (int i = 0; i < n; ++i) HIPCHK(hipGraphLaunch(h->graph_exec, st));
+    for (int i = 0; i < n; ++i) { HIPCHK(hipGraphLaunch(h->graph_exec, st)); h->steps_done++; }
     return EZDIT_OK;
 }
 
@@ -1030,9 +1162,12 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
-    if (g.epi > EPI_GEGLU || g.tile > 32) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
+    if (g.epi > EPI_GEGLU || g.tile > 63) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
-    launch_gemm(g, (hipStream_t)stream);
+    (void)hipGetLastError();
+    if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "gemm variant %d not supported", variant);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of k_gemm failed: %s", hipGetErrorString(e));
     return EZDIT_OK;
 }
 
@@ -1040,12 +1175,15 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
                          int Lq, int Lk, int Lqp, int Lkp, ezdit_stream stream) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
     AttnArgs a;
+    memset(&a, 0, sizeof a);
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
-    a.q_raw = nullptr; a.ld_qraw = 0; a.qn_w = nullptr; a.qn_b = nullptr; a.nkh = h->opt_attn_nkh;
-    a.xu = nullptr; a.ldu = 0; a.xw = nullptr; a.ldw = 0; a.xw_rows = 0; a.xK = 0;
+    a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
-    launch_attention(a, (hipStream_t)stream);
+    (void)hipGetLastError();
+    if (launch_attention(a, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "attention configuration not supported");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of k_attn failed: %s", hipGetErrorString(e));
     return EZDIT_OK;
 }
 
@@ -1078,6 +1216,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
+    else if (!strcmp(name, "attn_xcd")) h->opt_attn_xcd = value;
+    else if (!strcmp(name, "row_variant")) h->opt_row_variant = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

@@ -65,8 +65,20 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     const int wave = tid >> 6;
     const int qs = wave & 1, kh = wave >> 1;   // kh in [0, NKH)
     const int r32 = lane & 31, hi = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 64 + qs * 32;
+    // workgroup -> (query tile, head, batch).  XCD-aware form: the dispatcher deals workgroup i to XCD i % 8, so XCD x gets the
+    // ppx consecutive (batch, head) pairs [x * ppx, (x + 1) * ppx) with ALL their query tiles: a pair's K / V^T (and, in the fused
+    // projection, its head's weight rows and its batch row's activations) is pulled into exactly one L2.
+    int qt, h, b;
+    if (a.xcd_map) {
+        const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3;
+        const int pair = xcd * a.ppx + sl / a.nq;
+        qt = sl % a.nq;
+        if (pair >= a.B * a.H) return;   // whole workgroup, before any barrier
+        b = pair / a.H; h = pair % a.H;
+    } else {
+        qt = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+    }
+    const int q0 = qt * 64 + qs * 32;
     const long bh = (long)b * a.H + h;
 
     const bf16_t* Q = a.q + (bh * a.Lqp + q0 + r32) * DQK + 8 * hi;
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             const int mh = wave & 1, kq = wave >> 1;
             const int rowb = b * a.Lq;
             uint32_t aoff[1], boff[(DN * 8 + NT - 1) / NT];
-            stage_offsets<64, NT>(aoff, a.ldu, rowb + blockIdx.x * 64, rowb + a.Lq - 1, tid);
+            stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
             stage_offsets<DN, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
             const char* gA = reinterpret_cast<const char*>(a.xu);
@@ -422,12 +434,18 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 
 }  // namespace
 
-void launch_attention(const AttnArgs& a, hipStream_t st) {
-    dim3 grid((a.Lq + 63) / 64, a.H, a.B);
+int launch_attention(const AttnArgs& a0, hipStream_t st) {
+    AttnArgs a = a0;
+    a.nq = (a.Lq + 63) / 64;
+    a.ppx = (a.B * a.H + 7) / 8;
+    const long nwg = (long)a.nq * a.H * a.B;
+    dim3 grid(a.nq, a.H, a.B);
+    if (a.xcd_map) grid = dim3(8 * a.ppx * a.nq, 1, 1);
     int nkh = a.nkh;
-    if (nkh != 2 && nkh != 4) nkh = (long)grid.x * grid.y * grid.z <= 512 ? 4 : 2;   // 0 = choose by grid size
+    if (nkh != 2 && nkh != 4) nkh = nwg <= 512 ? 4 : 2;   // 0 = choose by grid size
     if (a.Lkp % 128) nkh = 2;
-    if (a.xu && nkh != 4) return;   // the fused projection exists in the 8-wave form only (callers check Lkp % 128 == 0)
+    if (a.xu && nkh != 4) return 1;   // the fused projection exists in the 8-wave form only (needs Lkp % 128 == 0)
+    if (a.dh != 64 && a.dh != 72) return 1;
     if (a.dh == 64) {
         if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a);
@@ -435,4 +453,5 @@ void launch_attention(const AttnArgs& a, hipStream_t st) {
         if (nkh == 4) hipLaunchKernelGGL((k_attn<72, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attn<72, 2>), grid, dim3(256), 0, st, a);
     }
+    return 0;
 }

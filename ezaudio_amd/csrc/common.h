@@ -40,6 +40,8 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+int ez_fail(int code, const char* fmt, ...);   // api.hip: record the message behind ezdit_last_error(), return code
+
 // ------------------------------------------------------------------------------------------
 // host-side launchers (one per kernel family); all asynchronous on `st`
 // ------------------------------------------------------------------------------------------
@@ -120,7 +122,7 @@ struct GemmArgs {
     HeadNormArgs hn;              // EPI_QKV only (x / ldx / *_col unused)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
 };
-void launch_gemm(const GemmArgs& a, hipStream_t st);
+int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 
 struct AttnArgs {
     const bf16_t* q;    // [B][H][Lqp][DQK]
@@ -137,8 +139,12 @@ struct AttnArgs {
     // by the workgroup itself (bf16 MFMA, K split over 4 wave groups, reduced through LDS), then normalised as above.
     // xu bf16 [B*Lq][ldu], xw bf16 [xw_rows][ldw] (nn.Linear layout), xK multiple of 64.  q and q_raw unused.
     const bf16_t* xu; int ldu; const bf16_t* xw; int ldw; int xw_rows; int xK;
+    // workgroup -> XCD placement: 1 = linear grid in which ALL query tiles of a (batch, head) pair -- and ceil(B*H/8) whole pairs --
+    // run on ONE XCD (hardware deals workgroup i to XCD i % 8), so each pair's K / V^T is fetched into exactly one L2.
+    // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
+    int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
 };
-void launch_attention(const AttnArgs& a, hipStream_t st);
+int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 
 struct RowArgs {
     // h_new = (mode SET) sum_s part_s + bias | (RES) h_in + gate * (sum_s part_s + bias) | (COPY) h_in
@@ -156,6 +162,7 @@ struct RowArgs {
     int M, D, L;           // rows, width, rows per batch element
     const int* cur_step; const int* row_slot;
     int wt;                // output stores are write-through (sc1)
+    int variant;           // 0: one 256-thread workgroup per row; 1: one wave per row (no LDS, no barriers)
 };
 void launch_row(const RowArgs& a, hipStream_t st);
 
@@ -209,6 +216,9 @@ struct CfgDdimArgs {
     float hc[5];         // (sa, sb, c_x0, c_dir, sigma) when cur_step is null
     float guidance_scale, guidance_rescale;  // guidance_scale <= 0: no CFG
     int P, n;            // n = C*L elements per sample
+    // fused sampler: the LAST workgroup to finish (arrival counter `done`, zero between launches) advances the device step
+    // counter, so the step needs no separate single-thread launch.  Both null: stand-alone operator.
+    int* step_inc; unsigned* done;
 };
 void launch_cfg_ddim(const CfgDdimArgs& a, float* partial /* [P][64][4] scratch */, hipStream_t st);
 void launch_prefetch(const void* p, size_t bytes, unsigned* sink, hipStream_t st);  // warm the Infinity Cache

@@ -55,6 +55,100 @@ __device__ __forceinline__ void wait_tiles(int younger) {
     wait_vmcnt<0>();
 }
 
+// ---- generic epilogues.  The MFMAs compute the TRANSPOSED tile (W fragment as the A operand), so in the 32x32 C layout a
+// lane owns ONE output row (m = lane & 31) and, per register group g, FOUR CONSECUTIVE output columns
+// n = 32j + 8g + 4*(lane>>5) + {0..3}: every store is 16 bytes (fp32) or 8 bytes (bf16) per lane instead of 4.
+// acc[i][j]: i-th 32-row fragment x j-th 32-column fragment of the wave tile at (wm * TM, wn * TN) of the workgroup tile.
+template <int FM, int FN, int TM, int TN, int EPI>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[FM][FN], int row0, int col0, int wm, int wn, int lane, int z) {
+    const int row_in = lane & 31, hi = lane >> 5;
+    if constexpr (EPI == EPI_GEGLU) {
+        // W rows are interleaved in groups of 8 (8 value rows, then their 8 gate rows): in the C layout above the
+        // value of inner index c sits in register group g (even) and its gate in group g + 1 of the SAME lane.
+        bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = row0 + wm * TM + i * 32 + row_in;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const int cv = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;       // packed column of the value
+                    const int oc = (col0 + wn * TN + j * 32 + 8 * g) / 2 + 4 * hi;  // output (inner) index
+                    if (row < a.M && cv < a.N) {
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+                        if (a.bias) {
+                            bv = *reinterpret_cast<const float4*>(a.bias + cv);
+                            bg = *reinterpret_cast<const float4*>(a.bias + cv + 8);
+                        }
+                        const float v0 = acc[i][j][4 * g + 0] + bv.x, g0 = acc[i][j][4 * g + 4] + bg.x;
+                        const float v1 = acc[i][j][4 * g + 1] + bv.y, g1 = acc[i][j][4 * g + 5] + bg.y;
+                        const float v2 = acc[i][j][4 * g + 2] + bv.z, g2 = acc[i][j][4 * g + 6] + bg.z;
+                        const float v3 = acc[i][j][4 * g + 3] + bv.w, g3 = acc[i][j][4 * g + 7] + bg.w;
+                        uint2 o;
+                        o.x = pack_bf2(v0 * gelu_erf(g0), v1 * gelu_erf(g1));
+                        o.y = pack_bf2(v2 * gelu_erf(g2), v3 * gelu_erf(g3));
+                        if (a.wt) st8_wt(out + (long)row * a.ldo + oc, o); else *reinterpret_cast<uint2*>(out + (long)row * a.ldo + oc) = o;
+                    }
+                }
+        }
+    } else {
+        float* out = reinterpret_cast<float*>(a.out);
+        if constexpr (EPI == EPI_PARTIAL) out += (long)z * a.slab_stride;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int row = row0 + wm * TM + i * 32 + row_in;
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int col = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;
+                    if (row < a.M && col < a.N) {  // N is a multiple of 4 for every caller
+                        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                        if constexpr (EPI == EPI_F32) {
+                            if (a.bias) {
+                                const float4 b = *reinterpret_cast<const float4*>(a.bias + col);
+                                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                            }
+                            if (a.resid) {
+                                const float4 r = *reinterpret_cast<const float4*>(a.resid + (long)row * a.ldr + col);
+                                if (a.gate) {
+                                    const int slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[row / a.rows_per_b] : 0);
+                                    const float4 g4 = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
+                                    v.x *= g4.x; v.y *= g4.y; v.z *= g4.z; v.w *= g4.w;
+                                }
+                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                            }
+                        }
+                        if (EPI == EPI_PARTIAL && a.part_bf16) {
+                            uint2 pk;
+                            pk.x = pack_bf2(v.x, v.y);
+                            pk.y = pack_bf2(v.z, v.w);
+                            bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (long)z * a.slab_stride + (long)row * a.ldo + col;
+                            if (a.wt) st8_wt(dst, pk); else *reinterpret_cast<uint2*>(dst) = pk;
+                        } else {
+                            float* dst = out + (long)row * a.ldo + col;
+                            if (a.wt) st16_wt(dst, v); else *reinterpret_cast<float4*>(dst) = v;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// XCD-aware tile map shared by both kernels: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the
+// (M tiles x N tiles x K splits) grid, M tiles fastest inside.  Returns false for a padding slot of a ragged box.
+__device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn, int& z) {
+    const int xcd = blockIdx.x & 7;
+    const int l = blockIdx.x >> 3;
+    const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
+    const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
+    tm = xm * a.bm + lm;
+    tn = xn * a.bn + ln;
+    z = xz * a.bz + lz;
+    return tm < tilesM && tn < tilesN && z < a.splitk;
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
@@ -182,9 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
     }
 
-    // ---- epilogue.  The MFMAs compute the TRANSPOSED tile (W fragment as the A operand), so in the 32x32 C layout a
-    // lane owns ONE output row (m = lane & 31) and, per register group g, FOUR CONSECUTIVE output columns
-    // n = 32j + 8g + 4*(lane>>5) + {0..3}: every store is 16 bytes (fp32) or 8 bytes (bf16) per lane instead of 4.
+    // ---- epilogue (lane <-> output element mapping: see store_tile) ----
     const int row_in = lane & 31;
     if constexpr (EPI == EPI_QKV) {
         // ---- fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection): the tile holds FOUR WHOLE heads
@@ -285,82 +377,145 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                 }
             }
         }
-    } else if constexpr (EPI == EPI_GEGLU) {
-        // W rows are interleaved in groups of 8 (8 value rows, then their 8 gate rows): in the C layout above the
-        // value of inner index c sits in register group g (even) and its gate in group g + 1 of the SAME lane.
-        bf16_t* out = reinterpret_cast<bf16_t*>(a.out);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int row = row0 + wm * TM + i * 32 + row_in;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    const int cv = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;       // packed column of the value
-                    const int oc = (col0 + wn * TN + j * 32 + 8 * g) / 2 + 4 * hi;  // output (inner) index
-                    if (row < a.M && cv < a.N) {
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
-                        if (a.bias) {
-                            bv = *reinterpret_cast<const float4*>(a.bias + cv);
-                            bg = *reinterpret_cast<const float4*>(a.bias + cv + 8);
-                        }
-                        const float v0 = acc[i][j][4 * g + 0] + bv.x, g0 = acc[i][j][4 * g + 4] + bg.x;
-                        const float v1 = acc[i][j][4 * g + 1] + bv.y, g1 = acc[i][j][4 * g + 5] + bg.y;
-                        const float v2 = acc[i][j][4 * g + 2] + bv.z, g2 = acc[i][j][4 * g + 6] + bg.z;
-                        const float v3 = acc[i][j][4 * g + 3] + bv.w, g3 = acc[i][j][4 * g + 7] + bg.w;
-                        uint2 o;
-                        o.x = pack_bf2(v0 * gelu_erf(g0), v1 * gelu_erf(g1));
-                        o.y = pack_bf2(v2 * gelu_erf(g2), v3 * gelu_erf(g3));
-                        if (a.wt) st8_wt(out + (long)row * a.ldo + oc, o); else *reinterpret_cast<uint2*>(out + (long)row * a.ldo + oc) = o;
-                    }
-                }
-        }
     } else {
-        float* out = reinterpret_cast<float*>(a.out);
-        if constexpr (EPI == EPI_PARTIAL) out += (long)z * a.slab_stride;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int row = row0 + wm * TM + i * 32 + row_in;
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;
-                    if (row < a.M && col < a.N) {  // N is a multiple of 4 for every caller
-                        float4 v = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                        if constexpr (EPI == EPI_F32) {
-                            if (a.bias) {
-                                const float4 b = *reinterpret_cast<const float4*>(a.bias + col);
-                                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-                            }
-                            if (a.resid) {
-                                const float4 r = *reinterpret_cast<const float4*>(a.resid + (long)row * a.ldr + col);
-                                if (a.gate) {
-                                    const int slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[row / a.rows_per_b] : 0);
-                                    const float4 g = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
-                                    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
-                                }
-                                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                            }
-                        }
-                        if (EPI == EPI_PARTIAL && a.part_bf16) {
-                            uint2 pk;
-                            pk.x = pack_bf2(v.x, v.y);
-                            pk.y = pack_bf2(v.z, v.w);
-                            bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (long)z * a.slab_stride + (long)row * a.ldo + col;
-                            if (a.wt) st8_wt(dst, pk); else *reinterpret_cast<uint2*>(dst) = pk;
-                        } else {
-                            float* dst = out + (long)row * a.ldo + col;
-                            if (a.wt) st16_wt(dst, v); else *reinterpret_cast<float4*>(dst) = v;
-                        }
-                    }
-                }
-        }
+        store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Large-tile kernel for many-row problems (batched prompts, M >= ~2000): 256 x 256 (or 192 x 256) output tile, 8 waves as 2 (M) x 4 (N),
+// wave tile 128 x 64 (96 x 64), BK = 64, TWO LDS stages with EARLY RELEASE.
+//
+// Why a second main loop: at 128 x 128 a K tile moves 32 KB for 2.1 MFLOP (64 FLOP per ingested byte) and the measured
+// L2 -> LDS ingest of a CU (~65 GB/s with 8 waves issuing) caps the loop at ~43 % of the CU's MFMA rate; 256 x 256 doubles
+// the reuse (128 FLOP / B).  A 2-deep ring of whole 64 KB stages, however, exposes the DMA latency of every tile (round 1's
+// tile 11).  Here every wave pulls ALL fragments of K tile t out of LDS during the first half of the tile's MFMAs
+// (k-steps 0, 1 compute while k-steps 2, 3 are read), so stage t & 1 is dead after half a tile: one barrier, and the
+// LDS-DMA of tile t + 2 is issued into it while k-steps 2, 3 still compute.  Tile t + 2's loads therefore fly for one and a
+// half K tiles (the prefetch distance of a 3-deep ring) out of 128 KB of LDS, and the wait at the top of tile t + 1 is a
+// COUNTED vmcnt that leaves tile t + 2's loads in flight across both barriers.
+// Order of one K tile (per wave, k-steps 0, 1 already in registers):
+//     mfma ks0 (half) | read ks2, ks3 | mfma ks0 (rest), ks1 | lgkmcnt(0) | barrier (stage free) | DMA A(t+2) | mfma ks2 | DMA W(t+2) |
+//     vmcnt(tile t+2 may fly) | barrier (tile t+1 visible) | read ks0, ks1 of tile t+1 | mfma ks3
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int FM = TM / 32, FN = TN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT, LPT = LA + LB;   // LDS-DMA instructions per thread per K tile
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "whole DMA passes only");
+    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is made of 32x32 fragments");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tilesM = (a.M + BM - 1) / BM;
+    const int tilesN = (a.N + BN - 1) / BN;
+    int tm, tn, z;
+    if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nk = a.K / BK;
+    const int kb = nk * z / a.splitk;
+    const int ke = nk * (z + 1) / a.splitk;
+    const int nt = ke - kb;
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint32_t aoff[LA], boff[LB];
+    stage_offsets<BM, NT>(aoff, a.lda, row0, a.M - 1, tid);
+    stage_offsets<BN, NT>(boff, a.ldw, col0, a.wrows - 1, tid);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* gA = reinterpret_cast<const char*>(a.A);
+    const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
+    auto stage_a = [&](int t) {
+        const long a_off = a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
+                                      : (long)(kb + t) * (BK * 2);
+        stage_tile<BM, NT>(gA + a_off, aoff, smem + (t & 1) * STAGE_BYTES + wave_u * 1024, tid);
+    };
+    auto stage_w = [&](int t) {
+        stage_tile<BN, NT>(gW + (long)t * (BK * 2), boff, smem + (t & 1) * STAGE_BYTES + A_BYTES + wave_u * 1024, tid);
+    };
+    if (nt > 0) { stage_a(0); stage_w(0); }
+    if (nt > 1) { stage_a(1); stage_w(1); }
+
+    const int r32 = lane & 31, hi = lane >> 5;
+    uint32_t foff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) foff[ks] = r32 * 128 + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4);
+    const int a_base = wm * TM * 128, b_base = A_BYTES + wn * TN * 128;
+
+    // Software-pipelined over K tiles: when an iteration starts, k-steps 0 and 1 of its tile are already in registers (or on
+    // their way), so no MFMA ever waits on an LDS read issued right behind a barrier.
+    bf16x8 af[4][FM], bfr[4][FN];
+#define EZ_READ_KS(base, ks)                                                                                              \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>((base) + foff[ks] + a_base + i * 4096);  \
+        _Pragma("unroll") for (int j = 0; j < FN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>((base) + foff[ks] + b_base + j * 4096); \
+    } while (0)
+#define EZ_MFMA_KS(ks, i0, i1)                                                                                            \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int i = (i0); i < (i1); ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);           \
+    } while (0)
+    constexpr int IH = FM / 2 > 0 ? FM / 2 : 1;   // first part of k-step 0's MFMAs, issued ahead of the reads of k-steps 2, 3
+    if (nt > 0) {
+        if (nt > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile 0 landed (this wave's part); tile 1 may still fly
+        __builtin_amdgcn_s_barrier();                           // ... and every other wave's part
+        EZ_READ_KS(smem, 0);
+        EZ_READ_KS(smem, 1);
+    }
+    for (int t = 0; t < nt; ++t) {
+        const char* cT = smem + (t & 1) * STAGE_BYTES;
+        EZ_MFMA_KS(0, 0, IH);
+        __builtin_amdgcn_sched_group_barrier(0x008, IH * FN, 0);
+        EZ_READ_KS(cT, 2);
+        EZ_READ_KS(cT, 3);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (FM + FN), 0);
+        EZ_MFMA_KS(0, IH, FM);
+        EZ_MFMA_KS(1, 0, FM);
+        __builtin_amdgcn_sched_group_barrier(0x008, (FM - IH) * FN + FM * FN, 0);
+        // every fragment of K tile t is in registers: its stage is dead for this wave and, after the barrier, for all of them
+        // (sched_barrier on BOTH sides: hipcc otherwise sinks the register-only MFMAs below the inline-asm wait, which then
+        // drains the LDS reads right after they were issued)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) stage_a(t + 2);          // refill it while k-steps 2, 3 compute
+        EZ_MFMA_KS(2, 0, FM);
+        if (t + 2 < nt) stage_w(t + 2);
+        if (t + 1 < nt) {
+            if (t + 2 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
+            __builtin_amdgcn_s_barrier();
+            const char* nT = smem + ((t + 1) & 1) * STAGE_BYTES;
+            EZ_READ_KS(nT, 0);
+            EZ_READ_KS(nT, 1);
+        }
+        EZ_MFMA_KS(3, 0, FM);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    }
+#undef EZ_READ_KS
+#undef EZ_MFMA_KS
+    store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
+}
+
+// NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
 template <int BM, int BN, int WM, int WN, int NS, int EPI>
-void launch_t(const GemmArgs& a0, hipStream_t st) {
+int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
@@ -381,14 +536,29 @@ void launch_t(const GemmArgs& a0, hipStream_t st) {
             if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
         }
     dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
-    constexpr int SMEM = NS * (BM + BN) * 128;
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in attribute once per kernel
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        attr_set = true;
+    constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128;
+    static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
+    // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device
+    static bool attr_set[32] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return 1;
+    if constexpr (NS > 0) {
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
+    } else {
+        if (!attr_set[dev]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
+            attr_set[dev] = true;
+        }
+        hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
     }
-    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
+    return 0;
 }
 
 // tile / pipeline configurations (GemmArgs.tile)
@@ -426,59 +596,66 @@ void launch_t(const GemmArgs& a0, hipStream_t st) {
 //   30  128x288  2x3    2     104 KB
 //   31  128x192  4x2    3     120 KB  8 waves, wave tile 32x96: N = 1152 -> 6 x 8 = 48 tiles, split-K 5 fills 240 CUs
 //   32  128x192  4x2    2      80 KB
+//   40  256x256  2x4    -     128 KB  k_gemm2: two stages with early release (wave tile 128x64), for M > 2048
+//   41  192x256  2x4    -     112 KB  k_gemm2, wave tile 96x64: M = 4000 x N = 9216 -> 21 x 36 = 756 workgroups = 2.95 rounds of 256 CUs
+//   42  256x128  4x2    -      96 KB  k_gemm2, wave tile 64x64
 template <int EPI>
-void launch_e(const GemmArgs& a, hipStream_t st) {
+int launch_e(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
-        case 0: launch_t<128, 128, 2, 2, 4, EPI>(a, st); return;
-        case 2: launch_t<128, 128, 2, 2, 2, EPI>(a, st); return;
-        case 4: launch_t<128, 128, 2, 2, 3, EPI>(a, st); return;
-        case 6: launch_t<128, 64, 4, 1, 2, EPI>(a, st); return;
-        case 7: launch_t<128, 128, 4, 2, 2, EPI>(a, st); return;
-        case 8: launch_t<256, 128, 4, 2, 2, EPI>(a, st); return;
-        case 9: launch_t<128, 128, 4, 2, 3, EPI>(a, st); return;
-        case 10: launch_t<256, 128, 4, 2, 3, EPI>(a, st); return;
-        case 11: launch_t<256, 256, 4, 2, 2, EPI>(a, st); return;
-        case 12: launch_t<128, 288, 4, 3, 2, EPI>(a, st); return;
-        case 13: launch_t<128, 288, 4, 3, 3, EPI>(a, st); return;
+        case 0: return launch_t<128, 128, 2, 2, 4, EPI>(a, st);
+        case 2: return launch_t<128, 128, 2, 2, 2, EPI>(a, st);
+        case 4: return launch_t<128, 128, 2, 2, 3, EPI>(a, st);
+        case 6: return launch_t<128, 64, 4, 1, 2, EPI>(a, st);
+        case 7: return launch_t<128, 128, 4, 2, 2, EPI>(a, st);
+        case 8: return launch_t<256, 128, 4, 2, 2, EPI>(a, st);
+        case 9: return launch_t<128, 128, 4, 2, 3, EPI>(a, st);
+        case 10: return launch_t<256, 128, 4, 2, 3, EPI>(a, st);
+        case 11: return launch_t<256, 256, 4, 2, 2, EPI>(a, st);
+        case 12: return launch_t<128, 288, 4, 3, 2, EPI>(a, st);
+        case 13: return launch_t<128, 288, 4, 3, 3, EPI>(a, st);
         default: break;
     }
     switch (a.tile) {
-        case 1: launch_t<128, 64, 2, 2, 3, EPI>(a, st); return;
-        case 3: launch_t<128, 64, 2, 2, 4, EPI>(a, st); return;
-        case 5: launch_t<128, 64, 2, 2, 2, EPI>(a, st); return;
-        case 14: launch_t<128, 64, 4, 1, 3, EPI>(a, st); return;
-        case 15: launch_t<128, 64, 4, 1, 4, EPI>(a, st); return;
-        case 16: launch_t<64, 64, 2, 2, 4, EPI>(a, st); return;
-        case 17: launch_t<64, 128, 2, 2, 3, EPI>(a, st); return;
-        case 18: launch_t<128, 64, 4, 1, 6, EPI>(a, st); return;
-        case 19: launch_t<64, 64, 2, 2, 8, EPI>(a, st); return;
-        case 20: launch_t<128, 64, 4, 1, 5, EPI>(a, st); return;
-        case 21: launch_t<64, 64, 2, 2, 5, EPI>(a, st); return;
-        case 22: launch_t<128, 128, 4, 4, 3, EPI>(a, st); return;
-        case 23: launch_t<128, 128, 4, 4, 2, EPI>(a, st); return;
-        case 24: launch_t<128, 64, 4, 2, 3, EPI>(a, st); return;
-        case 25: launch_t<128, 64, 4, 2, 4, EPI>(a, st); return;
-        case 26: launch_t<128, 128, 4, 4, 4, EPI>(a, st); return;
-        case 27: launch_t<256, 128, 8, 2, 2, EPI>(a, st); return;
-        case 28: launch_t<128, 256, 4, 4, 2, EPI>(a, st); return;
-        case 29: launch_t<128, 288, 2, 3, 3, EPI>(a, st); return;
-        case 30: launch_t<128, 288, 2, 3, 2, EPI>(a, st); return;
-        case 31: launch_t<128, 192, 4, 2, 3, EPI>(a, st); return;
-        case 32: launch_t<128, 192, 4, 2, 2, EPI>(a, st); return;
+        case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
+        case 3: return launch_t<128, 64, 2, 2, 4, EPI>(a, st);
+        case 5: return launch_t<128, 64, 2, 2, 2, EPI>(a, st);
+        case 14: return launch_t<128, 64, 4, 1, 3, EPI>(a, st);
+        case 15: return launch_t<128, 64, 4, 1, 4, EPI>(a, st);
+        case 16: return launch_t<64, 64, 2, 2, 4, EPI>(a, st);
+        case 17: return launch_t<64, 128, 2, 2, 3, EPI>(a, st);
+        case 18: return launch_t<128, 64, 4, 1, 6, EPI>(a, st);
+        case 19: return launch_t<64, 64, 2, 2, 8, EPI>(a, st);
+        case 20: return launch_t<128, 64, 4, 1, 5, EPI>(a, st);
+        case 21: return launch_t<64, 64, 2, 2, 5, EPI>(a, st);
+        case 22: return launch_t<128, 128, 4, 4, 3, EPI>(a, st);
+        case 23: return launch_t<128, 128, 4, 4, 2, EPI>(a, st);
+        case 24: return launch_t<128, 64, 4, 2, 3, EPI>(a, st);
+        case 25: return launch_t<128, 64, 4, 2, 4, EPI>(a, st);
+        case 26: return launch_t<128, 128, 4, 4, 4, EPI>(a, st);
+        case 27: return launch_t<256, 128, 8, 2, 2, EPI>(a, st);
+        case 28: return launch_t<128, 256, 4, 4, 2, EPI>(a, st);
+        case 29: return launch_t<128, 288, 2, 3, 3, EPI>(a, st);
+        case 30: return launch_t<128, 288, 2, 3, 2, EPI>(a, st);
+        case 31: return launch_t<128, 192, 4, 2, 3, EPI>(a, st);
+        case 32: return launch_t<128, 192, 4, 2, 2, EPI>(a, st);
+        case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
+        case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
+        case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
         default: break;
     }
-    launch_t<128, 64, 4, 1, 2, EPI>(a, st);
+    return 1;   // unknown tile id: refuse (the caller reports EZDIT_E_UNSUPPORTED) instead of silently running another configuration
 }
 
 }  // namespace
 
-void launch_gemm(const GemmArgs& a, hipStream_t st) {
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    if (a.K <= 0 || a.K % BK) return 1;
     if (a.epi == EPI_QKV) {   // tiles that hold four whole heads: 64x288 (head_dim 72, 6 waves) or 64x256 (head_dim 64, 8 waves)
-        if (a.hn.dh == 72) { if (a.tile == 1) launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st); else launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st); }
-        else launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
-        return;
+        if (a.hn.dh == 72) return a.tile == 1 ? launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st) : launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
+        if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
+        return 1;
     }
-    if (a.epi == EPI_GEGLU) launch_e<EPI_GEGLU>(a, st);
-    else if (a.epi == EPI_PARTIAL) launch_e<EPI_PARTIAL>(a, st);
-    else launch_e<EPI_F32>(a, st);
+    if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);
+    if (a.epi == EPI_PARTIAL) return launch_e<EPI_PARTIAL>(a, st);
+    return launch_e<EPI_F32>(a, st);
 }

@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void k_vae_sample(const float* __restrict__ en
     z[idx] = (noise ? noise[idx] : 0.f) * (softplus + 1e-4f) + mean;
 }
 
+int launch_status(const char* what) {   // a failed launch must surface as an error code, not as stale output
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ez_fail(EZDIT_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return EZDIT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -99,42 +105,44 @@ extern "C" {
 // out fp32 [M][ldo] = A . W^T (+ bias) (+ resid); conv_cpb / conv_tap_bytes as in GemmArgs.  N multiple of 4.
 int ezvae_gemm(const void* A, int lda, const void* W, int ldw, int wrows, const float* bias, const float* resid, int ldr,
                float* out, int ldo, int M, int N, int K, int conv_cpb, long conv_tap_bytes, int tile, ezdit_stream stream) {
-    if (K % 64 || N % 4) return EZDIT_E_INVALID;
+    if (K % 64 || N % 4) return ez_fail(EZDIT_E_INVALID, "ezvae_gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
     GemmArgs g;
+    memset(&g, 0, sizeof g);
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = wrows; g.bias = bias;
     g.out = out; g.ldo = ldo; g.slab_stride = 0; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_F32; g.tile = tile;
     g.debug = 0; g.conv_cpb = conv_cpb; g.conv_tap_bytes = conv_tap_bytes; g.resid = resid; g.ldr = ldr; g.xcd_map = 1; g.part_bf16 = 0; g.wt = 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
-    launch_gemm(g, (hipStream_t)stream);
-    return EZDIT_OK;
+    (void)hipGetLastError();
+    if (launch_gemm(g, (hipStream_t)stream)) return ez_fail(EZDIT_E_UNSUPPORTED, "ezvae_gemm: tile %d / shape not supported", tile);
+    return launch_status("k_gemm (vae)");
 }
 
 int ezvae_snake_bf16(const float* x, int ldx, const float* alpha, const float* inv_beta, void* out, int ldo, long L, int C,
                      ezdit_stream stream) {
-    if (C % 4) return EZDIT_E_INVALID;
+    if (C % 4) return ez_fail(EZDIT_E_INVALID, "C=%d must be a multiple of 4", C);
     const long total = L * (C / 4);
     hipLaunchKernelGGL(k_snake_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, alpha, inv_beta,
                        (bf16_t*)out, ldo, L, C);
-    return EZDIT_OK;
+    return launch_status("k_snake_bf16");
 }
 
 int ezvae_conv_out1(const void* xb, int ldx, const float* w, float* out, long L, int C, ezdit_stream stream) {
-    if (C % 8) return EZDIT_E_INVALID;
+    if (C % 8) return ez_fail(EZDIT_E_INVALID, "C=%d must be a multiple of 8", C);
     hipLaunchKernelGGL(k_conv_out1, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)xb, ldx, w, out, L, C);
-    return EZDIT_OK;
+    return launch_status("k_conv_out1");
 }
 
 int ezvae_conv_in1(const float* wav, const float* w, const float* bias, float* out, long T, int C, ezdit_stream stream) {
-    if (C % 4) return EZDIT_E_INVALID;
+    if (C % 4) return ez_fail(EZDIT_E_INVALID, "C=%d must be a multiple of 4", C);
     const long total = T * (C / 4);
     hipLaunchKernelGGL(k_conv_in1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav, w, bias, out, T, C);
-    return EZDIT_OK;
+    return launch_status("k_conv_in1");
 }
 
 int ezvae_sample(const float* enc, const float* noise, float* z, int L, int latent_dim, ezdit_stream stream) {
     const int total = L * latent_dim;
     hipLaunchKernelGGL(k_vae_sample, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, enc, noise, z, L, latent_dim);
-    return EZDIT_OK;
+    return launch_status("k_vae_sample");
 }
 
 }  // extern "C"

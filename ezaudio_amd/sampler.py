@@ -48,7 +48,14 @@ class LatentSampler:
         self.noise = None if (eta <= 0 or step_noises is None) else step_noises.to(dev, torch.float32).contiguous()
         if eta > 0 and self.noise is None:
             raise ValueError('eta > 0 needs step_noises [n_steps, P, C, L]')
-        self.gt = None if gt is None else gt.to(dev, torch.float32).contiguous()
+        if (gt is None) != (gt_mask is None):
+            raise ValueError('gt and gt_mask must be given together')
+        # the kernels index gt / gt_mask per latent row ([P, C, L]): a shared [1, C, L] reference (one clip edited under P prompts,
+        # which is also what the sharded driver forwards un-sliced) is broadcast here
+        for name, t in (('gt', gt), ('gt_mask', gt_mask)):
+            if t is not None and t.shape[0] not in (1, P):
+                raise ValueError(f'{name} has {t.shape[0]} rows; expected 1 or P={P}')
+        self.gt = None if gt is None else gt.to(dev, torch.float32).expand(P, Cc, L).contiguous()
         self.gt_mask = None if gt_mask is None else gt_mask.to(dev).expand(P, Cc, L).to(torch.uint8).contiguous()
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
@@ -167,6 +174,7 @@ def inference(autoencoder, unet, gt, gt_mask, tokenizer, text_encoder, params, n
     smp.run(use_graph=use_graph)
     latents = smp.finish()
     pred = scale_shift_re(latents, params['autoencoder']['scale'], params['autoencoder']['shift'])
-    if gt is not None:
-        pred[~gt_mask] = gt[~gt_mask]
+    if gt is not None:   # src/inference.py:103-104, with a shared [1, C, L] reference broadcast over the prompts
+        keep = ~gt_mask.to(pred.device).expand_as(pred)
+        pred = torch.where(keep, gt.to(pred.device, pred.dtype).expand_as(pred), pred)
     return autoencoder(embedding=pred)

@@ -90,12 +90,26 @@ class _OobleckNet:
 
     # ---- buffers -------------------------------------------------------------------------------------------------------
     def _buf(self, tag, rows, cols, dtype):
-        key = (tag, rows, cols, dtype)
-        b = self._bufs.get(key)
-        if b is None:
-            b = torch.zeros(rows, cols, dtype=dtype, device=self.device)    # halo rows stay zero: only interiors are written
-            self._bufs[key] = b
-        return b
+        """Activation buffer [rows][cols] for role `tag`.  ONE allocation per (tag, width), grown to the longest sequence seen and
+        handed out as a view: a long-running process that decodes / encodes many different lengths (`generate_audio(length=...)`,
+        `editing_audio` on arbitrary clips) keeps a bounded working set instead of one full buffer set per length (the widths are
+        fixed by the architecture, one per level).  Haloed buffers rely on their halo rows being zero and only interiors are
+        ever written, so a view with a NEW row count over an old allocation is re-zeroed once, on the current stream (the one
+        the kernels run on): stale interior rows would otherwise sit where the new halo is."""
+        key = (tag, cols, dtype)
+        need = rows * cols
+        ent = self._bufs.get(key)
+        if ent is None or ent[0].numel() < need:
+            ent = [torch.zeros(need, dtype=dtype, device=self.device), rows]
+            self._bufs[key] = ent
+        elif ent[1] != rows:
+            ent[0][:max(need, ent[1] * cols)].zero_()
+            ent[1] = rows
+        return ent[0][:need].view(rows, cols)
+
+    def release_buffers(self):
+        """Drop the cached activation buffers (they are re-created on the next call)."""
+        self._bufs = {}
 
     # ---- launches ------------------------------------------------------------------------------------------------------
     def _check(self, rc):

@@ -139,7 +139,8 @@ int ezdit_controlnet_forward(ezdit_handle* cn, const float* dev_x, int in_ch, in
 int ezdit_controlnet_residuals(ezdit_handle* cn, const float** out, int n);
 /* the backbone's sampler then runs ControlNet + backbone per step (src/inference_controlnet.py:89-99) */
 int ezdit_sampler_attach_controlnet(ezdit_handle* h, ezdit_handle* cn, float conditioning_scale);
-/* scale applied to cn_skips inside ezdit_forward (default 1.0: residuals already scaled by the caller) */
+/* scale applied to cn_skips inside ezdit_forward (default 1.0: residuals already scaled by the caller, as DiTControlNet.forward
+ * returns them).  Independent of the conditioning_scale of a ControlNet attached to the fused sampler. */
 int ezdit_set_cn_scale(ezdit_handle* h, float scale);
 
 /* ---- sampler: CFG + rescale + DDIM, src/inference.py:70-100 + diffusers DDIMScheduler.step ---- */
@@ -165,7 +166,8 @@ int ezdit_sampler_begin(ezdit_handle* h, float* dev_latents, int P, const float*
                         float guidance_scale, float guidance_rescale,
                         const float* dev_gt, const uint8_t* dev_gt_mask, ezdit_stream stream);
 /* run `n` consecutive steps from the current step counter; use_graph != 0 captures one step into a
- * hipGraph on first use and replays it (no host work between kernels). */
+ * hipGraph on first use and replays it (no host work between kernels).  Running past the prepared steps (n_steps of
+ * ezdit_sampler_begin / n of ezdit_prepare_timesteps) is refused with EZDIT_E_STATE; ezdit_set_step rewinds. */
 int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream);
 
 /* ---- Oobleck VAE decoder building blocks (src/modules/stable_vae/models/autoencoders.py:38-61,82-113,149-190) --------
@@ -208,6 +210,8 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1 (write-through stores)
  *   fuse_qkv 0/1 (head-norm + RoPE + V^T in the QKV GEMM epilogue), qkv_waves9 0/1, fuse_q2 0/1/2 (cross-attention computes its
  *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
+ *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
+ *     wave per row)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 

@@ -74,6 +74,18 @@ def t_(a, dev='cuda:0'):
     (500, 300, 192, 12 * 4 + 1, 2),     # 128x288 ragged
     (1000, 1152, 1152, 13 * 4 + 0, 1),  # 128x288, ring 3
     (1000, 1152, 1152, 13 * 4 + 1, 6),  # 128x288, ring 3, 3 K tiles per slice
+    # k_gemm2 (two LDS stages with early release): 256x256, 192x256, 256x128 tiles
+    (4000, 1152, 1152, 40 * 4 + 0, 1),
+    (1000, 3456, 1152, 40 * 4 + 0, 1),
+    (4000, 1152, 4608, 40 * 4 + 1, 3),  # split-K 3: 24 K tiles per slice
+    (1000, 1152, 1152, 40 * 4 + 1, 9),  # 2 K tiles per slice: shorter than the pipeline
+    (300, 256, 64, 40 * 4 + 0, 1),      # single K tile
+    (300, 256, 128, 40 * 4 + 0, 1),     # two K tiles
+    (300, 300, 192, 40 * 4 + 1, 2),     # ragged M / N, uneven split (1 + 2 tiles)
+    (4000, 1152, 1152, 41 * 4 + 0, 1),  # 192x256
+    (500, 300, 192, 41 * 4 + 1, 3),
+    (4000, 1152, 2304, 42 * 4 + 1, 2),  # 256x128
+    (130, 128, 64, 42 * 4 + 0, 1),
 ])
 def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     g = torch.Generator().manual_seed(M + N + K)
@@ -103,7 +115,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13])
+@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13, 40, 41, 42])
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
@@ -184,8 +196,10 @@ def _forward(m, inp, t, kw):
     return pred
 
 
-@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 'xs_cn', 's', 's64', 's_edit', 'l', 'xl'])
+@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 'xs_cn', 's', 's64', 's_edit', 'l', 'xl', 'xl_b8'])
 def test_forward_matches_reference_golden(lib, dev, name):
+    """xl_b8: BASELINE config #4's per-GPU shape (4 prompts = 8 denoiser rows, M = 4000 token rows at XL width), which takes the
+    large-M tile configurations."""
     cfg, sd, inp, kw, g, meta = golden_case(name)
     m = get_model(meta['size'], meta['seed_w'])
     for t in meta['timesteps']:
@@ -262,10 +276,12 @@ def _run_sampler(m, inp, init, noises, meta, use_graph=True, P=1):
     return lat
 
 
-@pytest.mark.parametrize('name,tol', [('smp_xs', 8e-2), ('smp_xs_e0', 8e-2), ('smp_s', 8e-2)])
+@pytest.mark.parametrize('name,tol', [('smp_xs', 2e-2), ('smp_xs_e0', 2e-2), ('smp_s', 2e-2), ('smp_l', 2e-2), ('smp_xl', 2e-2)])
 def test_sampler_matches_reference_loop_golden(lib, dev, name, tol):
-    """Final latent of the reference's own inference() (fp32, 20-50 steps) vs the HIP sampler (bf16 denoiser).
-    bf16 error compounds over the trajectory; the per-step error is gated at 2e-2 above."""
+    """Final latent of the reference's own unmodified inference() (fp32, 20-50 steps) vs the HIP sampler (bf16 denoiser).
+    smp_l / smp_xl are BASELINE.json configs #2 / #3 (the shipped L and XL architectures, 50 steps, 10 s latent, guidance 5,
+    rescale 0.75, eta 1).  bf16 error compounds over the trajectory: measured 7.0e-3 (xs) / 8.3e-3 (s) in round 1, gate 2e-2
+    (the per-step gate above is 2e-2 as well)."""
     cfg, sd, inp, init, noises, g, meta = sampler_case(name)
     m = get_model(meta['size'], meta['seed_w'])
     lat = _run_sampler(m, inp, init, noises, meta).cpu().numpy()
@@ -310,6 +326,112 @@ def test_fused_cfg_ddim_step_against_oracle_loop(lib, dev):
     # both loops call the SAME bf16 denoiser; fp32 rounding differences in CFG/DDIM (<1e-6) flip bf16 roundings inside the
     # next forward, so trajectories separate at the 1e-3 level after a dozen steps (measured 1.0e-3)
     assert rel_l2(lat.cpu().numpy(), tr[steps - 1]) < 5e-3, meta2
+
+
+def test_reference_style_loop_drives_the_operator(lib, dev):
+    """Surface B2 of SURVEY.md section 8b: the reference's loop body (src/inference.py:70-100), restated here line by line
+    with OUR denoiser called once per step as `unet(...)` and OUR DDIMScheduler.step as the scheduler -- what a maintainer
+    gets by swapping only the two objects -- against the reference's own final latent (smp_xs)."""
+    from ezaudio_amd.scheduler import DDIMScheduler
+    cfg, sd, inp, init, noises, g, meta = sampler_case('smp_xs')
+    unet = get_model('xs', meta['seed_w'])
+    sched = DDIMScheduler(**DIFF)
+    text, text_mask = t_(inp['ctx'][0:1]), t_(inp['ctx_mask'][0:1])
+    uncond_text, uncond_mask = t_(inp['ctx'][1:2]), t_(inp['ctx_mask'][1:2])
+    guidance_scale, guidance_rescale, eta = meta['guidance_scale'], meta['guidance_rescale'], meta['eta']
+    sched.set_timesteps(meta['steps'])
+    noise = t_(init)
+    latents = noise
+    for i, t in enumerate(sched.timesteps):
+        latents = sched.scale_model_input(latents, t)
+        latent_model_input = torch.cat([latents] * 2)                     # inference.py:75
+        context = torch.cat([text, uncond_text], dim=0)
+        context_mask = torch.cat([text_mask, uncond_mask], dim=0)
+        noise_pred, _ = unet(latent_model_input, t, context, context_mask=context_mask, cls_token=None, gt=None,
+                             mae_mask_infer=None)                         # inference.py:82-86
+        noise_pred_text, noise_pred_uncond = noise_pred.chunk(2)
+        out = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+        std_text = noise_pred_text.std(dim=list(range(1, noise_pred_text.ndim)), keepdim=True)   # rescale_noise_cfg, :12-23
+        std_cfg = out.std(dim=list(range(1, out.ndim)), keepdim=True)
+        out = guidance_rescale * (out * (std_text / std_cfg)) + (1 - guidance_rescale) * out
+        latents = sched.step(model_output=out, timestep=t, sample=latents, eta=eta, variance_noise=t_(noises[i])).prev_sample
+    torch.cuda.synchronize()
+    r = rel_l2(latents.cpu().numpy(), g['latent'])
+    print(f'reference-style loop on the drop-in operator: final-latent rel-L2 {r:.3e}')
+    assert r < 2e-2
+
+
+def test_sampler_run_rejects_steps_beyond_the_prepared_schedule(lib, dev):
+    from ezaudio_amd import _lib
+    cfg, sd, inp, init, noises, g, meta = sampler_case('smp_xs')
+    m = get_model('xs', meta['seed_w'])
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    smp = LatentSampler(m, DDIMScheduler(**DIFF))
+    smp.prepare(t_(inp['ctx'][0:1]), t_(inp['ctx_mask'][0:1]), t_(inp['ctx'][1:2]), t_(inp['ctx_mask'][1:2]), t_(init),
+                torch.stack([t_(z) for z in noises], 0), 5.0, 0.75, 50, 1.0)
+    smp.run(30)
+    with pytest.raises(_lib.EzditError):
+        smp.run(30)          # 60 > 50 prepared steps: coefficient / modulation / noise tables would be read out of bounds
+    smp.run(20)              # exactly to the end is fine
+    with pytest.raises(_lib.EzditError):
+        smp.run(1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(smp.finish()).all()
+
+
+def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
+    """P prompts editing the same clip: gt / gt_mask given once ([1, C, L]) must behave exactly like P copies."""
+    cfg, sd, inp, init, noises, g, meta = sampler_case('smp_xs_e0')
+    m = get_model('xs', meta['seed_w'])
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    P, steps = 3, meta['steps']
+    text, tm = t_(inp['ctx'][0:1]).repeat(P, 1, 1), t_(inp['ctx_mask'][0:1]).repeat(P, 1)
+    un, um = t_(inp['ctx'][1:2]).repeat(P, 1, 1), t_(inp['ctx_mask'][1:2]).repeat(P, 1)
+    gt1, gm1 = t_(inp['gt'][0:1]), t_(inp['gt_mask'][0:1])
+    outs = []
+    for gt, gm in ((gt1, gm1), (gt1.repeat(P, 1, 1), gm1.repeat(P, 1, 1))):
+        smp = LatentSampler(m, DDIMScheduler(**DIFF))
+        smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, meta['guidance_scale'], meta['guidance_rescale'], steps,
+                    meta['eta'], gt=gt, gt_mask=gm)
+        smp.run()
+        outs.append(smp.finish().clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    lat = torch.where(gm1, outs[0][0:1], gt1)
+    assert rel_l2(lat.cpu().numpy(), g['latent']) < 2e-2
+    with pytest.raises(ValueError):
+        smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
+
+
+@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1))])
+def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
+    """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
+    LayerNorm statistics (fp32 rounding only)."""
+    cfg, sd, inp, kw, g, meta = golden_case('s')
+    m = get_model('s', meta['seed_w'])
+    outs = []
+    for v in values:
+        assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
+        outs.append(_forward(m, inp, 499, kw).cpu().numpy())
+    assert lib.ezdit_set_option(m._h, opt.encode(), 1) == 0
+    if opt == 'attn_xcd':
+        np.testing.assert_array_equal(outs[0], outs[1])
+    else:
+        assert rel_l2(outs[0], outs[1]) < 2e-3
+        for o in outs:
+            assert rel_l2(o, g['pred_t499']) < REL_TOL
+
+
+def test_unsupported_kernel_configuration_is_an_error_not_a_silent_skip(lib, dev):
+    from ezaudio_amd import _lib
+    A = torch.zeros(128, 64, dtype=torch.bfloat16, device=dev)
+    out = torch.zeros(128, 128, device=dev)
+    rc = lib.ezdit_test_gemm(None, 99 * 4, A.data_ptr(), 64, A.data_ptr(), 64, None, out.data_ptr(), 128, 128, 128, 64, 1, None)
+    assert rc != 0 and lib.ezdit_last_error()
+    rc = lib.ezdit_test_gemm(None, 0, A.data_ptr(), 64, A.data_ptr(), 64, None, out.data_ptr(), 128, 128, 128, 100, 1, None)
+    assert rc != 0   # K not a multiple of 64
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -180,7 +180,7 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
     _, h = _handle(lib, 'xs')
     names = ['tile_partial', 'tile_f32', 'tile_qkv', 'tile_p18', 'tile_p36', 'tile_p72', 'geglu_tile', 'tile_partial_big', 'tile_f32_big',
              'geglu_big', 'split18', 'split36', 'split72', 'split_big', 'xcd_map', 'slab_bf16', 'wt', 'fuse_qkv', 'qkv_waves9', 'fuse_q2',
-             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch']
+             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant']
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
     for n in names:
         assert n in src, n
@@ -188,3 +188,44 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
     assert lib.ezdit_set_option(h, b'no_such_knob', 1) == -1
     assert b'no_such_knob' in lib.ezdit_last_error()
     lib.ezdit_destroy(h)
+
+
+def test_bench_relaunches_itself_for_multi_gpu_and_integration_stub_matches_header():
+    """`python bench.py --gpus N` (the driver's form) must start N ranks by itself; the ctypes struct INTEGRATION.md shows a
+    maintainer must have the header's field list (a short struct makes ezdit_create read stack garbage)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.relaunch_command(4, ['--gpus', '4', '--steps', '7'], port=12345)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd and '127.0.0.1' in cmd and '12345' in cmd
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '7'] and cmd[-5].endswith('bench.py')
+    hdr = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
+    body = re.search(r'typedef struct \{(.*?)\} ezdit_config;', hdr, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = re.findall(r'(?:int32_t|float)\s+([a-z_0-9]+);', body)
+    from ezaudio_amd import _lib
+    assert fields == [f[0] for f in _lib.EzditConfig._fields_]
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = re.search(r'class EzditConfig.*?_fields_ = \[(.*?)\]\n', doc, flags=re.S)
+    assert stub, 'INTEGRATION.md must show the ctypes struct'
+    assert re.findall(r"\('([a-z_0-9]+)'", stub.group(1)) == fields
+
+
+def test_torch_cpu_baseline_port_matches_reference_golden():
+    """oracle/torch_ref.py (what bench.py times as the CPU baseline on the GPU box) against the reference-minted goldens."""
+    from oracle.torch_ref import DiTTorchRef
+    from tests.util import golden_case, rel_l2
+    for name in ('xs', 'xs64', 'xs_edit'):
+        cfg, sd, inp, kw, g, meta = golden_case(name)
+        m = DiTTorchRef(cfg, sd)
+        for t in meta['timesteps']:
+            kk = dict(gt=kw['gt'], mae_mask_infer=kw['mae_mask_infer']) if 'gt' in kw else {}
+            pred, _ = m.forward(inp['x'], t, inp['ctx'], inp['ctx_mask'], **kk)
+            assert rel_l2(pred.numpy(), g[f'pred_t{t}']) < 1e-5, (name, t)
+
+
+def test_source_hash_tracks_kernel_sources():
+    from ezaudio_amd.build import source_hash
+    h = source_hash()
+    assert len(h) == 16 and h == source_hash()

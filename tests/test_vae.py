@@ -163,6 +163,30 @@ def test_hip_decoder_matches_reference_golden(name):
 
 
 @pytest.mark.gpu
+def test_hip_decoder_buffer_cache_is_bounded_across_lengths():
+    """A long-running process decodes many different lengths: the activation cache must not grow per length, and a buffer that
+    is re-used with a new geometry must still have clean halo rows (the result of a repeated length is bitwise unchanged)."""
+    import torch
+    cfg = dict(V.VAE_TINY)
+    sd = V.make_vae_state_dict(cfg, 5)
+    dec = _hip_decoder(cfg, sd)
+    lat = cfg['latent_dim']
+    zs = {L: torch.from_numpy((1.2 * uniform_pm1(f'vae_z_len{L}', lat * L, 3)).reshape(1, lat, L).astype(np.float32)).cuda()
+          for L in (40, 17, 64, 23)}
+    first = {L: dec(z).clone() for L, z in zs.items()}
+    torch.cuda.synchronize()
+    n_bufs = len(dec._bufs)
+    held = sum(e[0].numel() * e[0].element_size() for e in dec._bufs.values())
+    for L in (23, 64, 17, 40, 17):
+        assert torch.equal(dec(zs[L]), first[L]), L
+    torch.cuda.synchronize()
+    assert len(dec._bufs) == n_bufs
+    assert sum(e[0].numel() * e[0].element_size() for e in dec._bufs.values()) == held
+    ref = V.DecoderOracle(cfg, sd)(zs[17].cpu().numpy())
+    assert rel_l2(first[17].cpu().numpy(), ref) < VAE_REL
+
+
+@pytest.mark.gpu
 def test_hip_decoder_full_length_vs_oracle():
     """10 s of audio (250 latent frames -> 120000 samples), the size generate_audio() decodes."""
     import torch

@@ -26,7 +26,7 @@ def golden_case(name):
     g, meta = load_golden('dit_' + name)
     cfg = model_config(meta['size'])
     sd = make_state_dict(cfg, meta['seed_w'])
-    inp = make_inputs(cfg, B=2, L=meta['L'], Lc=meta['Lc'], n_valid=tuple(meta['n_valid']), seed=meta['seed_in'],
+    inp = make_inputs(cfg, B=meta.get('B', 2), L=meta['L'], Lc=meta['Lc'], n_valid=tuple(meta['n_valid']), seed=meta['seed_in'],
                       with_gt=meta['with_gt'])
     kw = {}
     if meta['with_gt']:
