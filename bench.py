@@ -103,17 +103,40 @@ def host_cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(cfg, sd, text, text_mask, uncond, uncond_mask, L, budget_s=20.0):
-    """The reference's CPU path -- fp32, PyTorch eager, every host core -- timed on THIS box on a bounded
-    sample of the same workload.  /root/reference does not travel to the GPU box, so the timed implementation is
-    oracle/torch_ref.py, a restatement on the same aten operators; profiles/ref_cpu_baseline.json (tools/ref_cpu_baseline.py,
-    build container) holds the unmodified reference timed next to it (ratio ~1.0) and is attached for provenance."""
+def usable_cpus():
+    """Host cores this process may actually use: the scheduler affinity mask and the cgroup CPU quota both bound os.cpu_count()
+    (a 256-core box with a 32-CPU quota must not get a 256-thread OpenMP pool: the spinning threads starve each other)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != 'max':
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def cpu_baseline_worker(size, threads, budget_s):
+    """Runs in a child process (bench.py --cpu-baseline-worker): fp32 PyTorch eager forward of the same workload, `threads` threads."""
+    from ezaudio_amd.weights import random_state_dict
     from oracle.torch_ref import DiTTorchRef
-    torch.set_num_threads(os.cpu_count())
-    o = DiTTorchRef(cfg, {k: v for k, v in sd.items()})
-    x = np.random.default_rng(0).standard_normal((2, cfg['out_chans'], L)).astype(np.float32)
-    ctx = np.concatenate([text[:1], uncond[:1]], 0)
-    msk = np.concatenate([text_mask[:1], uncond_mask[:1]], 0)
+    torch.set_num_threads(threads)
+    params = model_section(size)
+    cfg = params['model']
+    L = 10 * params['autoencoder']['latent_sr']
+    Lc = params['text_encoder']['max_length']
+    o = DiTTorchRef(cfg, random_state_dict(cfg, seed=1234))
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, cfg['out_chans'], L, generator=g)
+    ctx = torch.randn(2, Lc, cfg['context_dim'], generator=g)
+    msk = torch.zeros(2, Lc, dtype=torch.bool)
+    msk[0, :13] = True
+    msk[1, :1] = True
     o.forward(x, 499, ctx, msk)                       # warm-up (thread pool, allocator)
     times = []
     t_start = time.perf_counter()
@@ -122,20 +145,47 @@ def cpu_baseline(cfg, sd, text, text_mask, uncond, uncond_mask, L, budget_s=20.0
         o.forward(x, 499, ctx, msk)
         times.append(time.perf_counter() - t0)
     times.sort()
-    med = times[len(times) // 2]
-    res = dict(value=1.0 / med, unit='steps/s', cores=os.cpu_count(), kind='port', cpu_model=host_cpu_model(),
-               torch_threads=torch.get_num_threads(),
-               sample=f'{len(times)} CFG denoiser evaluations (B=2 rows, L={L}, Lc={ctx.shape[1]}), median; fp32 PyTorch eager on the '
-                      f'aten operators the reference modules call (oracle/torch_ref.py); CFG/DDIM update excluded (negligible)',
-               seconds_per_step=med, min_seconds_per_step=times[0])
-    ref_json = os.path.join(ROOT, 'profiles', 'ref_cpu_baseline.json')
-    if os.path.exists(ref_json):
-        with open(ref_json) as f:
-            r = json.load(f)
-        res['reference_on_build_box'] = {'steps_per_s': r['reference']['steps_per_s'], 'cores': r['host']['cores'],
-                                         'cpu_model': r['host']['cpu_model'], 'port_time_ratio': r['port']['time_ratio_vs_reference'],
-                                         'kind': 'reference', 'source': 'profiles/ref_cpu_baseline.json (tools/ref_cpu_baseline.py)'}
-    return res
+    print('CPU_BASELINE ' + json.dumps({'median_s': times[len(times) // 2], 'min_s': times[0], 'n': len(times), 'threads': torch.get_num_threads(),
+                                        'L': L, 'Lc': Lc}))
+
+
+def cpu_baseline(size, budget_s=20.0, timeout_s=240):
+    """The reference's CPU path -- fp32, PyTorch eager, every usable host core -- timed on THIS box on a bounded
+    sample of the same workload, in a child process with a hard timeout (a mis-sized thread pool must never hang the bench line).
+    /root/reference does not travel to the GPU box, so the timed implementation is oracle/torch_ref.py, a restatement on the same
+    aten operators; profiles/ref_cpu_baseline.json (tools/ref_cpu_baseline.py, build container) holds the unmodified reference
+    timed next to it (time ratio 0.95) and is attached for provenance."""
+    n = usable_cpus()
+    tried = []
+    for threads in dict.fromkeys([n, min(n, 64), min(n, 16)]):
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--cpu-baseline-worker', '--size', size, '--threads', str(threads),
+               '--budget', str(budget_s)]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('CPU_BASELINE ')]
+            if r.returncode == 0 and line:
+                m = json.loads(line[-1][len('CPU_BASELINE '):])
+                res = dict(value=1.0 / m['median_s'], unit='steps/s', cores=m['threads'], host_cores=os.cpu_count(), kind='port',
+                           cpu_model=host_cpu_model(),
+                           sample=f"{m['n']} CFG denoiser evaluations (B=2 rows, L={m['L']}, Lc={m['Lc']}), median; fp32 PyTorch eager on the aten "
+                                  f"operators the reference modules call (oracle/torch_ref.py), {m['threads']} threads; CFG/DDIM update excluded (negligible)",
+                           seconds_per_step=m['median_s'], min_seconds_per_step=m['min_s'])
+                if tried:
+                    res['note'] = 'thread counts that did not finish in %d s: %s' % (timeout_s, tried)
+                ref_json = os.path.join(ROOT, 'profiles', 'ref_cpu_baseline.json')
+                if os.path.exists(ref_json):
+                    with open(ref_json) as f:
+                        rj = json.load(f)
+                    res['reference_on_build_box'] = {'steps_per_s': rj['reference']['steps_per_s'], 'cores': rj['host']['cores'],
+                                                     'cpu_model': rj['host']['cpu_model'], 'kind': 'reference',
+                                                     'port_time_ratio': rj['port']['time_ratio_vs_reference'],
+                                                     'source': 'profiles/ref_cpu_baseline.json (tools/ref_cpu_baseline.py)'}
+                return res
+            tried.append((threads, 'rc=%d %s' % (r.returncode, r.stderr[-200:])))
+        except subprocess.TimeoutExpired:
+            tried.append((threads, 'timeout'))
+    return {'error': 'cpu baseline did not finish', 'tried': tried, 'kind': 'port'}
 
 
 def measured_traffic():
@@ -168,7 +218,13 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='name=value tuning knob passed to ezdit_set_option')
     ap.add_argument('--prefetch', action='store_true')
     ap.add_argument('--controlnet', action='store_true', help='BASELINE config #5: add an energy ControlNet of the same width')
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--budget', type=float, default=20.0, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_worker:
+        cpu_baseline_worker(a.size, a.threads or usable_cpus(), a.budget)
+        return
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -324,7 +380,7 @@ def main():
             except Exception as e:  # the probe must never cost the headline number
                 res['roofline']['dominant_kernel'] = {'error': repr(e)}
         if world == 1 and not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(cfg, sd, text.numpy(), text_mask.numpy(), uncond.numpy(), uncond_mask.numpy(), L)
+            res['cpu_baseline'] = cpu_baseline(a.size)
         print(json.dumps(res))
     if dist:
         dist.destroy_process_group()

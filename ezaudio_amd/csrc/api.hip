@@ -112,6 +112,9 @@ struct ezdit_handle {
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
+    int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
+    hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
+    int opt_dma_spread = 1;                                                               // GEMM: LDS-DMA refill spread over the k-steps
     int opt_row_variant = 1;                                                              // row kernel: 0 = one workgroup per row, 1 = one wave per row
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
@@ -396,6 +399,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.xcd_map = h->opt_xcd_map;
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
+    g.dma_spread = h->opt_dma_spread;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
@@ -551,6 +555,9 @@ int ezdit_destroy(ezdit_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     for (auto& e : h->pf_events) (void)hipEventDestroy(e);
+    if (h->cn_fork) (void)hipEventDestroy(h->cn_fork);
+    if (h->cn_join) (void)hipEventDestroy(h->cn_join);
+    if (h->cn_stream) (void)hipStreamDestroy(h->cn_stream);
     if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
     delete h;
     return EZDIT_OK;
@@ -717,8 +724,11 @@ int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream) {
 // ------------------------------------------------------------------------------------------------------
 // cn_scale multiplies the ControlNet residuals `cn` (conditioning_scale, controlnet.py:313): the fused sampler passes the
 // attached ControlNet's scale, ezdit_forward passes 1 (the caller's residuals are already scaled, as DiTControlNet.forward returns them)
+// cn_ready (nullable): event the residuals `cn` become valid at; waited for right before their first consumer, so a ControlNet
+// forward on another stream overlaps the backbone's in-blocks and mid block (the two chains are independent until then,
+// src/inference_controlnet.py:89-99 + udit.py:345-348).
 static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
-                        const float* const* cn, int n_cn, float cn_scale, float* out, hipStream_t st) {
+                        const float* const* cn, int n_cn, float cn_scale, float* out, hipStream_t st, hipEvent_t cn_ready = nullptr) {
     const bool cn_mode = h->is_cn;  // ControlNet: in-blocks only, then one zero-Linear per skip (controlnet.py:303-315)
     Ctx c{h, st};
     const WsPtrs& p = h->p;
@@ -921,6 +931,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             const float* skip = skips + (size_t)(nhalf - 1 - j) * Mp * D;
             const float* cnp = (cn && n_cn > 0) ? cn[n_cn - 1 - j] : nullptr;
             STOPCHK();
+            if (cnp && cn_ready) { (void)hipStreamWaitEvent(st, cn_ready, 0); cn_ready = nullptr; }   // join the ControlNet stream
             row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
@@ -1075,17 +1086,35 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
     float* pred = h->p.pred;
     const float* cnp[64];
     int n_cn = 0;
+    hipEvent_t cn_ready = nullptr;
     if (h->cn) {  // src/inference_controlnet.py:89-99: ControlNet on the same assembled input, then the backbone with its skips
         ezdit_handle* cn = h->cn;
         if (cn->B != h->B || cn->L != h->L || cn->nhalf != h->nhalf || cn->D != h->D || !cn->ctx_ready || !cn->ts_ready || !cn->cond_ready)
             return fail(EZDIT_E_STATE, "attached ControlNet is not prepared for this shape (bind/context/timesteps/condition)");
         cn->ext_mask_embed = h->w_mask_embed;
-        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, st);
+        hipStream_t cst = st;
+        if (h->opt_cn_overlap && h->debug_stop == 0) {   // fork: the ControlNet chain runs next to the backbone's first half
+            if (!h->cn_stream) {
+                HIPCHK(hipStreamCreateWithFlags(&h->cn_stream, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&h->cn_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&h->cn_join, hipEventDisableTiming));
+            }
+            HIPCHK(hipEventRecord(h->cn_fork, st));
+            HIPCHK(hipStreamWaitEvent(h->cn_stream, h->cn_fork, 0));
+            cst = h->cn_stream;
+        }
+        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, cst);
+        if (cst != st) {
+            HIPCHK(hipEventRecord(h->cn_join, cst));
+            cn_ready = h->cn_join;
+            if (rc0) (void)hipStreamWaitEvent(st, cn_ready, 0);   // never leave the side stream unjoined (capture)
+        }
         if (rc0) return rc0;
         n_cn = cn->nhalf;
         for (int i = 0; i < n_cn; ++i) cnp[i] = cn->p.cnres + (size_t)i * cn->Mp * cn->D;
     }
-    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st);
+    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st, cn_ready);
+    if (rc && cn_ready) (void)hipStreamWaitEvent(st, cn_ready, 0);
     if (rc) return rc;
     CfgDdimArgs a;
     a.pred = pred; a.latents = h->latents; a.noise = h->noise;
@@ -1158,7 +1187,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.dma_spread = h ? h->opt_dma_spread : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
@@ -1218,6 +1247,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "attn_xcd")) h->opt_attn_xcd = value;
     else if (!strcmp(name, "row_variant")) h->opt_row_variant = value;
+    else if (!strcmp(name, "dma_spread")) h->opt_dma_spread = value;
+    else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

@@ -121,6 +121,7 @@ struct GemmArgs {
     int wt;                       // output stores are write-through (sc1)
     HeadNormArgs hn;              // EPI_QKV only (x / ldx / *_col unused)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
+    int dma_spread;               // k_gemm: issue the LDS-DMA pieces of the refill one k-step apart instead of as one burst behind the barrier
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 

@@ -21,6 +21,8 @@
 //     (launch-boundary reduce, see rowops.hip), so no atomics and bitwise-deterministic results.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 // exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
@@ -149,7 +151,9 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int
     return tm < tilesM && tn < tilesN && z < a.splitk;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int EPI>
+// SP: the LDS-DMA pieces of a refill are issued one k-step apart behind that k-step's fragment reads (true) or as one burst
+// right behind the barrier (false; round 1's order, kept for A/B through GemmArgs.dma_spread)
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -205,6 +209,27 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         stage_tile<BM, NT>(gA + a_off, aoff, dst, tid);
         stage_tile<BN, NT>(gW + t * (BK * 2), boff, dst + A_BYTES, tid);
     };
+    // one LDS-DMA instruction (piece p: A pieces first, then W pieces) of K tile t.  Issuing the pieces one k-step apart, behind
+    // the fragment reads of that k-step, keeps the wave out of a burst on the CU's single vector-memory port: in lockstep all
+    // waves otherwise stall at issue together, with their first LDS reads (and so every MFMA of the tile) queued behind the burst.
+    constexpr int LA_ = (BM * 8 + NT - 1) / NT, LB_ = (BN * 8 + NT - 1) / NT, NP_ = LA_ + LB_;
+    auto a_offset = [&](int t) -> long {
+        return a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
+                          : (long)(kb + t) * (BK * 2);
+    };
+    auto stage_piece = [&](int t, long a_off, int p) {
+        char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
+        if (p < LA_) {
+            if ((BM * 8) % NT != 0 && p * NT + tid >= BM * 8) return;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + a_off + aoff[p]),
+                                             (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
+        } else {
+            const int q = p - LA_;
+            if ((BN * 8) % NT != 0 && q * NT + tid >= BN * 8) return;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + (long)t * (BK * 2) + boff[q]),
+                                             (__attribute__((address_space(3))) void*)(dst + A_BYTES + q * NT * 16), 16, 0, 0);
+        }
+    };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
         if (t < nt) stage(t);
@@ -218,7 +243,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     for (int ks = 0; ks < 4; ++ks) foff[ks] = r32 * 128 + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4);
     const int a_base = wm * TM * 128, b_base = A_BYTES + wn * TN * 128;
 
-    for (int t = 0; t < nt; ++t) {
+    // top of a K tile: its LDS-DMA has landed for this wave (counted vmcnt: younger tiles keep flying), then for every wave
+    auto tile_top = [&](int t) {
         // tile t has landed once at most (tiles still allowed in flight) * LPT loads are outstanding
         const int younger = nt - 1 - t;  // tiles issued after t (capped by the prefetch distance NS - 2 here)
         if constexpr (((BM + BN) * 8) % NT != 0) {
@@ -238,35 +264,44 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             wait_tiles<LPT, MAXY>(younger);
         }
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
-        if (t + NS - 1 < nt) stage(t + NS - 1);  // overwrites the slot of tile t-1
+    };
+    // one K tile: 4 k-steps of MFMAs with fragment double buffering (the ds_reads of k-step ks+1 are issued before the MFMAs
+    // of k-step ks); RF: tile t + NS - 1 is staged into the slot of tile t-1 on the way
+    auto ktile = [&](int t, auto RF) {
+        constexpr bool rf = decltype(RF)::value;
         const char* cT = smem + (t % NS) * STAGE_BYTES;
-        {
-            // fragment double buffering: the ds_reads of k-step ks+1 are issued before the MFMAs of k-step ks
-            bf16x8 af[2][FM], bfr[2][FN];
+        long ra_off = 0;
+        if constexpr (rf) {
+            if constexpr (SP) ra_off = a_offset(t + NS - 1); else stage(t + NS - 1);
+        }
+        bf16x8 af[2][FM], bfr[2][FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + a_base + i * 4096);
+        for (int i = 0; i < FM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + a_base + i * 4096);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + b_base + j * 4096);
-            __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+        for (int j = 0; j < FN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + b_base + j * 4096);
+        __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < 3) {
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-                        af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + a_base + i * 4096);
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + b_base + j * 4096);
-                }
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
+                    af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + a_base + i * 4096);
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
-                // pin the order: next k-step's LDS reads first, then this k-step's MFMAs (hides the ds_read latency)
-                if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);
+                for (int j = 0; j < FN; ++j)
+                    bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + b_base + j * 4096);
             }
+            if constexpr (rf && SP) {   // this k-step's share of the refill: pieces [ks * NP / 4, (ks + 1) * NP / 4)
+#pragma unroll
+                for (int p = ks * NP_ / 4; p < (ks + 1) * NP_ / 4; ++p) stage_piece(t + NS - 1, ra_off, p);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+            // pin the order: next k-step's LDS reads first, then this k-step's MFMAs (hides the ds_read latency)
+            if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);
         }
         // keep the accumulators resident in AGPRs across the back edge: without this hipcc copies all of them to VGPRs
         // and back around every barrier (64+ v_accvgpr moves per K tile, and the copy-out waits for the MFMAs to drain)
@@ -274,7 +309,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-    }
+    };
+    // steady state (every tile refills the ring) and drain (the last NS - 1 tiles): two loops, each with ONE straight-line body
+    const int nt_refill = nt - (NS - 1) > 0 ? nt - (NS - 1) : 0;
+    int t = 0;
+    for (; t < nt_refill; ++t) { tile_top(t); ktile(t, std::true_type{}); }
+    for (; t < nt; ++t) { tile_top(t); ktile(t, std::false_type{}); }
 
     // ---- epilogue (lane <-> output element mapping: see store_tile) ----
     const int row_in = lane & 31;
@@ -475,7 +515,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
         EZ_READ_KS(smem, 0);
         EZ_READ_KS(smem, 1);
     }
-    for (int t = 0; t < nt; ++t) {
+    // one LDS-DMA piece of K tile t (A pieces first, then W pieces)
+    auto stage_piece = [&](int t, long a_off, int p) {
+        char* dst = smem + (t & 1) * STAGE_BYTES + wave_u * 1024;
+        if (p < LA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + a_off + aoff[p]),
+                                             (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + (long)t * (BK * 2) + boff[p - LA]),
+                                             (__attribute__((address_space(3))) void*)(dst + A_BYTES + (p - LA) * NT * 16), 16, 0, 0);
+    };
+    // RF: tile t + 2 exists (refill this tile's stage once it is released); NX: tile t + 1 exists (pre-read its k-steps 0, 1)
+    auto ktile = [&](int t, auto RF, auto NX) {
+        constexpr bool rf = decltype(RF)::value, nx = decltype(NX)::value;
         const char* cT = smem + (t & 1) * STAGE_BYTES;
         EZ_MFMA_KS(0, 0, IH);
         __builtin_amdgcn_sched_group_barrier(0x008, IH * FN, 0);
@@ -492,21 +544,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) stage_a(t + 2);          // refill it while k-steps 2, 3 compute
-        EZ_MFMA_KS(2, 0, FM);
-        if (t + 2 < nt) stage_w(t + 2);
-        if (t + 1 < nt) {
-            if (t + 2 < nt) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
+        if constexpr (rf) {
+            // refill it while k-step 2 computes: ONE piece behind each MFMA, so that no wave sits in a burst on the CU's
+            // vector-memory port while its MFMAs (and those of the wave sharing its SIMD, in lockstep) wait
+            const long ra_off = a.conv_cpb ? (long)((kb + t + 2) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t + 2) % a.conv_cpb) * (BK * 2)
+                                           : (long)(kb + t + 2) * (BK * 2);
+            int p = 0;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[2][j], af[2][i], acc[i][j], 0, 0, 0);
+                    // pieces per MFMA: ceil so that all LPT pieces are out by the last MFMA of the k-step
+                    constexpr int PPM = (LPT + FM * FN - 1) / (FM * FN);
+#pragma unroll
+                    for (int q = 0; q < PPM; ++q, ++p)
+                        if (p < LPT) stage_piece(t + 2, ra_off, p);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x010, PPM, 0);
+                }
+        } else {
+            EZ_MFMA_KS(2, 0, FM);
+        }
+        if constexpr (nx) {
+            if constexpr (rf) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
             __builtin_amdgcn_s_barrier();
             const char* nT = smem + ((t + 1) & 1) * STAGE_BYTES;
             EZ_READ_KS(nT, 0);
             EZ_READ_KS(nT, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (FM + FN), 0);
         }
         EZ_MFMA_KS(3, 0, FM);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    };
+    {
+        int t = 0;
+        for (; t + 2 < nt; ++t) ktile(t, std::true_type{}, std::true_type{});     // steady state
+        if (t + 1 < nt) { ktile(t, std::false_type{}, std::true_type{}); ++t; }   // last but one: nothing left to stage
+        if (t < nt) ktile(t, std::false_type{}, std::false_type{});               // last tile
     }
 #undef EZ_READ_KS
 #undef EZ_MFMA_KS
@@ -514,7 +592,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
 }
 
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
-template <int BM, int BN, int WM, int WN, int NS, int EPI>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
@@ -545,11 +623,11 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     if (dev < 0 || dev >= 32) return 1;
     if constexpr (NS > 0) {
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP>), grid, dim3(64 * WM * WN), SMEM, st, a);
     } else {
         if (!attr_set[dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
@@ -561,7 +639,7 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-// tile / pipeline configurations (GemmArgs.tile)
+// tile / pipeline configurations (GemmArgs.tile); ids are stable (round 1's experimental ids 11, 14-24, 26-32 were retired)
 //   id  tile     waves  ring  LDS     note
 //   0   128x128  2x2    4     128 KB
 //   1   128x64   2x2    3      72 KB
@@ -569,75 +647,35 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 //   3   128x64   2x2    4      96 KB
 //   4   128x128  2x2    3      96 KB
 //   5   128x64   2x2    2      48 KB  3 workgroups / CU
-//   6   128x64   4x1    2      48 KB  GEGLU-capable 128x64
+//   6   128x64   4x1    2      48 KB  GEGLU-capable 128x64 (VAE default)
 //   7   128x128  4x2    2      64 KB  8 waves
 //   8   256x128  4x2    2      96 KB  8 waves, wave tile 64x64
-//   9   128x128  4x2    3      96 KB  8 waves
+//   9   128x128  4x2    3      96 KB  8 waves: split-K residual GEMMs at M <= 2048 (dma_spread 0: burst refill, for A/B)
 //   10  256x128  4x2    3     144 KB  8 waves
-//   11  256x256  4x2    2     128 KB  8 waves, wave tile 64x128
 //   12  128x288  4x3    2     104 KB  12 waves: N = 9216 -> 8 x 32 = 256 workgroups at M = 1000 (89 flop/B ingest)
-//   13  128x288  4x3    3     156 KB  same, ring 3 (one whole tile in flight behind the one being consumed)
-//   14  128x64   4x1    3      72 KB  deeper rings for the cold-weight (HBM latency bound) small GEMMs
-//   15  128x64   4x1    4      96 KB
-//   16  64x64    2x2    4      64 KB  288 tiles for N = 1152 at M = 1000 without split-K
-//   17  64x128   2x2    3      72 KB
-//   18  128x64   4x1    6     144 KB  the whole LDS as one deep ring (1 workgroup / CU): ~120 KB of loads in flight
-//   19  64x64    2x2    8     128 KB
-//   20  128x64   4x1    5     120 KB
-//   21  64x64    2x2    5      80 KB  2 workgroups / CU
-//   22  128x128  4x4    3      96 KB  16 waves: a round-1 ingest microbenchmark showed L2 -> LDS ingest per CU scales with the number of
-//   23  128x128  4x4    2      64 KB  waves issuing loads (4: 39, 8: 70, 16: 95 GB/s), not with the depth per wave
-//   24  128x64   4x2    3      72 KB  8 waves
-//   25  128x64   4x2    4      96 KB
-//   26  128x128  4x4    4     128 KB
-//   27  256x128  8x2    2      96 KB  16 waves
-//   28  128x256  4x4    2      96 KB  16 waves
-//   29  128x288  2x3    3     156 KB  6 waves, wave tile 64x96: 40 % fewer LDS fragment reads than the 4x3 form
-//   30  128x288  2x3    2     104 KB
-//   31  128x192  4x2    3     120 KB  8 waves, wave tile 32x96: N = 1152 -> 6 x 8 = 48 tiles, split-K 5 fills 240 CUs
-//   32  128x192  4x2    2      80 KB
+//   13  128x288  4x3    3     156 KB  same, ring 3: GEGLU GEMM at M <= 2048 (dma_spread 0: burst refill)
+//   25  128x64   4x2    4      96 KB  8 waves: small fp32-output GEMMs
 //   40  256x256  2x4    -     128 KB  k_gemm2: two stages with early release (wave tile 128x64), for M > 2048
 //   41  192x256  2x4    -     112 KB  k_gemm2, wave tile 96x64: M = 4000 x N = 9216 -> 21 x 36 = 756 workgroups = 2.95 rounds of 256 CUs
 //   42  256x128  4x2    -      96 KB  k_gemm2, wave tile 64x64
 template <int EPI>
 int launch_e(const GemmArgs& a, hipStream_t st) {
+    const bool sp = a.dma_spread != 0;
     switch (a.tile) {
         case 0: return launch_t<128, 128, 2, 2, 4, EPI>(a, st);
+        case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
         case 2: return launch_t<128, 128, 2, 2, 2, EPI>(a, st);
+        case 3: return launch_t<128, 64, 2, 2, 4, EPI>(a, st);
         case 4: return launch_t<128, 128, 2, 2, 3, EPI>(a, st);
+        case 5: return launch_t<128, 64, 2, 2, 2, EPI>(a, st);
         case 6: return launch_t<128, 64, 4, 1, 2, EPI>(a, st);
         case 7: return launch_t<128, 128, 4, 2, 2, EPI>(a, st);
         case 8: return launch_t<256, 128, 4, 2, 2, EPI>(a, st);
-        case 9: return launch_t<128, 128, 4, 2, 3, EPI>(a, st);
+        case 9: return sp ? launch_t<128, 128, 4, 2, 3, EPI, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false>(a, st);
         case 10: return launch_t<256, 128, 4, 2, 3, EPI>(a, st);
-        case 11: return launch_t<256, 256, 4, 2, 2, EPI>(a, st);
         case 12: return launch_t<128, 288, 4, 3, 2, EPI>(a, st);
-        case 13: return launch_t<128, 288, 4, 3, 3, EPI>(a, st);
-        default: break;
-    }
-    switch (a.tile) {
-        case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
-        case 3: return launch_t<128, 64, 2, 2, 4, EPI>(a, st);
-        case 5: return launch_t<128, 64, 2, 2, 2, EPI>(a, st);
-        case 14: return launch_t<128, 64, 4, 1, 3, EPI>(a, st);
-        case 15: return launch_t<128, 64, 4, 1, 4, EPI>(a, st);
-        case 16: return launch_t<64, 64, 2, 2, 4, EPI>(a, st);
-        case 17: return launch_t<64, 128, 2, 2, 3, EPI>(a, st);
-        case 18: return launch_t<128, 64, 4, 1, 6, EPI>(a, st);
-        case 19: return launch_t<64, 64, 2, 2, 8, EPI>(a, st);
-        case 20: return launch_t<128, 64, 4, 1, 5, EPI>(a, st);
-        case 21: return launch_t<64, 64, 2, 2, 5, EPI>(a, st);
-        case 22: return launch_t<128, 128, 4, 4, 3, EPI>(a, st);
-        case 23: return launch_t<128, 128, 4, 4, 2, EPI>(a, st);
-        case 24: return launch_t<128, 64, 4, 2, 3, EPI>(a, st);
-        case 25: return launch_t<128, 64, 4, 2, 4, EPI>(a, st);
-        case 26: return launch_t<128, 128, 4, 4, 4, EPI>(a, st);
-        case 27: return launch_t<256, 128, 8, 2, 2, EPI>(a, st);
-        case 28: return launch_t<128, 256, 4, 4, 2, EPI>(a, st);
-        case 29: return launch_t<128, 288, 2, 3, 3, EPI>(a, st);
-        case 30: return launch_t<128, 288, 2, 3, 2, EPI>(a, st);
-        case 31: return launch_t<128, 192, 4, 2, 3, EPI>(a, st);
-        case 32: return launch_t<128, 192, 4, 2, 2, EPI>(a, st);
+        case 13: return sp ? launch_t<128, 288, 4, 3, 3, EPI, true>(a, st) : launch_t<128, 288, 4, 3, 3, EPI, false>(a, st);
+        case 25: return sp ? launch_t<128, 64, 4, 2, 4, EPI, true>(a, st) : launch_t<128, 64, 4, 2, 4, EPI, false>(a, st);
         case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
         case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
         case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
@@ -651,7 +689,11 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.K <= 0 || a.K % BK) return 1;
     if (a.epi == EPI_QKV) {   // tiles that hold four whole heads: 64x288 (head_dim 72, 6 waves) or 64x256 (head_dim 64, 8 waves)
-        if (a.hn.dh == 72) return a.tile == 1 ? launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st) : launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
+        const bool sp = a.dma_spread != 0;
+        if (a.hn.dh == 72) {
+            if (a.tile != 1) return launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
+            return sp ? launch_t<64, 288, 1, 9, 3, EPI_QKV, true>(a, st) : launch_t<64, 288, 1, 9, 3, EPI_QKV, false>(a, st);
+        }
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
         return 1;
     }

@@ -212,6 +212,8 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
  *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
  *     wave per row)
+ *   dma_spread 0/1 (GEMM: LDS-DMA refill pieces issued one k-step apart / as one burst), cn_overlap 0/1 (fused sampler: ControlNet
+ *     branch on a side stream next to the backbone's in-blocks)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 

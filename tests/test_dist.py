@@ -171,3 +171,24 @@ def test_inference_shards_prompts_and_gathers_audio_gloo_world2(n):
     # and the batched call is NOT the same as n single calls with the same seed: sample i uses seed + i
     if n > 1:
         assert torch.equal(singles[0], ref[0]) and not torch.equal(singles[1], ref[1])
+
+
+@pytest.mark.gpu
+def test_bench_spawns_two_rccl_ranks_when_two_gpus_are_present():
+    """`python bench.py --gpus 2` -- the form the driver uses -- must start its own ranks (torch.distributed.run on 127.0.0.1),
+    shard the prompts, all-gather over RCCL and print ONE JSON line.  Needs >= 2 GPUs (skipped on the 1-GPU test boxes)."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '10',
+                        '--no-cpu-baseline', '--no-probe'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['distributed']['world_size'] == 2 and res['distributed']['backend'] == 'nccl'
+    assert res['scaling'] == 'weak' and res['value'] > 0
