@@ -72,6 +72,7 @@ PROTOTYPES = {
     'ezdit_test_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    'ezdit_device_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ezdit_last_launch_count': (C.c_int, [C.c_void_p]),
     'ezdit_debug_stop_after': (C.c_int, [C.c_void_p, C.c_int]),
     'ezdit_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

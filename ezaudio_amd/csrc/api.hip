@@ -51,8 +51,8 @@ struct BlkW {   // per-block parameters used on the per-step path (no string / m
     WRef wskip, wqkv, wo, wq2, wo2, w1, w2, zw;
 };
 struct WsPtrs {  // workspace regions used on the per-step path, resolved once at ezdit_bind_workspace
-    int* ints; float *rope_cos, *rope_sin, *coef, *cfgpart;
-    bf16_t* ape; float *h, *skips; bf16_t* u; float* qkv; bf16_t *q, *k, *vt, *ao, *act; float *part, *y, *pred;
+    int* ints; unsigned* sync; float *rope_cos, *rope_sin, *coef, *cfgpart;
+    bf16_t* ape; float *h, *skips; bf16_t *u, *ucat; float* qkv; bf16_t *q, *k, *vt, *ao, *act; float *part, *y, *pred;
     uint8_t* kmask; bf16_t *kc, *vct; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
 };
@@ -112,6 +112,7 @@ struct ezdit_handle {
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
+    int opt_fuse_row = 1;                                                                 // residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch (M <= 2048)
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
     int opt_dma_spread = 1;                                                               // GEMM: LDS-DMA refill spread over the k-steps
@@ -294,7 +295,8 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     const long M = (long)B * L, Mp = rup(M, 128), Lp = rup(L, 128), Lcp = rup(Lc, 128);  // attention stages 64- or 128-key tiles
     const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
     const int nblk = h->nblk;
-    add("ints", 256 * sizeof(int));                       // [0] cur_step, [16..] row_slot (<= 240 rows)
+    add("ints", 256 * sizeof(int));                       // [0] cur_step, [8] CFG arrival counter, [16..] row_slot (<= 240 rows)
+    add("sync", 256 * sizeof(int));                       // [0..127] per-M-tile (arrive, passed) counters of the fused residual GEMM, [128] device error flag
     add("rope_cos", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("rope_sin", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
@@ -312,7 +314,9 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("ape", Mp * h->ldPE * 2);
     add("h", Mp * D * 4);
     add("skips", (size_t)h->nhalf * Mp * D * 4);
-    add("u", Mp * h->ld2D * 2);
+    add("u", Mp * h->ldD * 2);
+    add("ucat", Mp * h->ld2D * 2);                        // LN_2D([x | skip]) of the out-blocks: its own buffer, because the skip GEMM that reads it
+                                                          // writes `u` from inside the same launch (fused row operator)
     add("qkv", Mp * 3 * D * 4);
     add("q", (size_t)B * H * Lp * h->DQK * 2);
     add("k", (size_t)B * H * Lp * h->DQK * 2);
@@ -473,9 +477,9 @@ void resolve_weights(ezdit_handle* h) {
 void resolve_workspace(ezdit_handle* h) {
     WsPtrs& p = h->p;
     memset(&p, 0, sizeof p);
-    p.ints = h->buf<int>("ints"); p.rope_cos = h->buf<float>("rope_cos"); p.rope_sin = h->buf<float>("rope_sin");
+    p.ints = h->buf<int>("ints"); p.sync = h->buf<unsigned>("sync"); p.rope_cos = h->buf<float>("rope_cos"); p.rope_sin = h->buf<float>("rope_sin");
     p.coef = h->buf<float>("coef"); p.cfgpart = h->buf<float>("cfgpart");
-    p.ape = h->buf<bf16_t>("ape"); p.h = h->buf<float>("h"); p.skips = h->buf<float>("skips"); p.u = h->buf<bf16_t>("u");
+    p.ape = h->buf<bf16_t>("ape"); p.h = h->buf<float>("h"); p.skips = h->buf<float>("skips"); p.u = h->buf<bf16_t>("u"); p.ucat = h->buf<bf16_t>("ucat");
     p.qkv = h->buf<float>("qkv"); p.q = h->buf<bf16_t>("q"); p.k = h->buf<bf16_t>("k"); p.vt = h->buf<bf16_t>("vt");
     p.ao = h->buf<bf16_t>("ao"); p.act = h->buf<bf16_t>("act"); p.part = h->buf<float>("part"); p.y = h->buf<float>("y");
     p.pred = h->buf<float>("pred"); p.kmask = h->buf<uint8_t>("kmask"); p.kc = h->buf<bf16_t>("kc"); p.vct = h->buf<bf16_t>("vct");
@@ -724,11 +728,14 @@ int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream) {
 // ------------------------------------------------------------------------------------------------------
 // cn_scale multiplies the ControlNet residuals `cn` (conditioning_scale, controlnet.py:313): the fused sampler passes the
 // attached ControlNet's scale, ezdit_forward passes 1 (the caller's residuals are already scaled, as DiTControlNet.forward returns them)
+// exclusive: no other kernel of this library runs next to this call (false while the ControlNet branch overlaps the backbone): only
+// then may the residual GEMMs wait on each other inside a launch (EPI_PARTIAL_ROW needs all its workgroups co-resident).
 // cn_ready (nullable): event the residuals `cn` become valid at; waited for right before their first consumer, so a ControlNet
 // forward on another stream overlaps the backbone's in-blocks and mid block (the two chains are independent until then,
 // src/inference_controlnet.py:89-99 + udit.py:345-348).
 static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
-                        const float* const* cn, int n_cn, float cn_scale, float* out, hipStream_t st, hipEvent_t cn_ready = nullptr) {
+                        const float* const* cn, int n_cn, float cn_scale, float* out, hipStream_t st, hipEvent_t cn_ready = nullptr,
+                        bool exclusive = true) {
     const bool cn_mode = h->is_cn;  // ControlNet: in-blocks only, then one zero-Linear per skip (controlnet.py:303-315)
     Ctx c{h, st};
     const WsPtrs& p = h->p;
@@ -758,9 +765,9 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, tile_for(h, M, false));
 
     const float* part_src = part;
-    auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
-                   long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
-                   int ld_u) {
+    auto make_row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
+                        long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
+                        int ld_u) {
         RowArgs r;
         memset(&r, 0, sizeof r);
         r.h_in = h_in; r.h_out = h_out;
@@ -770,12 +777,44 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         r.bias = bias; r.gate = gate; r.gate_slot_stride = gate_stride; r.mode = mode;
         r.ln_g = lg; r.ln_c = lc; r.ln_slot_stride = ln_stride;
         r.skip = skip; r.cn = cnp;
-        r.u = lg ? u : nullptr; r.ld_u = ld_u;
+        r.u = lg ? (skip ? p.ucat : u) : nullptr; r.ld_u = ld_u;
         r.M = M; r.D = D; r.L = h->L;
         r.cur_step = cur; r.row_slot = row_slot; r.wt = h->opt_wt;
         r.variant = h->opt_row_variant;
+        return r;
+    };
+    auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
+                   long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
+                   int ld_u) {
+        const RowArgs r = make_row(mode, h_in, h_out, nsplit, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         launch_row(r, st);
         c.launched("k_row");
+    };
+    // residual GEMM + its row operator: out = rowop(A . W^T as split-K slabs).  One launch (the GEMM's workgroups meet at a per-M-tile
+    // counter and then reduce the rows themselves) when the whole grid is co-resident and nothing runs beside it; else two launches.
+    auto resid = [&](const bf16_t* A, int lda, const WRef& w, int mode, const float* h_in, float* h_out, const float* bias, const float* gate,
+                     long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp, int ld_u) {
+        const int K = w.ld;
+        const int s = pick_splitk(h, M, D, K);
+        const long wgs = (long)((M + 127) / 128) * ((D + 127) / 128) * s;
+        const bool fuse = exclusive && h->opt_fuse_row && h->debug_stop == 0 && h->opt_slab_bf16 && M <= 2048 && wgs <= 240 && s <= 4 &&
+                          h->opt_tile_partial == 9 && h->opt_tile_p18 < 0 && h->opt_tile_p36 < 0 && h->opt_tile_p72 < 0;
+        if (!fuse) {
+            const int s2 = gemm_partial(c, A, lda, w, M, D);
+            if (c.bad() || (h->debug_stop > 0 && h->launches >= h->debug_stop)) return;
+            row(mode, h_in, h_out, s2, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
+            return;
+        }
+        GemmArgs g;
+        memset(&g, 0, sizeof g);
+        g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows;
+        g.out = part; g.ldo = D; g.slab_stride = (long)Mp * D;
+        g.M = M; g.N = D; g.K = K; g.splitk = s; g.epi = EPI_PARTIAL_ROW; g.tile = 9;
+        g.xcd_map = h->opt_xcd_map; g.part_bf16 = 1; g.wt = 1; g.dma_spread = h->opt_dma_spread; g.rows_per_b = 1;
+        g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
+        g.row.slab_sc1 = 1;
+        g.panel_cnt = p.sync; g.dev_err = p.sync + 128;
+        c.launched("k_gemm (residual + row)", launch_gemm(g, st));
     };
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
 
@@ -816,9 +855,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            const int s = gemm_partial(c, u, h->ld2D, w.wskip, M, D);
-            STOPCHK();
-            row(2, nullptr, hA, s, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
+            resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
         // ---- self attention (blocks.py:136-141) ----
@@ -853,7 +890,6 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         c.launched("k_attn (self)", launch_attention(at, st));
         STOPCHK();
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
-        int s = 0;
         const bool fuse_res = h->opt_fuse_resid && M <= 2048;   // non-split GEMM with the gated residual in its epilogue
         if (fuse_res) {
             const FuseResid fr{hcur, D, modv(b, 2), mod_slot, cur, row_slot, h->L};
@@ -862,9 +898,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             STOPCHK();
             row(0, hA, nullptr, 0, nullptr, nullptr, 0, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         } else {
-            s = gemm_partial(c, at.out, h->ldD, w.wo, M, D);
-            STOPCHK();
-            row(1, hcur, hA, s, w.bo, modv(b, 2), mod_slot, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
+            resid(at.out, h->ldD, w.wo, 1, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         }
         hcur = hA;
         // ---- cross attention (blocks.py:147-151) ----
@@ -907,36 +941,29 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             STOPCHK();
             row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         } else {
-            s = gemm_partial(c, at.out, h->ldD, w.wo2, M, D);
-            STOPCHK();
-            row(1, hA, hA, s, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+            resid(at.out, h->ldD, w.wo2, 1, hA, hA, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         }
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU,
              h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 13 : h->opt_geglu_big));
         STOPCHK();
-        s = gemm_partial(c, p.act, h->ldI, w.w2, M, D);
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
         const float* b2 = w.b2;
         if (cn_mode && b == nblk - 1) {
-            STOPCHK();
-            row(1, hA, skips + (size_t)b * Mp * D, s, b2, modv(b, 5), mod_slot, nullptr, nullptr, 0, nullptr, nullptr, h->ldD);
+            resid(p.act, h->ldI, w.w2, 1, hA, skips + (size_t)b * Mp * D, b2, modv(b, 5), mod_slot, nullptr, nullptr, 0, nullptr, nullptr, h->ldD);
         } else if (b == nblk - 1) {
             const float* mf = p.modf;
-            STOPCHK();
-            row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, mf, mf + D, 2L * D, nullptr, nullptr, h->ldD);
+            resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, mf, mf + D, 2L * D, nullptr, nullptr, h->ldD);
         } else if (b + 1 > nhalf) {
             const int j = b + 1 - nhalf - 1;  // out block index of the consumer
             const float* skip = skips + (size_t)(nhalf - 1 - j) * Mp * D;
             const float* cnp = (cn && n_cn > 0) ? cn[n_cn - 1 - j] : nullptr;
-            STOPCHK();
             if (cnp && cn_ready) { (void)hipStreamWaitEvent(st, cn_ready, 0); cn_ready = nullptr; }   // join the ControlNet stream
-            row(1, hA, nullptr, s, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
+            resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
-            STOPCHK();
-            row(1, hA, dst, s, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
+            resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
     }
@@ -1073,6 +1100,7 @@ int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noi
     HIPCHK(hipMemcpyAsync(h->buf<float>("coef"), cf.data(), cf.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     launch_set_int(h->p.ints, 0, 0, st);
+    HIPCHK(hipMemsetAsync(h->p.sync, 0, 256 * sizeof(int), st));   // counters of the fused residual GEMM + device error flag
     h->steps_done = 0;
     h->latents = latents; h->noise = noise; h->P = P; h->n_steps = n_steps;
     h->gscale = guidance_scale; h->grescale = guidance_rescale;
@@ -1103,7 +1131,7 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
             HIPCHK(hipStreamWaitEvent(h->cn_stream, h->cn_fork, 0));
             cst = h->cn_stream;
         }
-        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, cst);
+        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, cst, nullptr, cst == st);
         if (cst != st) {
             HIPCHK(hipEventRecord(h->cn_join, cst));
             cn_ready = h->cn_join;
@@ -1113,7 +1141,7 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
         n_cn = cn->nhalf;
         for (int i = 0; i < n_cn; ++i) cnp[i] = cn->p.cnres + (size_t)i * cn->Mp * cn->D;
     }
-    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st, cn_ready);
+    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st, cn_ready, cn_ready == nullptr);
     if (rc && cn_ready) (void)hipStreamWaitEvent(st, cn_ready, 0);
     if (rc) return rc;
     CfgDdimArgs a;
@@ -1225,6 +1253,19 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** ptr, size_t* by
     return EZDIT_OK;
 }
 
+int ezdit_device_status(ezdit_handle* h, ezdit_stream stream) {
+    if (!h || !h->ws) return fail(EZDIT_E_STATE, "bind workspace first");
+    unsigned flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, h->p.sync + 128, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (flag) {
+        (void)hipMemsetAsync(h->p.sync, 0, 256 * sizeof(int), (hipStream_t)stream);
+        return fail(EZDIT_E_HIP, "a fused residual GEMM timed out waiting for its partner workgroups (another spinning kernel was "
+                                 "holding the GPU); results of this call are invalid -- set option fuse_row = 0 when sharing the GPU");
+    }
+    return EZDIT_OK;
+}
+
 int ezdit_last_launch_count(const ezdit_handle* h) { return h ? h->launches : 0; }
 int ezdit_debug_stop_after(ezdit_handle* h, int n) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
@@ -1249,6 +1290,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "row_variant")) h->opt_row_variant = value;
     else if (!strcmp(name, "dma_spread")) h->opt_dma_spread = value;
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
+    else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

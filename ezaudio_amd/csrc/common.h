@@ -49,6 +49,7 @@ enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
     EPI_GEGLU = 2,    // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
+    EPI_PARTIAL_ROW = 4,  // EPI_PARTIAL + the row kernel's work in the same launch (GemmArgs.row), see GemmArgs
     EPI_QKV = 3       // fused q|k|v projection (tile 64 x 4 whole heads: 64x288 for head_dim 72, 64x256 for 64): per-head LayerNorm + RoPE of q / k and
                       // V -> V^T straight into the attention layouts through LDS (GemmArgs.hn); nothing is written to `out`
 };
@@ -95,6 +96,26 @@ struct HeadNormArgs {
     int B, H, L, Lp, dh;
 };
 
+struct RowArgs {
+    // h_new = (mode SET) sum_s part_s + bias | (RES) h_in + gate * (sum_s part_s + bias) | (COPY) h_in
+    const float* h_in; float* h_out;  // h_out nullable (not stored)
+    const float* part; int nsplit; long part_stride; int ld_part;  // strides in elements
+    int part_bf16;                       // slabs hold bf16 instead of fp32
+    const float* bias;
+    const float* gate; long gate_slot_stride;  // gate nullable -> 1; per-slot vector when stride != 0
+    int mode;  // 0 COPY, 1 RES, 2 SET
+    // LN output: u = LN(x) * g + c (per-slot or static vectors), bf16, zero padded to ld_u
+    const float* ln_g; const float* ln_c; long ln_slot_stride;
+    float cn_scale;                      // multiplies cn (conditioning_scale, controlnet.py:313)
+    const float* skip; const float* cn;  // concat mode: x = [h_new | skip (+ cn)], LN over 2D with ln_g/ln_c of length 2D
+    bf16_t* u; int ld_u;
+    int M, D, L;           // rows, width, rows per batch element
+    const int* cur_step; const int* row_slot;
+    int wt;                // output stores are write-through (sc1)
+    int variant;           // 0: one 256-thread workgroup per row; 1: one wave per row (no LDS, no barriers)
+    int slab_sc1;          // the slabs were written write-through by OTHER workgroups of this launch: read them past the L1 (sc1)
+};
+
 struct GemmArgs {
     const bf16_t* A; int lda;   // [M][lda] bf16, row-major, K contiguous, zero padded to K_pad
     const bf16_t* W; int ldw;   // [wrows][ldw] bf16 (nn.Linear layout: out x in), rows >= N zero padded
@@ -122,6 +143,11 @@ struct GemmArgs {
     HeadNormArgs hn;              // EPI_QKV only (x / ldx / *_col unused)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
     int dma_spread;               // k_gemm: issue the LDS-DMA pieces of the refill one k-step apart instead of as one burst behind the barrier
+    // EPI_PARTIAL_ROW: the split-K reduce + bias + gated residual + LayerNorm of `row` runs INSIDE this launch.  The workgroups of
+    // one M tile (N tiles x K splits of them) publish their slabs write-through, meet at an arrival counter, and then each
+    // takes a share of the tile's rows (one wave per row).  panel_cnt: 2 words per M tile (arrive, passed), zero between
+    // launches (the last workgroup through resets them); dev_err: set to 1 if a wait times out (never hang).
+    RowArgs row; unsigned* panel_cnt; unsigned* dev_err;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 
@@ -147,24 +173,6 @@ struct AttnArgs {
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 
-struct RowArgs {
-    // h_new = (mode SET) sum_s part_s + bias | (RES) h_in + gate * (sum_s part_s + bias) | (COPY) h_in
-    const float* h_in; float* h_out;  // h_out nullable (not stored)
-    const float* part; int nsplit; long part_stride; int ld_part;  // strides in elements
-    int part_bf16;                       // slabs hold bf16 instead of fp32
-    const float* bias;
-    const float* gate; long gate_slot_stride;  // gate nullable -> 1; per-slot vector when stride != 0
-    int mode;  // 0 COPY, 1 RES, 2 SET
-    // LN output: u = LN(x) * g + c (per-slot or static vectors), bf16, zero padded to ld_u
-    const float* ln_g; const float* ln_c; long ln_slot_stride;
-    float cn_scale;                      // multiplies cn (conditioning_scale, controlnet.py:313)
-    const float* skip; const float* cn;  // concat mode: x = [h_new | skip (+ cn)], LN over 2D with ln_g/ln_c of length 2D
-    bf16_t* u; int ld_u;
-    int M, D, L;           // rows, width, rows per batch element
-    const int* cur_step; const int* row_slot;
-    int wt;                // output stores are write-through (sc1)
-    int variant;           // 0: one 256-thread workgroup per row; 1: one wave per row (no LDS, no barriers)
-};
 void launch_row(const RowArgs& a, hipStream_t st);
 
 void launch_headnorm(const HeadNormArgs& a, hipStream_t st);

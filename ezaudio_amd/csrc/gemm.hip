@@ -20,6 +20,7 @@
 //   * split-K (blockIdx.z) writes raw fp32 slabs; the row kernel that follows reduces them
 //     (launch-boundary reduce, see rowops.hip), so no atomics and bitwise-deterministic results.
 #include "common.h"
+#include "rowbody.h"
 
 #include <type_traits>
 
@@ -417,6 +418,44 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                 }
             }
         }
+    } else if constexpr (EPI == EPI_PARTIAL_ROW) {
+        // ---- split-K slabs + the row operator in ONE launch (replaces the k_row launch that used to follow every residual GEMM) ----
+        // Hand-off protocol (placement independent, cdna_hip_programming.md Guideline 16): slabs are stored write-through (sc1), every
+        // storing wave drains its stores, ONE lane arrives on the M tile's counter; ONE lane polls it relaxed and performs ONE agent-scope
+        // acquire; then each workgroup reduces its share of the tile's rows, reading the other workgroups' slabs past the L1.
+        // All workgroups of the launch are co-resident (the launcher refuses grids above one workgroup per CU), so the wait cannot
+        // deadlock on this kernel's own dispatch; it is bounded anyway and reports through dev_err.
+        store_tile<FM, FN, TM, TN, EPI_PARTIAL>(a, acc, row0, col0, wm, wn, lane, z);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned total = (unsigned)(tilesN * a.splitk);
+        unsigned* cnt = a.panel_cnt + 2 * tm;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 22)) {   // ~0.5 s: another spinning kernel holds the CUs our partners need
+                    __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // the last workgroup through the wait re-arms the counters for the next launch (nobody polls them any more)
+            const unsigned passed = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (passed == total - 1) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        const int rows = a.M - row0 < BM ? a.M - row0 : BM;
+        const int first = tn * a.splitk + z;   // this workgroup's position among the `total` workgroups of the M tile
+        if (a.row.skip) {
+            for (int r = first + wave_u * (int)total; r < rows; r += WM * WN * (int)total) row_wave<true>(a.row, row0 + r, lane);
+        } else {
+            for (int r = first + wave_u * (int)total; r < rows; r += WM * WN * (int)total) row_wave<false>(a.row, row0 + r, lane);
+        }
     } else {
         store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
     }
@@ -696,6 +735,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         }
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
         return 1;
+    }
+    if (a.epi == EPI_PARTIAL_ROW) {
+        // co-residency: one workgroup per CU (96 KB of LDS each), every workgroup of the grid must be able to run at once
+        const long wgs = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.splitk;
+        if (a.tile != 9 || !a.part_bf16 || !a.panel_cnt || !a.dev_err || wgs > 240 || a.row.nsplit != a.splitk || a.row.nsplit > RW_MAXS ||
+            a.row.D > RW * 256 || (a.row.D & 3))
+            return 1;
+        return a.dma_spread ? launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);
     if (a.epi == EPI_PARTIAL) return launch_e<EPI_PARTIAL>(a, st);

@@ -87,6 +87,8 @@ class LatentSampler:
         return self.latents
 
     def finish(self):
+        """Wait for the sampler stream and raise if the device reported a failure (a timed-out in-launch wait)."""
+        _lib.check(self.unet.lib.ezdit_device_status(self.unet._h, C.c_void_p(self.stream.cuda_stream)))
         torch.cuda.current_stream(self.unet.device).wait_stream(self.stream)
         return self.latents
 

@@ -199,6 +199,10 @@ int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, 
                          ezdit_stream stream);
 /* copy an internal fp32/bf16 buffer (by name, e.g. "h", "u", "q", "k", "vt", "mod") for debugging. */
 int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t* bytes);
+/* Synchronises `stream` and reports device-side failures of the calls issued so far: the residual GEMMs reduce their split-K slabs
+ * inside the launch (option fuse_row), which makes their workgroups wait for each other; that is safe when nothing else spins on
+ * the GPU, and bounded (about 0.5 s) otherwise -- a timed-out wait is reported here as EZDIT_E_HIP instead of hanging. */
+int ezdit_device_status(ezdit_handle* h, ezdit_stream stream);
 /* number of kernel launches issued by the last ezdit_forward (host counter). */
 int ezdit_last_launch_count(const ezdit_handle* h);
 /* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
@@ -214,6 +218,7 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *     wave per row)
  *   dma_spread 0/1 (GEMM: LDS-DMA refill pieces issued one k-step apart / as one burst), cn_overlap 0/1 (fused sampler: ControlNet
  *     branch on a side stream next to the backbone's in-blocks)
+ *   fuse_row 0/1 (M <= 2048: residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 

@@ -405,7 +405,7 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1))])
+@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -418,12 +418,30 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
         assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
         outs.append(_forward(m, inp, 499, kw).cpu().numpy())
     assert lib.ezdit_set_option(m._h, opt.encode(), 1) == 0
-    if opt in ('attn_xcd', 'dma_spread'):   # placement / issue order only: bitwise identical
+    if opt in ('attn_xcd', 'dma_spread', 'fuse_row'):   # placement / issue order / launch structure only: bitwise identical
         np.testing.assert_array_equal(outs[0], outs[1])
     else:
         assert rel_l2(outs[0], outs[1]) < 1e-2
         for o in outs:
             assert rel_l2(o, g['pred_t499']) < REL_TOL
+
+
+def test_fused_residual_gemm_handoff_is_stable_under_repetition(lib, dev):
+    """The residual GEMMs of the XL model exchange split-K slabs between workgroups INSIDE a launch (write-through stores, arrival
+    counter, one acquire).  A broken hand-off shows as rare stale rows, so: the shipped XL shape (88 hand-offs per forward), many
+    repetitions, every output bit compared with the two-launch path, then the device error flag."""
+    cfg, sd, inp, kw, g, meta = golden_case('xl')
+    m = get_model('xl', meta['seed_w'])
+    assert lib.ezdit_set_option(m._h, b'fuse_row', 0) == 0
+    ref = _forward(m, inp, 499, kw).clone()
+    n_unfused = m.last_launch_count
+    assert lib.ezdit_set_option(m._h, b'fuse_row', 1) == 0
+    for rep in range(25):
+        out = _forward(m, inp, 499, kw)
+        assert torch.equal(out, ref), rep
+    assert m.last_launch_count == n_unfused - (3 * 29 + 14)      # one row-kernel launch less per residual GEMM
+    assert lib.ezdit_device_status(m._h, None) == 0
+    assert rel_l2(ref.cpu().numpy(), g['pred_t499']) < REL_TOL
 
 
 def test_unsupported_kernel_configuration_is_an_error_not_a_silent_skip(lib, dev):
