@@ -103,7 +103,9 @@ struct ezdit_handle {
     // tuning knobs (M <= 2048 rows); defaults from tools/bench_cold.py + tools/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
     // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
-    int opt_tile_partial_big = 5, opt_tile_f32_big = 10, opt_geglu_big = 13, opt_split_big = 0;  // M > 2048 rows (batched prompts)
+    // M > 2048 rows (batched prompts): the large-tile kernel (k_gemm2, 256x256) for the residual and GEGLU GEMMs; split_big 0 = as
+    // many K splits as keep the grid within one round of the 256 CUs (measured on MI355X at M = 4000: -2.6 % per step vs round 1's tiles)
+    int opt_tile_partial_big = 40, opt_tile_f32_big = 10, opt_geglu_big = 40, opt_split_big = 0;
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
     int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
@@ -112,10 +114,16 @@ struct ezdit_handle {
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
-    int opt_fuse_row = 1;                                                                 // residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch (M <= 2048)
+    int opt_fuse_flags = 0;
+    // measured on MI355X (XL, one prompt): 5.00 ms/step fused vs 4.46 ms with the separate row kernel (+5.4 us per hand-off: the
+    // write-through slab stores, the counter round trip and the acquire cost more than the 1.6 us kernel boundary they replace;
+    // release-fence, plain-load and coarse-poll variants are no better) -> kept as an option, OFF by default
+    int opt_fuse_row = 0;                                                                 // residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch (M <= 2048)
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
-    int opt_dma_spread = 1;                                                               // GEMM: LDS-DMA refill spread over the k-steps
+    // GEMM: LDS-DMA refill pieces issued one k-step apart (1) or as one burst behind the barrier (0).  In situ on MI355X the two are
+    // within noise (XL 4.546 vs 4.529 ms, L 3.592 vs 3.576 ms per step): the K loop is not bound by vector-memory issue.  Burst kept.
+    int opt_dma_spread = 0;
     int opt_row_variant = 1;                                                              // row kernel: 0 = one workgroup per row, 1 = one wave per row
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
@@ -296,7 +304,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
     const int nblk = h->nblk;
     add("ints", 256 * sizeof(int));                       // [0] cur_step, [8] CFG arrival counter, [16..] row_slot (<= 240 rows)
-    add("sync", 256 * sizeof(int));                       // [0..127] per-M-tile (arrive, passed) counters of the fused residual GEMM, [128] device error flag
+    add("sync", 1024 * sizeof(int));                      // per-M-tile (arrive, passed) counters of the fused residual GEMM, one 128-byte line each (<= 16 tiles), [1000] device error flag
     add("rope_cos", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("rope_sin", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
@@ -426,6 +434,12 @@ int pick_splitk(const ezdit_handle* h, int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = K / 64;
     if (M > 2048 && h->opt_split_big > 0) return h->opt_split_big < nk ? h->opt_split_big : nk;
+    if (M > 2048 && h->opt_tile_partial_big == 40) {   // 256 x 256 tiles: fill one round of CUs, at most 4 slabs
+        const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
+        int s = 256 / t256;
+        s = s < 1 ? 1 : s > 4 ? 4 : s;
+        return s < nk ? s : nk;
+    }
     if (tiles >= 256) return 1;
     int s = nk >= 72 ? h->opt_split72 : nk >= 36 ? h->opt_split36 : h->opt_split18;  // fewer slabs = less row-kernel traffic
     if (s > nk) s = nk;
@@ -813,7 +827,9 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.xcd_map = h->opt_xcd_map; g.part_bf16 = 1; g.wt = 1; g.dma_spread = h->opt_dma_spread; g.rows_per_b = 1;
         g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         g.row.slab_sc1 = 1;
-        g.panel_cnt = p.sync; g.dev_err = p.sync + 128;
+        g.panel_cnt = p.sync; g.dev_err = p.sync + 1000; g.fuse_flags = h->opt_fuse_flags;
+        if (g.fuse_flags & 1) g.wt = 0;
+        if (g.fuse_flags & 2) g.row.slab_sc1 = 0;
         c.launched("k_gemm (residual + row)", launch_gemm(g, st));
     };
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
@@ -1100,7 +1116,7 @@ int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noi
     HIPCHK(hipMemcpyAsync(h->buf<float>("coef"), cf.data(), cf.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     launch_set_int(h->p.ints, 0, 0, st);
-    HIPCHK(hipMemsetAsync(h->p.sync, 0, 256 * sizeof(int), st));   // counters of the fused residual GEMM + device error flag
+    HIPCHK(hipMemsetAsync(h->p.sync, 0, 1024 * sizeof(int), st));   // counters of the fused residual GEMM + device error flag
     h->steps_done = 0;
     h->latents = latents; h->noise = noise; h->P = P; h->n_steps = n_steps;
     h->gscale = guidance_scale; h->grescale = guidance_rescale;
@@ -1215,7 +1231,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.dma_spread = h ? h->opt_dma_spread : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.dma_spread = h ? h->opt_dma_spread : 0; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
@@ -1256,10 +1272,10 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** ptr, size_t* by
 int ezdit_device_status(ezdit_handle* h, ezdit_stream stream) {
     if (!h || !h->ws) return fail(EZDIT_E_STATE, "bind workspace first");
     unsigned flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, h->p.sync + 128, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(&flag, h->p.sync + 1000, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (flag) {
-        (void)hipMemsetAsync(h->p.sync, 0, 256 * sizeof(int), (hipStream_t)stream);
+        (void)hipMemsetAsync(h->p.sync, 0, 1024 * sizeof(int), (hipStream_t)stream);
         return fail(EZDIT_E_HIP, "a fused residual GEMM timed out waiting for its partner workgroups (another spinning kernel was "
                                  "holding the GPU); results of this call are invalid -- set option fuse_row = 0 when sharing the GPU");
     }
@@ -1291,6 +1307,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "dma_spread")) h->opt_dma_spread = value;
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
     else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
+    else if (!strcmp(name, "fuse_flags")) h->opt_fuse_flags = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

@@ -145,9 +145,9 @@ struct GemmArgs {
     int dma_spread;               // k_gemm: issue the LDS-DMA pieces of the refill one k-step apart instead of as one burst behind the barrier
     // EPI_PARTIAL_ROW: the split-K reduce + bias + gated residual + LayerNorm of `row` runs INSIDE this launch.  The workgroups of
     // one M tile (N tiles x K splits of them) publish their slabs write-through, meet at an arrival counter, and then each
-    // takes a share of the tile's rows (one wave per row).  panel_cnt: 2 words per M tile (arrive, passed), zero between
-    // launches (the last workgroup through resets them); dev_err: set to 1 if a wait times out (never hang).
-    RowArgs row; unsigned* panel_cnt; unsigned* dev_err;
+    // takes a share of the tile's rows (one wave per row).  panel_cnt: 2 words per M tile (arrive, passed), zero between launches, 32 words apart;
+    // (the last workgroup through resets them); dev_err: set to 1 if a wait times out (never hang).
+    RowArgs row; unsigned* panel_cnt; unsigned* dev_err; int fuse_flags;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 

@@ -425,16 +425,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         // acquire; then each workgroup reduces its share of the tile's rows, reading the other workgroups' slabs past the L1.
         // All workgroups of the launch are co-resident (the launcher refuses grids above one workgroup per CU), so the wait cannot
         // deadlock on this kernel's own dispatch; it is bounded anyway and reports through dev_err.
+        // fuse_flags (A/B): 1 = plain slab stores + ONE agent-scope release per workgroup instead of write-through stores;
+        //                   2 = plain slab loads behind the acquire instead of sc1 loads; 4 = coarser poll (s_sleep 32)
         store_tile<FM, FN, TM, TN, EPI_PARTIAL>(a, acc, row0, col0, wm, wn, lane, z);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const unsigned total = (unsigned)(tilesN * a.splitk);
-        unsigned* cnt = a.panel_cnt + 2 * tm;
+        unsigned* cnt = a.panel_cnt + 32 * tm;   // one 128-byte line per M tile: arrivals and pollers of different tiles never share a line
         if (tid == 0) {
+            if (a.fuse_flags & 1) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // hipcc may drop the wait behind buffer_wbl2 (ROCm 7.2)
+            }
             __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned spins = 0;
             while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-                __builtin_amdgcn_s_sleep(4);
+                if (a.fuse_flags & 4) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
                 if (++spins > (1u << 22)) {   // ~0.5 s: another spinning kernel holds the CUs our partners need
                     __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
