@@ -218,6 +218,10 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='name=value tuning knob passed to ezdit_set_option')
     ap.add_argument('--prefetch', action='store_true')
     ap.add_argument('--controlnet', action='store_true', help='BASELINE config #5: add an energy ControlNet of the same width')
+    ap.add_argument('--dist-backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI, the real thing) or 'gloo' "
+                                                           '(test mode: latents are gathered through host memory)')
+    ap.add_argument('--shared-device', action='store_true',
+                    help='test mode for 1-GPU boxes: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--budget', type=float, default=20.0, help=argparse.SUPPRESS)
@@ -236,13 +240,17 @@ def main():
             env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
             raise SystemExit(subprocess.call(relaunch_command(a.gpus, sys.argv[1:]), env=env))
         a.gpus = world
+    if a.shared_device:
+        if a.dist_backend != 'gloo':
+            raise SystemExit('--shared-device needs --dist-backend gloo')
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         from ezaudio_amd.dist import init_from_env
-        init_from_env('nccl', dev)
+        init_from_env(a.dist_backend, dev if a.dist_backend == 'nccl' else None)
 
     from ezaudio_amd import MaskDiT
     from ezaudio_amd.sampler import LatentSampler
@@ -324,7 +332,7 @@ def main():
     lat = smp.finish()
     if dist:  # the only collective of the job: gather the finished latents (256 KB per sample)
         from ezaudio_amd.dist import gather_samples
-        all_lat = gather_samples(lat, P * world)
+        all_lat = gather_samples(lat if a.dist_backend == 'nccl' else lat.cpu(), P * world)
         assert all_lat.shape[0] == P * world
     torch.cuda.synchronize()
     if dist:
@@ -333,7 +341,7 @@ def main():
     dt = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
     if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if a.dist_backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(lat).all(), 'non-finite latents'

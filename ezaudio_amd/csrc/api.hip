@@ -113,8 +113,12 @@ struct ezdit_handle {
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
+    // self-attention over 129..512 keys: all K tiles requested at once, exact softmax (k_attn2).  Measured equal to the flash loop
+    // on MI355X (XL 4.504 vs 4.484 ms, L 3.540 vs 3.555 ms per step): the kernel is not bound by its tile loop.  Option, off.
+    int opt_attn_two_pass = 0;
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
     int opt_fuse_flags = 0;
+    int opt_gemm_debug = 0;   // k_gemm2 experiments: bit 0 = s_setprio(1) over the first MFMA cluster of a K tile, bit 1 = static priority for waves 4-7
     // measured on MI355X (XL, one prompt): 5.00 ms/step fused vs 4.46 ms with the separate row kernel (+5.4 us per hand-off: the
     // write-through slab stores, the counter round trip and the acquire cost more than the 1.6 us kernel boundary they replace;
     // release-fence, plain-load and coarse-poll variants are no better) -> kept as an option, OFF by default
@@ -412,6 +416,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
     g.dma_spread = h->opt_dma_spread;
+    g.debug = h->opt_gemm_debug;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
@@ -899,7 +904,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         AttnArgs at;
         memset(&at, 0, sizeof at);
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
-        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd;
+        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd; at.two_pass = h->opt_attn_two_pass;
         at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
@@ -1250,7 +1255,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     AttnArgs a;
     memset(&a, 0, sizeof a);
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
-    a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd;
+    a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd; a.two_pass = h->opt_attn_two_pass;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
     (void)hipGetLastError();
@@ -1303,11 +1308,13 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "attn_xcd")) h->opt_attn_xcd = value;
+    else if (!strcmp(name, "attn_two_pass")) h->opt_attn_two_pass = value;
     else if (!strcmp(name, "row_variant")) h->opt_row_variant = value;
     else if (!strcmp(name, "dma_spread")) h->opt_dma_spread = value;
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
     else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
     else if (!strcmp(name, "fuse_flags")) h->opt_fuse_flags = value;
+    else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

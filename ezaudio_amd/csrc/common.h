@@ -170,6 +170,7 @@ struct AttnArgs {
     // run on ONE XCD (hardware deals workgroup i to XCD i % 8), so each pair's K / V^T is fetched into exactly one L2.
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
+    int two_pass;               // allow the two-pass form (k_attn2) where it applies: 128 < Lk <= 512 keys, plain q operand, 8 waves
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 

@@ -570,10 +570,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + (long)t * (BK * 2) + boff[p - LA]),
                                              (__attribute__((address_space(3))) void*)(dst + A_BYTES + (p - LA) * NT * 16), 16, 0, 0);
     };
+    const bool prio = (a.debug & 1) != 0;
+    if ((a.debug & 2) && wave_u >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half (T5 static form)
     // RF: tile t + 2 exists (refill this tile's stage once it is released); NX: tile t + 1 exists (pre-read its k-steps 0, 1)
     auto ktile = [&](int t, auto RF, auto NX) {
         constexpr bool rf = decltype(RF)::value, nx = decltype(NX)::value;
         const char* cT = smem + (t & 1) * STAGE_BYTES;
+        if (prio) __builtin_amdgcn_s_setprio(1);
         EZ_MFMA_KS(0, 0, IH);
         __builtin_amdgcn_sched_group_barrier(0x008, IH * FN, 0);
         EZ_READ_KS(cT, 2);
@@ -582,6 +585,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
         EZ_MFMA_KS(0, IH, FM);
         EZ_MFMA_KS(1, 0, FM);
         __builtin_amdgcn_sched_group_barrier(0x008, (FM - IH) * FN + FM * FN, 0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
         // every fragment of K tile t is in registers: its stage is dead for this wave and, after the barrier, for all of them
         // (sched_barrier on BOTH sides: hipcc otherwise sinks the register-only MFMAs below the inline-asm wait, which then
         // drains the LDS reads right after they were issued)

@@ -214,6 +214,7 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1 (write-through stores)
  *   fuse_qkv 0/1 (head-norm + RoPE + V^T in the QKV GEMM epilogue), qkv_waves9 0/1, fuse_q2 0/1/2 (cross-attention computes its
  *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
+ *   attn_two_pass 0/1 (self-attention over 129..512 keys: all K tiles requested at once, exact softmax, V^T streamed under it)
  *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
  *     wave per row)
  *   dma_spread 0/1 (GEMM: LDS-DMA refill pieces issued one k-step apart / as one burst), cn_overlap 0/1 (fused sampler: ControlNet

@@ -192,3 +192,24 @@ def test_bench_spawns_two_rccl_ranks_when_two_gpus_are_present():
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['distributed']['world_size'] == 2 and res['distributed']['backend'] == 'nccl'
     assert res['scaling'] == 'weak' and res['value'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_on_one_gpu_over_gloo():
+    """The whole N > 1 path of bench.py -- self re-launch under torch.distributed.run on 127.0.0.1, prompt sharding, the timed loop on
+    every rank, the final gather, max-over-ranks timing, ONE JSON line from rank 0 -- exercised on a 1-GPU box: both ranks share
+    cuda:0 and the collectives go through gloo (RCCL refuses two ranks on one device; the nccl form is the test above)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--size', 'l', '--steps', '20', '--warmup', '10',
+                        '--no-cpu-baseline', '--no-probe', '--dist-backend', 'gloo', '--shared-device'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['distributed']['world_size'] == 2 and res['distributed']['backend'] == 'gloo'
+    assert res['scaling'] == 'weak' and res['value'] > 0 and res['config']['prompts_per_gpu'] == 1

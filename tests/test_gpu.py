@@ -139,7 +139,7 @@ def test_gemm_geglu_epilogue(lib, dev, tile):
 @pytest.mark.parametrize('nkh', [2, 4])   # 64-key tiles / 4 waves and 128-key tiles / 8 waves
 @pytest.mark.parametrize('size,Lq,Lk,masked', [('xs', 96, 96, False), ('xs64', 96, 96, False), ('xs', 500, 100, True), ('xs', 64, 20, True),
                                                ('xs64', 500, 100, True), ('xs', 500, 500, False), ('xs64', 77, 500, False),
-                                               ('xs', 300, 300, False)])
+                                               ('xs', 300, 300, False), ('xs', 500, 129, True), ('xs64', 130, 512, False), ('xs', 64, 385, True)])
 def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked, nkh):
     m = get_model(size, 1)
     cfg = model_config(size)
@@ -166,18 +166,23 @@ def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked, nkh
     out = torch.zeros(B * Lq, ldD, dtype=torch.bfloat16, device=dev)
     md = mask.to(torch.uint8).to(dev)
     qd, kd, vd = qp.to(dev), kp.to(dev), vt.to(dev)   # keep the device tensors alive across the launch
-    rc = lib.ezdit_test_attention(m._h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
-                                  md.data_ptr() if masked else None, out.data_ptr(), B, Lq, Lk, Lqp, Lkp, None)
-    assert rc == 0
-    torch.cuda.synchronize()
-    assert lib.ezdit_set_option(m._h, b'attn_nkh', 0) == 0
     s = (q.double() @ k.double().transpose(2, 3)) * dh ** -0.5
     s = s.masked_fill(~mask[:, None, None, :], float('-inf'))
     ref = (torch.softmax(s, -1) @ v.double()).transpose(1, 2).reshape(B * Lq, D)
-    got = out.float().cpu()[:, :D]
-    assert torch.isfinite(got).all()
-    assert rel_l2(got.numpy(), ref.numpy()) < 1.2e-2  # P and O rounded to bf16
-    assert (got.double() - ref).abs().max().item() < 0.06
+    # two_pass 1: keys in (128, 512] with 8 waves take the two-pass kernel (all K tiles at once, exact softmax); 0: the flash loop
+    for two_pass in (1, 0):
+        assert lib.ezdit_set_option(m._h, b'attn_two_pass', two_pass) == 0
+        out.zero_()
+        rc = lib.ezdit_test_attention(m._h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                      md.data_ptr() if masked else None, out.data_ptr(), B, Lq, Lk, Lqp, Lkp, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = out.float().cpu()[:, :D]
+        assert torch.isfinite(got).all()
+        assert rel_l2(got.numpy(), ref.numpy()) < 1.2e-2, two_pass  # P and O rounded to bf16
+        assert (got.double() - ref).abs().max().item() < 0.06, two_pass
+    assert lib.ezdit_set_option(m._h, b'attn_two_pass', 0) == 0
+    assert lib.ezdit_set_option(m._h, b'attn_nkh', 0) == 0
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -405,7 +410,8 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1))])
+@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1)),
+                                        ('attn_two_pass', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -417,10 +423,10 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     for v in values:
         assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
         outs.append(_forward(m, inp, 499, kw).cpu().numpy())
-    assert lib.ezdit_set_option(m._h, opt.encode(), 0 if opt in ('fuse_row', 'dma_spread') else 1) == 0   # shipped defaults
+    assert lib.ezdit_set_option(m._h, opt.encode(), 0 if opt in ('fuse_row', 'dma_spread', 'attn_two_pass') else 1) == 0   # shipped defaults
     if opt in ('attn_xcd', 'dma_spread', 'fuse_row'):   # placement / issue order / launch structure only: bitwise identical
         np.testing.assert_array_equal(outs[0], outs[1])
-    else:
+    else:   # row_variant, attn_two_pass: same math, different rounding points
         assert rel_l2(outs[0], outs[1]) < 1e-2
         for o in outs:
             assert rel_l2(o, g['pred_t499']) < REL_TOL
