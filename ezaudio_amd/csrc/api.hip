@@ -1238,7 +1238,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.slab_stride = (long)rup(M, 128) * ldo;
     g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.dma_spread = h ? h->opt_dma_spread : 0; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
-    g.debug = variant / 1000; variant %= 1000;   // 1000 + v: stage only, 2000 + v: compute only (perf probes)
+    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: k_gemm2 experiment bits (GemmArgs.debug)
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.epi > EPI_GEGLU || g.tile > 63) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;

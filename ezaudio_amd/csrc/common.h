@@ -127,7 +127,7 @@ struct GemmArgs {
     int splitk;                 // >= 1 (EPI_PARTIAL only)
     int epi;
     int tile;                   // tile / pipeline configuration, see gemm.hip
-    int debug;                  // unused (kept for ABI stability of the probe hook)
+    int debug;                  // k_gemm2 experiment bits: 1 = s_setprio(1) over the first MFMA cluster of a K tile, 2 = static priority for waves 4-7
     // convolution-as-GEMM addressing (VAE decoder): K tile t reads A at byte offset (t / conv_cpb) * conv_tap_bytes +
     // (t % conv_cpb) * 128, i.e. tap t/conv_cpb is the SAME activation rows shifted by a fixed number of rows.
     // conv_cpb = 0: plain GEMM (offset t * 128).

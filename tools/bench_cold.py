@@ -70,11 +70,9 @@ def run(name, configs, iters=192, pad=0):
 
 which = [a for a in sys.argv[1:] if not a.startswith('pad=') and a != 'warm'] or ['proj', 'mlpout', 'qkv', 'q2', 'skip', 'geglu']
 pads = [int(a[4:]) for a in sys.argv[1:] if a.startswith('pad=')] or [0]
-W16 = [(22, 1), (22, 2), (22, 3), (23, 2), (23, 3), (26, 3), (26, 2), (24, 1), (24, 2), (25, 1), (25, 2), (24, 3)]
-SHORT = {'proj': [(9, 3), (31, 3), (31, 4), (31, 5), (32, 4), (32, 5)], 'xproj': [(5, 2), (9, 3), (4, 3), (15, 1)] + W16, 'skip': [(9, 3), (31, 4), (31, 5), (31, 3), (32, 5)], 'xskip': [(5, 2), (9, 3), (4, 3)] + W16 + [(22, 4), (26, 4)],
-         'mlpout': [(9, 3), (31, 4), (31, 5), (31, 6), (32, 5), (31, 3)], 'xmlpout': [(5, 4), (9, 3), (4, 3)] + W16 + [(22, 4), (26, 4), (27, 6), (27, 4)],
-         'qkv': [(14, 1), (9, 1), (22, 1), (23, 1), (26, 1), (24, 1), (25, 1), (27, 1), (28, 1)], 'q2': [(14, 1), (15, 1), (22, 1), (26, 1), (24, 1), (25, 1)],
-         'geglu': [(12, 1), (13, 1), (29, 1), (30, 1), (9, 1)]}
+# (tile id, split-K) candidates per shape; ids as in csrc/gemm.hip (round 1's experimental ids 11, 14-24, 26-32 are retired)
+SHORT = {'proj': [(9, 3), (9, 2), (5, 2), (4, 3), (7, 3)], 'skip': [(9, 3), (9, 2), (4, 3), (7, 3)], 'mlpout': [(9, 3), (9, 4), (5, 4), (4, 3)],
+         'qkv': [(9, 1), (10, 1), (25, 1), (8, 1)], 'q2': [(25, 1), (9, 1), (3, 1)], 'geglu': [(12, 1), (13, 1), (9, 1)]}
 for w in which:
     for pad in pads:
         run(w, SHORT[w], pad=pad)

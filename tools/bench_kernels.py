@@ -1,5 +1,5 @@
 """GPU micro-benchmarks of the kernel families through the C ABI test hooks (not a pytest).
-    python tools/bench_kernels.py gemm|attn|all"""
+    python tools/bench_kernels.py gemm|attn|all      (large-tile kernel: tools/bench_gemm2.py)"""
 import ctypes as C
 import os
 import sys
@@ -78,31 +78,6 @@ def bench_attn(lib):
         lib.ezdit_destroy(h)
 
 
-def probe_gemm(lib):
-    """Where does the GEMM time go?  full kernel vs stage-only (global -> LDS, no MFMA) vs compute-only (no loads)."""
-    dev = 'cuda'
-    names = {2: '128x128 r2', 5: '128x64 r2', 6: '128x64 4x1 r2', 7: '128x128 8w r2', 8: '256x128 8w r2', 10: '256x128 8w r3',
-             11: '256x256 8w r2', 0: '128x128 r4'}
-    for name, M, N, K in [('geglu-in', 1000, 9216, 1152), ('geglu-in B8', 4000, 9216, 1152), ('qkv', 1000, 3456, 1152), ('proj', 1000, 1152, 1152)]:
-        A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-        W = (torch.randn((N + 255) // 256 * 256, K, device=dev) / K ** 0.5).to(torch.bfloat16)
-        out = torch.empty(((M + 255) // 256 * 256) * N, device=dev)
-        fl = 2.0 * M * N * K
-        for tile in (5, 6, 2, 7, 8, 10, 11, 0):
-            r = []
-            for dbg in (0, 1, 2):
-                v = dbg * 1000 + tile * 4 + 0
-                us = timeit(lambda: lib.ezdit_test_gemm(None, v, A.data_ptr(), K, W.data_ptr(), K, None, out.data_ptr(), N, M, N, K, 1, None))
-                r.append(us)
-            ctas = ((M + (255 if tile in (8, 10, 11) else 127)) // (256 if tile in (8, 10, 11) else 128)) * \
-                   ((N + (63 if tile in (5, 6) else 255 if tile == 11 else 127)) // (64 if tile in (5, 6) else 256 if tile == 11 else 128))
-            bm = 256 if tile in (8, 10, 11) else 128
-            bn = 64 if tile in (5, 6) else 256 if tile == 11 else 128
-            traffic = ctas * (bm + bn) * K * 2
-            print(f'{name:12s} {names[tile]:15s} ctas {ctas:5d}: full {r[0]:6.1f}us ({fl/r[0]/1e6:4.0f} TF) | stage-only {r[1]:6.1f}us '
-                  f'({traffic/r[1]/1e6:5.1f} TB/s L2->LDS) | compute-only {r[2]:6.1f}us ({fl/r[2]/1e6:4.0f} TF)')
-
-
 if __name__ == '__main__':
     build.build(verbose=False)
     lib = _lib.load()
@@ -111,5 +86,3 @@ if __name__ == '__main__':
         bench_gemm(lib)
     if what in ('attn', 'all'):
         bench_attn(lib)
-    if what in ('probe',):
-        probe_gemm(lib)
