@@ -123,6 +123,11 @@ struct ezdit_handle {
     // write-through slab stores, the counter round trip and the acquire cost more than the 1.6 us kernel boundary they replace;
     // release-fence, plain-load and coarse-poll variants are no better) -> kept as an option, OFF by default
     int opt_fuse_row = 0;                                                                 // residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch (M <= 2048)
+    // fuse_row 2: panel placement (all workgroups of an M tile on one XCD) + hand-off through that XCD's L2 (GemmArgs.xcd_panel);
+    // fuse_mask selects the shapes: 1 = D x D projections (attn-out, cross-out), 2 = skip_linear (K = 2D), 4 = MLP-out (K = 4D)
+    int opt_fuse_mask = 7;
+    int opt_pf_attn = 0;                                                                  // same run-ahead in the cross-attention kernel's fused q projection
+    int opt_pf_dist = 0;                                                                  // k_gemm L2 run-ahead distance in K tiles (0 = off)
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
     // GEMM: LDS-DMA refill pieces issued one k-step apart (1) or as one burst behind the barrier (0).  In situ on MI355X the two are
@@ -416,6 +421,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
     g.dma_spread = h->opt_dma_spread;
+    g.pf_dist = h->opt_pf_dist;
     g.debug = h->opt_gemm_debug;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
@@ -816,8 +822,11 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         const int K = w.ld;
         const int s = pick_splitk(h, M, D, K);
         const long wgs = (long)((M + 127) / 128) * ((D + 127) / 128) * s;
+        const int shape_bit = K >= 4 * D ? 4 : K >= 2 * D ? 2 : 1;
+        const bool panel = h->opt_fuse_row == 2;   // one XCD per M tile: needs a CU per workgroup on that XCD
         const bool fuse = exclusive && h->opt_fuse_row && h->debug_stop == 0 && h->opt_slab_bf16 && M <= 2048 && wgs <= 240 && s <= 4 &&
-                          h->opt_tile_partial == 9 && h->opt_tile_p18 < 0 && h->opt_tile_p36 < 0 && h->opt_tile_p72 < 0;
+                          h->opt_tile_partial == 9 && h->opt_tile_p18 < 0 && h->opt_tile_p36 < 0 && h->opt_tile_p72 < 0 &&
+                          (!panel || ((h->opt_fuse_mask & shape_bit) && (long)((D + 127) / 128) * s * (((M + 127) / 128 + 7) / 8) <= 32));
         if (!fuse) {
             const int s2 = gemm_partial(c, A, lda, w, M, D);
             if (c.bad() || (h->debug_stop > 0 && h->launches >= h->debug_stop)) return;
@@ -833,6 +842,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         g.row.slab_sc1 = 1;
         g.panel_cnt = p.sync; g.dev_err = p.sync + 1000; g.fuse_flags = h->opt_fuse_flags;
+        g.pf_dist = h->opt_pf_dist;
+        if (panel) { g.xcd_panel = 1; g.fuse_flags = 8; g.wt = 0; }
         if (g.fuse_flags & 1) g.wt = 0;
         if (g.fuse_flags & 2) g.row.slab_sc1 = 0;
         c.launched("k_gemm (residual + row)", launch_gemm(g, st));
@@ -936,7 +947,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (fuse_q2) {
             at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
-            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4;
+            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.pf_dist = h->opt_pf_attn;
         } else {
             gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
@@ -1233,6 +1244,8 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
                     int ldo, int M, int N, int K, int splitk, ezdit_stream stream) {
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.pf_dist = h ? h->opt_pf_dist : 0;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
@@ -1314,6 +1327,9 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
     else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
     else if (!strcmp(name, "fuse_flags")) h->opt_fuse_flags = value;
+    else if (!strcmp(name, "fuse_mask")) h->opt_fuse_mask = value;
+    else if (!strcmp(name, "pf_dist")) h->opt_pf_dist = value;
+    else if (!strcmp(name, "pf_attn")) h->opt_pf_attn = value;
     else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;

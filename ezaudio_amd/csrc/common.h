@@ -148,6 +148,14 @@ struct GemmArgs {
     // takes a share of the tile's rows (one wave per row).  panel_cnt: 2 words per M tile (arrive, passed), zero between launches, 32 words apart;
     // (the last workgroup through resets them); dev_err: set to 1 if a wait times out (never hang).
     RowArgs row; unsigned* panel_cnt; unsigned* dev_err; int fuse_flags;
+    // fuse_flags & 8 (with xcd_panel = 1): all workgroups of an M tile are dealt to ONE XCD and hand their slabs over through that
+    // XCD's L2 (plain stores, L1-bypassing loads, no write-back / invalidate); the arrival word records every arriver's XCC id, and a
+    // tile whose workgroups turn out to span XCDs falls back to the agent-scope protocol inside the same launch (gemm.hip).
+    // panel_cnt words per M tile: [0] arrive (agent protocol), [1] passed, [2..3] 64-bit per-XCC arrival bytes, [4] second arrive.
+    int xcd_panel;
+    // k_gemm L2 run-ahead: > 0 = every staged K tile is preceded by a 4-byte-per-lane touch of the operand lines `pf_dist` K tiles
+    // further on (PF variants of the step's tiles; ignored elsewhere)
+    int pf_dist;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 
@@ -171,6 +179,7 @@ struct AttnArgs {
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
     int two_pass;               // allow the two-pass form (k_attn2) where it applies: 128 < Lk <= 512 keys, plain q operand, 8 waves
+    int pf_dist;                // fused projection: L2 run-ahead distance in K tiles (0 = off), see GemmArgs.pf_dist
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 

@@ -154,9 +154,13 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int
 
 // SP: the LDS-DMA pieces of a refill are issued one k-step apart behind that k-step's fragment reads (true) or as one burst
 // right behind the barrier (false; round 1's order, kept for A/B through GemmArgs.dma_spread)
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP>
+// PF: every staged K tile is preceded by ONE 4-byte-per-lane LDS-DMA "touch" of the operand lines of the K tile `pf_dist` tiles
+// further on (one 128-byte line per operand row and K tile), so that the ring's own 16-byte loads of that tile hit the XCD's L2
+// instead of waiting for the fabric: the ring depth is bounded by the 160 KB of LDS, the L2 run-ahead is not.
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP, bool PF>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
+    static_assert(!PF || NT >= BM + BN, "one touch per operand row and K tile");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -175,11 +179,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int tilesN = (a.N + BN - 1) / BN;
     const int xcd = blockIdx.x & 7;
     const int l = blockIdx.x >> 3;
-    const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
-    const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
-    const int tm = xm * a.bm + lm;
-    const int tn = xn * a.bn + ln;
-    const int z = xz * a.bz + lz;
+    int tm, tn, z;
+    if (EPI == EPI_PARTIAL_ROW && a.xcd_panel) {
+        // panel placement: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8), so the
+        // tile's slabs, arrival word and row operator stay inside that XCD's L2 (see the hand-off below)
+        const int G = tilesN * a.splitk;
+        tm = xcd + 8 * (l / G);
+        tn = (l % G) / a.splitk;
+        z = (l % G) % a.splitk;
+    } else {
+        const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
+        const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
+        tm = xm * a.bm + lm;
+        tn = xn * a.bn + ln;
+        z = xz * a.bz + lz;
+    }
     if (tm >= tilesM || tn >= tilesN || z >= a.splitk) return;
     const int row0 = tm * BM, col0 = tn * BN;
 
@@ -231,9 +245,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(dst + A_BYTES + q * NT * 16), 16, 0, 0);
         }
     };
+    // L2 run-ahead (PF): lane i touches row i of [A tile rows | W tile rows] (clamped); destination = 256 scratch bytes per wave
+    // behind the ring.  Group order is ALWAYS [touch, tile loads], also in the prologue, so the counted waits below see
+    // uniform groups of LPT + 1 loads per staged tile.
+    // (plain GEMM addressing only: the launcher never picks a PF variant for the convolution form)
+    const char* pf_base = nullptr;
+    if constexpr (PF) {
+        int prow;
+        if (tid < BM) { prow = row0 + tid; prow = prow < a.M - 1 ? prow : a.M - 1; pf_base = gA + (long)kb * (BK * 2) + (long)prow * a.lda * 2; }
+        else { prow = col0 + (tid - BM < BN ? tid - BM : BN - 1); prow = prow < a.wrows - 1 ? prow : a.wrows - 1; pf_base = gW + (long)prow * a.ldw * 2; }
+    }
+    const int pfd = PF ? a.pf_dist : 0;
+    auto touch = [&](int t) {   // group of K tile t: touch the lines of K tile min(t + pf_dist, nt - 1)
+        if constexpr (PF) {
+            int tp = t + pfd;
+            tp = tp < nt ? tp : nt - 1;
+            const long off = (long)tp * (BK * 2);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_base + off),
+                                             (__attribute__((address_space(3))) void*)(smem + NS * STAGE_BYTES + wave_u * 256), 4, 0, 0);
+        }
+    };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-        if (t < nt) stage(t);
+        if (t < nt) { touch(t); stage(t); }
 
     const int r32 = lane & 31, hi = lane >> 5;
     // fragment read offsets: row r32 of a 32-row fragment, k-step ks -> 16-byte slot (2ks + hi) ^ ((r32>>1)&7).  Fragment
@@ -255,14 +289,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             constexpr int LO = (BM * 8) / NT + (BN * 8) / NT;
             static_assert(NS <= 3, "ragged staging supports rings up to 3");
             if (NS >= 3 && younger >= 1) {
-                if (wave_u < REM_WAVES) wait_vmcnt<LO + 1>(); else wait_vmcnt<LO>();
+                if (wave_u < REM_WAVES) wait_vmcnt<LO + 1 + (PF ? 1 : 0)>(); else wait_vmcnt<LO + (PF ? 1 : 0)>();
             } else {
                 wait_vmcnt<0>();
             }
         } else {
             constexpr int MAXY = NS - 2 < 5 ? NS - 2 : 5;   // tiles t+1 .. t+NS-2 are in flight here (t+NS-1 is issued below)
-            static_assert(MAXY * LPT < 64, "ring too deep for the 6-bit vmcnt");  // deeper rings wait conservatively (at most 5 tiles in flight)
-            wait_tiles<LPT, MAXY>(younger);
+            constexpr int PER = LPT + (PF ? 1 : 0);        // loads of one staged tile (+ its L2 touch)
+            static_assert(MAXY * PER < 64, "ring too deep for the 6-bit vmcnt");  // deeper rings wait conservatively (at most 5 tiles in flight)
+            wait_tiles<PER, MAXY>(younger);
         }
         __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
     };
@@ -273,6 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         const char* cT = smem + (t % NS) * STAGE_BYTES;
         long ra_off = 0;
         if constexpr (rf) {
+            touch(t + NS - 1);
             if constexpr (SP) ra_off = a_offset(t + NS - 1); else stage(t + NS - 1);
         }
         bf16x8 af[2][FM], bfr[2][FN];
@@ -432,7 +468,48 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         __syncthreads();
         const unsigned total = (unsigned)(tilesN * a.splitk);
         unsigned* cnt = a.panel_cnt + 32 * tm;   // one 128-byte line per M tile: arrivals and pollers of different tiles never share a line
-        if (tid == 0) {
+        if (a.fuse_flags & 8) {
+            // ---- same-XCD fast path, placement INDEPENDENT in its result.  Slabs are plain stores (they stay, dirty, in the
+            // storing XCD's L2) and every workgroup arrives by adding 1 to ITS XCC's byte of one 64-bit word (words 2, 3 of the
+            // tile's line; the arrival count is the sum of the bytes).  When the word shows that all `total` workgroups of the
+            // tile run on this XCC -- what the panel placement arranges, the dispatcher willing -- the slabs are read straight
+            // out of the shared L2 with L1-bypassing (sc1) loads: no write-back, no invalidate, no fabric round trip.  Any other
+            // placement takes the agent-scope protocol after all: release (write-back), second counter (word 4), acquire.
+            if (tid == 0) {
+                const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+                unsigned long long* aw = reinterpret_cast<unsigned long long*>(cnt + 2);
+                __hip_atomic_fetch_add(aw, 1ull << (8 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long v = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    v = __hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long t2 = (v & 0x00ff00ff00ff00ffull) + ((v >> 8) & 0x00ff00ff00ff00ffull);
+                    t2 = (t2 & 0x0000ffff0000ffffull) + ((t2 >> 16) & 0x0000ffff0000ffffull);
+                    if ((unsigned)(t2 + (t2 >> 32)) >= total) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 17)) { __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                if (v != ((unsigned long long)total << (8 * xcc))) {
+                    // the tile's workgroups span XCDs (or the wait timed out): make the slabs visible the placement-independent way
+                    __hip_atomic_store(a.dev_err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostic only: "slow path taken"
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(cnt + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    spins = 0;
+                    while (__hip_atomic_load(cnt + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1u << 17)) { __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                const unsigned passed = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (passed == total - 1) {   // everyone is through both waits: re-arm the tile's words for the next launch
+                    __hip_atomic_store(aw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else if (tid == 0) {
             if (a.fuse_flags & 1) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // hipcc may drop the wait behind buffer_wbl2 (ROCm 7.2)
@@ -482,9 +559,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
 // Order of one K tile (per wave, k-steps 0, 1 already in registers):
 //     mfma ks0 (half) | read ks2, ks3 | mfma ks0 (rest), ks1 | lgkmcnt(0) | barrier (stage free) | DMA A(t+2) | mfma ks2 | DMA W(t+2) |
 //     vmcnt(tile t+2 may fly) | barrier (tile t+1 visible) | read ks0, ks1 of tile t+1 | mfma ks3
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool PF>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
+    static_assert(!PF || NT >= BM + BN, "one touch per operand row and K tile");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -530,8 +608,25 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     auto stage_w = [&](int t) {
         stage_tile<BN, NT>(gW + (long)t * (BK * 2), boff, smem + (t & 1) * STAGE_BYTES + A_BYTES + wave_u * 1024, tid);
     };
-    if (nt > 0) { stage_a(0); stage_w(0); }
-    if (nt > 1) { stage_a(1); stage_w(1); }
+    // L2 run-ahead (PF), as in k_gemm: group of K tile t = [touch of tile t + pf_dist, tile loads]
+    const char* pf_base = nullptr;
+    if constexpr (PF) {
+        int prow;
+        if (tid < BM) { prow = row0 + tid; prow = prow < a.M - 1 ? prow : a.M - 1; pf_base = gA + (long)kb * (BK * 2) + (long)prow * a.lda * 2; }
+        else { prow = col0 + (tid - BM < BN ? tid - BM : BN - 1); prow = prow < a.wrows - 1 ? prow : a.wrows - 1; pf_base = gW + (long)prow * a.ldw * 2; }
+    }
+    const int pfd = PF ? a.pf_dist : 0;
+    auto touch = [&](int t) {
+        if constexpr (PF) {
+            int tp = t + pfd;
+            tp = tp < nt ? tp : nt - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_base + (long)tp * (BK * 2)),
+                                             (__attribute__((address_space(3))) void*)(smem + 2 * STAGE_BYTES + wave_u * 256), 4, 0, 0);
+        }
+    };
+    constexpr int PER = LPT + (PF ? 1 : 0);
+    if (nt > 0) { touch(0); stage_a(0); stage_w(0); }
+    if (nt > 1) { touch(1); stage_a(1); stage_w(1); }
 
     const int r32 = lane & 31, hi = lane >> 5;
     uint32_t foff[4];
@@ -555,7 +650,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     } while (0)
     constexpr int IH = FM / 2 > 0 ? FM / 2 : 1;   // first part of k-step 0's MFMAs, issued ahead of the reads of k-steps 2, 3
     if (nt > 0) {
-        if (nt > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile 0 landed (this wave's part); tile 1 may still fly
+        if (nt > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // tile 0 landed (this wave's part); tile 1 may still fly
         __builtin_amdgcn_s_barrier();                           // ... and every other wave's part
         EZ_READ_KS(smem, 0);
         EZ_READ_KS(smem, 1);
@@ -598,6 +693,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
             // vector-memory port while its MFMAs (and those of the wave sharing its SIMD, in lockstep) wait
             const long ra_off = a.conv_cpb ? (long)((kb + t + 2) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t + 2) % a.conv_cpb) * (BK * 2)
                                            : (long)(kb + t + 2) * (BK * 2);
+            touch(t + 2);
             int p = 0;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -616,7 +712,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
             EZ_MFMA_KS(2, 0, FM);
         }
         if constexpr (nx) {
-            if constexpr (rf) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
+            if constexpr (rf) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
             __builtin_amdgcn_s_barrier();
             const char* nT = smem + ((t + 1) & 1) * STAGE_BYTES;
             EZ_READ_KS(nT, 0);
@@ -641,7 +737,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
 }
 
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool PF = false>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
@@ -663,7 +759,8 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
             if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
         }
     dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
-    constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128;
+    if (EPI == EPI_PARTIAL_ROW && a.xcd_panel) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
+    constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128 + (PF ? WM * WN * 256 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device
     static bool attr_set[32] = {};
@@ -672,18 +769,18 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     if (dev < 0 || dev >= 32) return 1;
     if constexpr (NS > 0) {
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP, PF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP, PF>), grid, dim3(64 * WM * WN), SMEM, st, a);
     } else {
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI, PF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI, PF>), grid, dim3(64 * WM * WN), SMEM, st, a);
     }
     return 0;
 }
@@ -710,6 +807,7 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 template <int EPI>
 int launch_e(const GemmArgs& a, hipStream_t st) {
     const bool sp = a.dma_spread != 0;
+    const bool pf = a.pf_dist > 0 && !sp && !a.conv_cpb;   // L2 run-ahead variants exist for the burst-refill form of the step's tiles
     switch (a.tile) {
         case 0: return launch_t<128, 128, 2, 2, 4, EPI>(a, st);
         case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
@@ -720,14 +818,14 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
         case 6: return launch_t<128, 64, 4, 1, 2, EPI>(a, st);
         case 7: return launch_t<128, 128, 4, 2, 2, EPI>(a, st);
         case 8: return launch_t<256, 128, 4, 2, 2, EPI>(a, st);
-        case 9: return sp ? launch_t<128, 128, 4, 2, 3, EPI, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false>(a, st);
+        case 9: return sp ? launch_t<128, 128, 4, 2, 3, EPI, true>(a, st) : pf ? launch_t<128, 128, 4, 2, 3, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false>(a, st);
         case 10: return launch_t<256, 128, 4, 2, 3, EPI>(a, st);
         case 12: return launch_t<128, 288, 4, 3, 2, EPI>(a, st);
-        case 13: return sp ? launch_t<128, 288, 4, 3, 3, EPI, true>(a, st) : launch_t<128, 288, 4, 3, 3, EPI, false>(a, st);
-        case 25: return sp ? launch_t<128, 64, 4, 2, 4, EPI, true>(a, st) : launch_t<128, 64, 4, 2, 4, EPI, false>(a, st);
-        case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
-        case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
-        case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
+        case 13: return sp ? launch_t<128, 288, 4, 3, 3, EPI, true>(a, st) : pf ? launch_t<128, 288, 4, 3, 3, EPI, false, true>(a, st) : launch_t<128, 288, 4, 3, 3, EPI, false>(a, st);
+        case 25: return sp ? launch_t<128, 64, 4, 2, 4, EPI, true>(a, st) : pf ? launch_t<128, 64, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 64, 4, 2, 4, EPI, false>(a, st);
+        case 40: return pf ? launch_t<256, 256, 2, 4, 0, EPI, true, true>(a, st) : launch_t<256, 256, 2, 4, 0, EPI>(a, st);
+        case 41: return pf ? launch_t<192, 256, 2, 4, 0, EPI, true, true>(a, st) : launch_t<192, 256, 2, 4, 0, EPI>(a, st);
+        case 42: return pf ? launch_t<256, 128, 4, 2, 0, EPI, true, true>(a, st) : launch_t<256, 128, 4, 2, 0, EPI>(a, st);
         default: break;
     }
     return 1;   // unknown tile id: refuse (the caller reports EZDIT_E_UNSUPPORTED) instead of silently running another configuration
@@ -741,6 +839,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const bool sp = a.dma_spread != 0;
         if (a.hn.dh == 72) {
             if (a.tile != 1) return launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
+            if (a.pf_dist > 0 && !sp) return launch_t<64, 288, 1, 9, 3, EPI_QKV, false, true>(a, st);
             return sp ? launch_t<64, 288, 1, 9, 3, EPI_QKV, true>(a, st) : launch_t<64, 288, 1, 9, 3, EPI_QKV, false>(a, st);
         }
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
@@ -752,6 +851,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         if (a.tile != 9 || !a.part_bf16 || !a.panel_cnt || !a.dev_err || wgs > 240 || a.row.nsplit != a.splitk || a.row.nsplit > RW_MAXS ||
             a.row.D > RW * 256 || (a.row.D & 3))
             return 1;
+        // panel placement: one workgroup per CU on EVERY XCD (32 CUs each), M tile tm on XCD tm % 8
+        if (a.xcd_panel && (long)((a.N + 127) / 128) * a.splitk * (((a.M + 127) / 128 + 7) / 8) > 32) return 1;
+        if (a.pf_dist > 0 && !a.dma_spread) return launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false, true>(a, st);
         return a.dma_spread ? launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);
