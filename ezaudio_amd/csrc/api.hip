@@ -126,6 +126,9 @@ struct ezdit_handle {
     // fuse_row 2: panel placement (all workgroups of an M tile on one XCD) + hand-off through that XCD's L2 (GemmArgs.xcd_panel);
     // fuse_mask selects the shapes: 1 = D x D projections (attn-out, cross-out), 2 = skip_linear (K = 2D), 4 = MLP-out (K = 4D)
     int opt_fuse_mask = 7;
+    // XCD affinity of the residual path (placement only, results bit-identical): gemm_panel = shapes (1 D x D, 2 skip, 4 MLP-out) whose
+    // split-K GEMM puts all workgroups of an M tile on XCD tm % 8; row_affine = the row kernel processes row panel p on XCD p % 8
+    int opt_gemm_panel = 0, opt_row_affine = 0;
     int opt_pf_attn = 0;                                                                  // same run-ahead in the cross-attention kernel's fused q projection
     int opt_pf_dist = 0;                                                                  // k_gemm L2 run-ahead distance in K tiles (0 = off)
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
@@ -378,6 +381,7 @@ struct Ctx {
     hipStream_t st;
     const FuseResid* fuse = nullptr;
     const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
+    bool panel = false;                 // one-shot: panel placement of a split-K GEMM (GemmArgs.xcd_panel)
     // first launch failure of this call (hipGetLastError after EVERY launch: a rejected launch -- LDS limit, bad grid,
     // unsupported fused configuration -- must surface as an error code, never as stale numbers)
     hipError_t err = hipSuccess;
@@ -425,6 +429,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.debug = h->opt_gemm_debug;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
+    if (c.panel) { g.xcd_panel = 1; c.panel = false; }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
         g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
         g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
@@ -469,6 +474,8 @@ int gemm_partial(Ctx& c, const bf16_t* A, int lda, const WRef& w, int M, int N) 
         const int o = nk >= 72 ? h->opt_tile_p72 : nk >= 36 ? h->opt_tile_p36 : h->opt_tile_p18;
         if (o >= 0) tile = o;
     }
+    const int shape_bit = K >= 4 * N ? 4 : K >= 2 * N ? 2 : 1;
+    c.panel = (h->opt_gemm_panel & shape_bit) && M <= 2048;
     gemm(c, A, lda, w, nullptr, h->p.part, h->D, M, N, EPI_PARTIAL, tile, s, (long)h->Mp * h->D);
     return s;
 }
@@ -806,6 +813,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         r.M = M; r.D = D; r.L = h->L;
         r.cur_step = cur; r.row_slot = row_slot; r.wt = h->opt_wt;
         r.variant = h->opt_row_variant;
+        r.affine = h->opt_row_affine;
         return r;
     };
     auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
@@ -1330,6 +1338,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_mask")) h->opt_fuse_mask = value;
     else if (!strcmp(name, "pf_dist")) h->opt_pf_dist = value;
     else if (!strcmp(name, "pf_attn")) h->opt_pf_attn = value;
+    else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
+    else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
     else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;

@@ -114,6 +114,7 @@ struct RowArgs {
     int wt;                // output stores are write-through (sc1)
     int variant;           // 0: one 256-thread workgroup per row; 1: one wave per row (no LDS, no barriers)
     int slab_sc1;          // the slabs were written write-through by OTHER workgroups of this launch: read them past the L1 (sc1)
+    int affine;            // wave-per-row form: rows [128 p, 128 p + 128) are processed on XCD p % 8 (see k_row_w)
 };
 
 struct GemmArgs {

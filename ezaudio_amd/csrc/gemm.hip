@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int xcd = blockIdx.x & 7;
     const int l = blockIdx.x >> 3;
     int tm, tn, z;
-    if (EPI == EPI_PARTIAL_ROW && a.xcd_panel) {
+    if ((EPI == EPI_PARTIAL_ROW || EPI == EPI_PARTIAL) && a.xcd_panel) {
         // panel placement: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8), so the
         // tile's slabs, arrival word and row operator stay inside that XCD's L2 (see the hand-off below)
         const int G = tilesN * a.splitk;
@@ -759,7 +759,8 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
             if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
         }
     dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
-    if (EPI == EPI_PARTIAL_ROW && a.xcd_panel) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
+    if ((EPI == EPI_PARTIAL_ROW || EPI == EPI_PARTIAL) && a.xcd_panel && NS > 0) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
+    else a.xcd_panel = 0;
     constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128 + (PF ? WM * WN * 256 : 0);
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device

@@ -155,7 +155,13 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
 
 template <bool CONCAT>
 __global__ __launch_bounds__(256) void k_row_w(RowArgs a) {   // rowbody.h: one wave per row, 4 rows per workgroup
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a.affine) {
+        // row panel p (128 rows) is processed on XCD p % 8 (hardware deals workgroup b to XCD b % 8): the same placement as the
+        // panel form of the residual GEMMs, so slabs, residual stream and LayerNorm output of a panel stay in ONE XCD's L2
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        row = 128 * (xcd + 8 * (j >> 5)) + 4 * (j & 31) + (threadIdx.x >> 6);
+    }
     if (row >= a.M) return;   // wave-uniform
     row_wave<CONCAT>(a, row, threadIdx.x & 63);
 }
@@ -536,7 +542,7 @@ void launch_row(const RowArgs& a, hipStream_t st) {
     const bool wave_form = a.variant == 1 && a.D <= RW * 256 && (a.D & 3) == 0 &&
                            (a.mode == 0 || (a.part_bf16 ? a.nsplit <= RW_MAXS : a.nsplit <= 1));
     if (wave_form) {
-        const dim3 grid((a.M + 3) / 4);
+        const dim3 grid(a.affine ? 8 * 32 * (((a.M + 127) / 128 + 7) / 8) : (a.M + 3) / 4);
         if (a.skip) hipLaunchKernelGGL(k_row_w<true>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(k_row_w<false>, grid, dim3(256), 0, st, a);
         return;
