@@ -129,8 +129,8 @@ struct ezdit_handle {
     // XCD affinity of the residual path (placement only, results bit-identical): gemm_panel = shapes (1 D x D, 2 skip, 4 MLP-out) whose
     // split-K GEMM puts all workgroups of an M tile on XCD tm % 8; row_affine = the row kernel processes row panel p on XCD p % 8
     int opt_gemm_panel = 0, opt_row_affine = 0;
-    int opt_pf_attn = 0;                                                                  // same run-ahead in the cross-attention kernel's fused q projection
-    int opt_pf_dist = 0;                                                                  // k_gemm L2 run-ahead distance in K tiles (0 = off)
+    int opt_skew = 0;                                                                     // k_gemm: skewed LDS-DMA refill across the wave groups of a workgroup (SK variants)
+    int opt_skew_attn = 0;                                                                // the same in the cross-attention kernel's fused q projection
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
     // GEMM: LDS-DMA refill pieces issued one k-step apart (1) or as one burst behind the barrier (0).  In situ on MI355X the two are
@@ -425,7 +425,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
     g.dma_spread = h->opt_dma_spread;
-    g.pf_dist = h->opt_pf_dist;
+    g.skew = h->opt_skew;
     g.debug = h->opt_gemm_debug;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
@@ -850,7 +850,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         g.row.slab_sc1 = 1;
         g.panel_cnt = p.sync; g.dev_err = p.sync + 1000; g.fuse_flags = h->opt_fuse_flags;
-        g.pf_dist = h->opt_pf_dist;
+        g.skew = h->opt_skew;
         if (panel) { g.xcd_panel = 1; g.fuse_flags = 8; g.wt = 0; }
         if (g.fuse_flags & 1) g.wt = 0;
         if (g.fuse_flags & 2) g.row.slab_sc1 = 0;
@@ -955,7 +955,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (fuse_q2) {
             at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
-            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.pf_dist = h->opt_pf_attn;
+            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.skew = h->opt_skew_attn;
         } else {
             gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
@@ -1253,7 +1253,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.pf_dist = h ? h->opt_pf_dist : 0;
+    g.skew = h ? h->opt_skew : 0;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
@@ -1336,8 +1336,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
     else if (!strcmp(name, "fuse_flags")) h->opt_fuse_flags = value;
     else if (!strcmp(name, "fuse_mask")) h->opt_fuse_mask = value;
-    else if (!strcmp(name, "pf_dist")) h->opt_pf_dist = value;
-    else if (!strcmp(name, "pf_attn")) h->opt_pf_attn = value;
+    else if (!strcmp(name, "skew")) h->opt_skew = value;
+    else if (!strcmp(name, "skew_attn")) h->opt_skew_attn = value;
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
     else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int PSTAGE = (64 + DN) * 128, PRING = 3 * PSTAGE;
     constexpr int PRED = 4 * 64 * DS * 4, PQS = 64 * DQK * 2;
     constexpr int SMEM = NKH == 4 ? (2 * BUF > PRED + PQS ? (2 * BUF > PRING ? 2 * BUF : PRING) : (PRED + PQS > PRING ? PRED + PQS : PRING)) : 2 * BUF;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM + (NKH == 4 ? 8 * 256 : 0)];   // + scratch of the L2 touches (fused projection)
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,24 +107,11 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             };
             // loads per tile of this wave: 1 (x) + 1 or 2 (W: the second pass covers chunks [NT, DN * 8))
             const bool two = (DN * 8 > NT) && (wave_u * 64 + NT < DN * 8);
-            // L2 run-ahead (a.pf_dist > 0), as in k_gemm: every staged K tile is preceded by ONE 4-byte-per-lane touch of the x / W
-            // lines of the K tile pf_dist further on, so the ring's loads of that tile hit the L2 (group = [touch, tile loads])
-            const bool pf = a.pf_dist > 0;
-            const char* pf_base;
-            {
-                int prow;
-                if (tid < 64) { prow = rowb + qt * 64 + tid; prow = prow < rowb + a.Lq - 1 ? prow : rowb + a.Lq - 1; pf_base = gA + (long)prow * a.ldu * 2; }
-                else { prow = h * DH + (tid - 64 < DN ? tid - 64 : DN - 1); prow = prow < a.xw_rows - 1 ? prow : a.xw_rows - 1; pf_base = gW + (long)prow * a.ldw * 2; }
-            }
-            auto touch = [&](int t) {
-                int tp = t + a.pf_dist;
-                tp = tp < nt ? tp : nt - 1;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_base + (long)tp * 128),
-                                                 (__attribute__((address_space(3))) void*)(smem + SMEM + wave_u * 256), 4, 0, 0);
-            };
-            if (pf) touch(0);
+            // skewed refill (a.skew, see k_gemm): waves 4-7 -- the second wave of every SIMD -- issue their share of the refill behind
+            // their MFMAs instead of behind the barrier, so their issue stall lies under the first group's MFMAs and vice versa
+            const bool late = a.skew && wave_u >= 4;
             stage(0);
-            if (nt > 1) { if (pf) touch(1); stage(1); }
+            if (nt > 1) stage(1);
             f32x16 acc[FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j)
@@ -132,14 +119,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
             const uint32_t fo = r32 * 128 + (((2 * kq + hi) ^ ((r32 >> 1) & 7)) << 4);
             for (int t = 0; t < nt; ++t) {
-                if (t + 1 < nt) {   // tile t + 1 (and its touch) may stay in flight
-                    if (pf) { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
-                    else { if (two) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                if (t + 1 < nt) {   // tile t + 1 may stay in flight
+                    if (two) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                if (t + 2 < nt) { if (pf) touch(t + 2); stage(t + 2); }
+                if (t + 2 < nt && !late) stage(t + 2);
                 const char* cT = smem + (t % 3) * PSTAGE;
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(cT + fo + mh * 4096);
 #pragma unroll
@@ -149,6 +135,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[j]));
+                if (t + 2 < nt && late) stage(t + 2);
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[j]));

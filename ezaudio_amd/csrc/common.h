@@ -154,9 +154,9 @@ struct GemmArgs {
     // tile whose workgroups turn out to span XCDs falls back to the agent-scope protocol inside the same launch (gemm.hip).
     // panel_cnt words per M tile: [0] arrive (agent protocol), [1] passed, [2..3] 64-bit per-XCC arrival bytes, [4] second arrive.
     int xcd_panel;
-    // k_gemm L2 run-ahead: > 0 = every staged K tile is preceded by a 4-byte-per-lane touch of the operand lines `pf_dist` K tiles
-    // further on (PF variants of the step's tiles; ignored elsewhere)
-    int pf_dist;
+    // k_gemm skewed refill (SK variants of the step's tiles): the wave groups of a workgroup issue their LDS-DMA refill at different
+    // points of a K tile, so one group's issue stall lies under the other groups' MFMAs (gemm.hip)
+    int skew;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 
@@ -180,7 +180,7 @@ struct AttnArgs {
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
     int two_pass;               // allow the two-pass form (k_attn2) where it applies: 128 < Lk <= 512 keys, plain q operand, 8 waves
-    int pf_dist;                // fused projection: L2 run-ahead distance in K tiles (0 = off), see GemmArgs.pf_dist
+    int skew;                   // fused projection: skewed refill (see GemmArgs.skew)
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 

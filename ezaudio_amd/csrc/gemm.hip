@@ -154,19 +154,25 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int
 
 // SP: the LDS-DMA pieces of a refill are issued one k-step apart behind that k-step's fragment reads (true) or as one burst
 // right behind the barrier (false; round 1's order, kept for A/B through GemmArgs.dma_spread)
-// PF: every staged K tile is preceded by ONE 4-byte-per-lane LDS-DMA "touch" of the operand lines of the K tile `pf_dist` tiles
-// further on (one 128-byte line per operand row and K tile), so that the ring's own 16-byte loads of that tile hit the XCD's L2
-// instead of waiting for the fabric: the ring depth is bounded by the 160 KB of LDS, the L2 run-ahead is not.
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP, bool PF>
+// SK (skewed refill): the waves of a workgroup do not all issue their share of the LDS-DMA refill at the same point of a K tile.
+// In lockstep (SK = 0, or SP) every wave queues its pieces behind the barrier at once: the CU accepts one 1-KB piece per ~17
+// cycles (tools/_run/ingest_bench: ~140 GB/s per CU), a wave's own ds_reads and MFMAs wait in order behind its stalled pieces, and
+// then all waves of a SIMD want the matrix pipe together -- a K tile costs (pieces x 17) + (MFMA time of ALL the SIMD's waves),
+// which reproduces the measured 0.55 / 0.87 / 1.3 us per tile of the 128x128 / 64x288 / 128x288 configurations.  With SK the waves
+// that share a SIMD (wave w runs on SIMD w % 4: group = w / 4) refill at DIFFERENT points -- group 0 behind the barrier, group 1
+// after its second k-step (the last group of a 3-group workgroup after its last) -- so one group's issue stall lies under the other
+// groups' MFMAs.  Same loads, same counted waits (a wave's pieces of tile t + NS - 1 are issued during tile t wherever they sit), same results.
+// ABL (timing experiments only, results are garbage): 1 = no MFMAs, 2 = no fragment reads, 4 = no refill, 8 = no barrier
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP, bool SK, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
-    static_assert(!PF || NT >= BM + BN, "one touch per operand row and K tile");
+    static_assert(!(SP && SK), "skewed refill is a variant of the burst form");
+    constexpr int LPT = (BM + BN) * 8 / NT;          // LDS-DMA instructions per thread per tile
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // stage s: [A tile | B tile] at smem + s * STAGE_BYTES
     // NS = ring depth; prefetch distance NS - 1 tiles
-    constexpr int LPT = (BM + BN) * 8 / NT;          // LDS-DMA instructions per thread per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -219,8 +225,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
     auto stage = [&](int t) {  // K tile t (relative) -> ring slot t % NS
         char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
-        const long a_off = a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
-                                      : (long)(kb + t) * (BK * 2);
+        // (the skewed-refill variants are plain-GEMM only: no data-dependent branch in the middle of their MFMA stream)
+        const long a_off = (!SK && a.conv_cpb) ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
+                                               : (long)(kb + t) * (BK * 2);
         stage_tile<BM, NT>(gA + a_off, aoff, dst, tid);
         stage_tile<BN, NT>(gW + t * (BK * 2), boff, dst + A_BYTES, tid);
     };
@@ -245,29 +252,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(dst + A_BYTES + q * NT * 16), 16, 0, 0);
         }
     };
-    // L2 run-ahead (PF): lane i touches row i of [A tile rows | W tile rows] (clamped); destination = 256 scratch bytes per wave
-    // behind the ring.  Group order is ALWAYS [touch, tile loads], also in the prologue, so the counted waits below see
-    // uniform groups of LPT + 1 loads per staged tile.
-    // (plain GEMM addressing only: the launcher never picks a PF variant for the convolution form)
-    const char* pf_base = nullptr;
-    if constexpr (PF) {
-        int prow;
-        if (tid < BM) { prow = row0 + tid; prow = prow < a.M - 1 ? prow : a.M - 1; pf_base = gA + (long)kb * (BK * 2) + (long)prow * a.lda * 2; }
-        else { prow = col0 + (tid - BM < BN ? tid - BM : BN - 1); prow = prow < a.wrows - 1 ? prow : a.wrows - 1; pf_base = gW + (long)prow * a.ldw * 2; }
-    }
-    const int pfd = PF ? a.pf_dist : 0;
-    auto touch = [&](int t) {   // group of K tile t: touch the lines of K tile min(t + pf_dist, nt - 1)
-        if constexpr (PF) {
-            int tp = t + pfd;
-            tp = tp < nt ? tp : nt - 1;
-            const long off = (long)tp * (BK * 2);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_base + off),
-                                             (__attribute__((address_space(3))) void*)(smem + NS * STAGE_BYTES + wave_u * 256), 4, 0, 0);
-        }
-    };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
-        if (t < nt) { touch(t); stage(t); }
+        if (t < nt) stage(t);
 
     const int r32 = lane & 31, hi = lane >> 5;
     // fragment read offsets: row r32 of a 32-row fragment, k-step ks -> 16-byte slot (2ks + hi) ^ ((r32>>1)&7).  Fragment
@@ -289,37 +276,47 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             constexpr int LO = (BM * 8) / NT + (BN * 8) / NT;
             static_assert(NS <= 3, "ragged staging supports rings up to 3");
             if (NS >= 3 && younger >= 1) {
-                if (wave_u < REM_WAVES) wait_vmcnt<LO + 1 + (PF ? 1 : 0)>(); else wait_vmcnt<LO + (PF ? 1 : 0)>();
+                if (wave_u < REM_WAVES) wait_vmcnt<LO + 1>(); else wait_vmcnt<LO>();
             } else {
                 wait_vmcnt<0>();
             }
         } else {
             constexpr int MAXY = NS - 2 < 5 ? NS - 2 : 5;   // tiles t+1 .. t+NS-2 are in flight here (t+NS-1 is issued below)
-            constexpr int PER = LPT + (PF ? 1 : 0);        // loads of one staged tile (+ its L2 touch)
-            static_assert(MAXY * PER < 64, "ring too deep for the 6-bit vmcnt");  // deeper rings wait conservatively (at most 5 tiles in flight)
-            wait_tiles<PER, MAXY>(younger);
+            static_assert(MAXY * LPT < 64, "ring too deep for the 6-bit vmcnt");  // deeper rings wait conservatively (at most 5 tiles in flight)
+            wait_tiles<LPT, MAXY>(younger);
         }
-        __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
     };
     // one K tile: 4 k-steps of MFMAs with fragment double buffering (the ds_reads of k-step ks+1 are issued before the MFMAs
     // of k-step ks); RF: tile t + NS - 1 is staged into the slot of tile t-1 on the way
-    auto ktile = [&](int t, auto RF) {
-        constexpr bool rf = decltype(RF)::value;
-        const char* cT = smem + (t % NS) * STAGE_BYTES;
+    bf16x8 abl_frag;
+    if constexpr (ABL & 2) { abl_frag = *reinterpret_cast<const bf16x8*>(smem + lane * 16); asm volatile("" : "+v"(abl_frag)); }
+    // POS: where this wave issues the refill (SK): 0 = behind the barrier, 1 = after the MFMAs of k-step 1, 2 = after those of k-step 3
+    auto ktile = [&](int t, auto RF, auto POS) {
+        constexpr bool rf = decltype(RF)::value && !(ABL & 4);
+        constexpr int pos = decltype(POS)::value;
+        f32x16 (&acc_r)[FM][FN] = acc;
+        const char* cT = smem + ((ABL & 2) ? 0 : (t % NS)) * STAGE_BYTES;
         long ra_off = 0;
-        if constexpr (rf) {
-            touch(t + NS - 1);
+        if constexpr (rf && pos == 0) {
             if constexpr (SP) ra_off = a_offset(t + NS - 1); else stage(t + NS - 1);
         }
         bf16x8 af[2][FM], bfr[2][FN];
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) { af[0][i] = abl_frag; af[1][i] = abl_frag; }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { bfr[0][j] = abl_frag; bfr[1][j] = abl_frag; }
+        } else {
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + a_base + i * 4096);
 #pragma unroll
         for (int j = 0; j < FN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + b_base + j * 4096);
         __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) {
+            if (ks < 3 && !(ABL & 2)) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
                     af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + a_base + i * 4096);
@@ -331,27 +328,54 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
 #pragma unroll
                 for (int p = ks * NP_ / 4; p < (ks + 1) * NP_ / 4; ++p) stage_piece(t + NS - 1, ra_off, p);
             }
+            if constexpr (ABL & 1) {   // keep the fragments alive, issue no MFMA
+#pragma unroll
+                for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[ks & 1][i]));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[ks & 1][j]));
+            } else {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
+            }
             // pin the order: next k-step's LDS reads first, then this k-step's MFMAs (hides the ds_read latency)
+            if constexpr (ABL == 0) {
             if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);
+            }
+            if constexpr (rf && pos != 0) {
+                if ((pos == 1 && ks == 1) || (pos == 2 && ks == 3)) {   // this group's refill point: behind the MFMAs just queued
+                    __builtin_amdgcn_sched_barrier(0);
+                    stage(t + NS - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         // keep the accumulators resident in AGPRs across the back edge: without this hipcc copies all of them to VGPRs
         // and back around every barrier (64+ v_accvgpr moves per K tile, and the copy-out waits for the MFMAs to drain)
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc_r[i][j]));
     };
     // steady state (every tile refills the ring) and drain (the last NS - 1 tiles): two loops, each with ONE straight-line body
     const int nt_refill = nt - (NS - 1) > 0 ? nt - (NS - 1) : 0;
-    int t = 0;
-    for (; t < nt_refill; ++t) { tile_top(t); ktile(t, std::true_type{}); }
-    for (; t < nt; ++t) { tile_top(t); ktile(t, std::false_type{}); }
+    auto kloop = [&](auto POS) {
+        int t = 0;
+        for (; t < nt_refill; ++t) { tile_top(t); ktile(t, std::true_type{}, POS); }
+        for (; t < nt; ++t) { tile_top(t); ktile(t, std::false_type{}, POS); }
+    };
+    if constexpr (SK) {
+        constexpr int NG = (WM * WN + 3) / 4;   // groups of 4 waves: one wave per SIMD each
+        const int grp = wave_u >> 2;
+        if (grp == 0) kloop(std::integral_constant<int, 0>{});
+        else if (NG == 2 || grp == 1) kloop(std::integral_constant<int, 1>{});
+        else kloop(std::integral_constant<int, 2>{});
+    } else {
+        kloop(std::integral_constant<int, 0>{});
+    }
 
     // ---- epilogue (lane <-> output element mapping: see store_tile) ----
     const int row_in = lane & 31;
@@ -559,10 +583,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
 // Order of one K tile (per wave, k-steps 0, 1 already in registers):
 //     mfma ks0 (half) | read ks2, ks3 | mfma ks0 (rest), ks1 | lgkmcnt(0) | barrier (stage free) | DMA A(t+2) | mfma ks2 | DMA W(t+2) |
 //     vmcnt(tile t+2 may fly) | barrier (tile t+1 visible) | read ks0, ks1 of tile t+1 | mfma ks3
-template <int BM, int BN, int WM, int WN, int EPI, bool PF>
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
-    static_assert(!PF || NT >= BM + BN, "one touch per operand row and K tile");
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -608,25 +631,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     auto stage_w = [&](int t) {
         stage_tile<BN, NT>(gW + (long)t * (BK * 2), boff, smem + (t & 1) * STAGE_BYTES + A_BYTES + wave_u * 1024, tid);
     };
-    // L2 run-ahead (PF), as in k_gemm: group of K tile t = [touch of tile t + pf_dist, tile loads]
-    const char* pf_base = nullptr;
-    if constexpr (PF) {
-        int prow;
-        if (tid < BM) { prow = row0 + tid; prow = prow < a.M - 1 ? prow : a.M - 1; pf_base = gA + (long)kb * (BK * 2) + (long)prow * a.lda * 2; }
-        else { prow = col0 + (tid - BM < BN ? tid - BM : BN - 1); prow = prow < a.wrows - 1 ? prow : a.wrows - 1; pf_base = gW + (long)prow * a.ldw * 2; }
-    }
-    const int pfd = PF ? a.pf_dist : 0;
-    auto touch = [&](int t) {
-        if constexpr (PF) {
-            int tp = t + pfd;
-            tp = tp < nt ? tp : nt - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pf_base + (long)tp * (BK * 2)),
-                                             (__attribute__((address_space(3))) void*)(smem + 2 * STAGE_BYTES + wave_u * 256), 4, 0, 0);
-        }
-    };
-    constexpr int PER = LPT + (PF ? 1 : 0);
-    if (nt > 0) { touch(0); stage_a(0); stage_w(0); }
-    if (nt > 1) { touch(1); stage_a(1); stage_w(1); }
+    if (nt > 0) { stage_a(0); stage_w(0); }
+    if (nt > 1) { stage_a(1); stage_w(1); }
 
     const int r32 = lane & 31, hi = lane >> 5;
     uint32_t foff[4];
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     } while (0)
     constexpr int IH = FM / 2 > 0 ? FM / 2 : 1;   // first part of k-step 0's MFMAs, issued ahead of the reads of k-steps 2, 3
     if (nt > 0) {
-        if (nt > 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // tile 0 landed (this wave's part); tile 1 may still fly
+        if (nt > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile 0 landed (this wave's part); tile 1 may still fly
         __builtin_amdgcn_s_barrier();                           // ... and every other wave's part
         EZ_READ_KS(smem, 0);
         EZ_READ_KS(smem, 1);
@@ -693,7 +699,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
             // vector-memory port while its MFMAs (and those of the wave sharing its SIMD, in lockstep) wait
             const long ra_off = a.conv_cpb ? (long)((kb + t + 2) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t + 2) % a.conv_cpb) * (BK * 2)
                                            : (long)(kb + t + 2) * (BK * 2);
-            touch(t + 2);
             int p = 0;
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
             EZ_MFMA_KS(2, 0, FM);
         }
         if constexpr (nx) {
-            if constexpr (rf) wait_vmcnt<PER>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
+            if constexpr (rf) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
             __builtin_amdgcn_s_barrier();
             const char* nT = smem + ((t + 1) & 1) * STAGE_BYTES;
             EZ_READ_KS(nT, 0);
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
 }
 
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool PF = false>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool SK = false, int ABL = 0>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
@@ -761,7 +766,7 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
     if ((EPI == EPI_PARTIAL_ROW || EPI == EPI_PARTIAL) && a.xcd_panel && NS > 0) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
     else a.xcd_panel = 0;
-    constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128 + (PF ? WM * WN * 256 : 0);
+    constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device
     static bool attr_set[32] = {};
@@ -770,18 +775,18 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     if (dev < 0 || dev >= 32) return 1;
     if constexpr (NS > 0) {
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP, PF>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP, SK, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP, PF>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP, SK, ABL>), grid, dim3(64 * WM * WN), SMEM, st, a);
     } else {
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI, PF>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI, PF>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
     }
     return 0;
 }
@@ -808,7 +813,12 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 template <int EPI>
 int launch_e(const GemmArgs& a, hipStream_t st) {
     const bool sp = a.dma_spread != 0;
-    const bool pf = a.pf_dist > 0 && !sp && !a.conv_cpb;   // L2 run-ahead variants exist for the burst-refill form of the step's tiles
+    const bool sk = a.skew != 0 && !sp && !a.conv_cpb;   // skewed-refill variants exist for the burst form of the step's tiles
+    if ((a.debug >> 4) && (a.tile == 13 || a.tile == 9) && (EPI == EPI_GEGLU || EPI == EPI_PARTIAL)) {   // timing ablations (tools/_run/ablate.py)
+#define EZ_ABL(n) case n: return a.tile == 13 ? launch_t<128, 288, 4, 3, 3, EPI, false, false, n>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false, false, n>(a, st);
+        switch (a.debug >> 4) { EZ_ABL(1) EZ_ABL(2) EZ_ABL(3) EZ_ABL(4) EZ_ABL(5) EZ_ABL(6) EZ_ABL(7) EZ_ABL(8) EZ_ABL(12) EZ_ABL(15) EZ_ABL(9) EZ_ABL(11) default: break; }
+#undef EZ_ABL
+    }
     switch (a.tile) {
         case 0: return launch_t<128, 128, 2, 2, 4, EPI>(a, st);
         case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
@@ -819,14 +829,15 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
         case 6: return launch_t<128, 64, 4, 1, 2, EPI>(a, st);
         case 7: return launch_t<128, 128, 4, 2, 2, EPI>(a, st);
         case 8: return launch_t<256, 128, 4, 2, 2, EPI>(a, st);
-        case 9: return sp ? launch_t<128, 128, 4, 2, 3, EPI, true>(a, st) : pf ? launch_t<128, 128, 4, 2, 3, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false>(a, st);
+        case 9: return sp ? launch_t<128, 128, 4, 2, 3, EPI, true>(a, st) : sk ? launch_t<128, 128, 4, 2, 3, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false>(a, st);
         case 10: return launch_t<256, 128, 4, 2, 3, EPI>(a, st);
         case 12: return launch_t<128, 288, 4, 3, 2, EPI>(a, st);
-        case 13: return sp ? launch_t<128, 288, 4, 3, 3, EPI, true>(a, st) : pf ? launch_t<128, 288, 4, 3, 3, EPI, false, true>(a, st) : launch_t<128, 288, 4, 3, 3, EPI, false>(a, st);
-        case 25: return sp ? launch_t<128, 64, 4, 2, 4, EPI, true>(a, st) : pf ? launch_t<128, 64, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 64, 4, 2, 4, EPI, false>(a, st);
-        case 40: return pf ? launch_t<256, 256, 2, 4, 0, EPI, true, true>(a, st) : launch_t<256, 256, 2, 4, 0, EPI>(a, st);
-        case 41: return pf ? launch_t<192, 256, 2, 4, 0, EPI, true, true>(a, st) : launch_t<192, 256, 2, 4, 0, EPI>(a, st);
-        case 42: return pf ? launch_t<256, 128, 4, 2, 0, EPI, true, true>(a, st) : launch_t<256, 128, 4, 2, 0, EPI>(a, st);
+        case 13: return sp ? launch_t<128, 288, 4, 3, 3, EPI, true>(a, st) : sk ? launch_t<128, 288, 4, 3, 3, EPI, false, true>(a, st) : launch_t<128, 288, 4, 3, 3, EPI, false>(a, st);
+        case 25: return sp ? launch_t<128, 64, 4, 2, 4, EPI, true>(a, st) : sk ? launch_t<128, 64, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 64, 4, 2, 4, EPI, false>(a, st);
+        case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
+        case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
+        case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
+        case 50: return sk ? launch_t<128, 128, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 4, EPI, false>(a, st);   // tile 9 with a 4-deep ring (128 KB)
         default: break;
     }
     return 1;   // unknown tile id: refuse (the caller reports EZDIT_E_UNSUPPORTED) instead of silently running another configuration
@@ -840,7 +851,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const bool sp = a.dma_spread != 0;
         if (a.hn.dh == 72) {
             if (a.tile != 1) return launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
-            if (a.pf_dist > 0 && !sp) return launch_t<64, 288, 1, 9, 3, EPI_QKV, false, true>(a, st);
+            if (a.skew && !sp) return launch_t<64, 288, 1, 9, 3, EPI_QKV, false, true>(a, st);
             return sp ? launch_t<64, 288, 1, 9, 3, EPI_QKV, true>(a, st) : launch_t<64, 288, 1, 9, 3, EPI_QKV, false>(a, st);
         }
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
@@ -854,7 +865,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             return 1;
         // panel placement: one workgroup per CU on EVERY XCD (32 CUs each), M tile tm on XCD tm % 8
         if (a.xcd_panel && (long)((a.N + 127) / 128) * a.splitk * (((a.M + 127) / 128 + 7) / 8) > 32) return 1;
-        if (a.pf_dist > 0 && !a.dma_spread) return launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false, true>(a, st);
+        if (a.skew && !a.dma_spread) return launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false, true>(a, st);
         return a.dma_spread ? launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);
