@@ -126,10 +126,14 @@ struct ezdit_handle {
     // fuse_row 2: panel placement (all workgroups of an M tile on one XCD) + hand-off through that XCD's L2 (GemmArgs.xcd_panel);
     // fuse_mask selects the shapes: 1 = D x D projections (attn-out, cross-out), 2 = skip_linear (K = 2D), 4 = MLP-out (K = 4D)
     int opt_fuse_mask = 7;
-    // XCD affinity of the residual path (placement only, results bit-identical): gemm_panel = shapes (1 D x D, 2 skip, 4 MLP-out) whose
-    // split-K GEMM puts all workgroups of an M tile on XCD tm % 8; row_affine = the row kernel processes row panel p on XCD p % 8
-    int opt_gemm_panel = 0, opt_row_affine = 0;
-    int opt_skew = 0;                                                                     // k_gemm: skewed LDS-DMA refill across the wave groups of a workgroup (SK variants)
+    // XCD affinity of the residual path at M <= 1024 (placement only, results bit-identical): gemm_panel = shapes (1 D x D, 2 skip, 4 MLP-out)
+    // whose split-K GEMM puts ALL workgroups of an M tile on XCD tm % 8; row_affine = the row kernel processes row panel p on XCD p % 8, so
+    // a panel's slabs, residual stream and LayerNorm output stay in one XCD's L2 (the L2 keeps its lines across kernel boundaries: a
+    // same-XCD consumer of 4 MB is 2 us faster than a cross-XCD one, tools/microbench/xcd_bench.hip).  In situ on MI355X: XL 4.497 ->
+    // 4.442 ms/step (+1.2 %, three boxes +0.9 ... +1.5 %), L 3.611 -> 3.518 (+2.7 %); the MLP-out shape gains nothing more and re-reads W
+    // 8x (94 vs 66 MB fetched per launch), so it keeps the box placement.
+    int opt_gemm_panel = 3, opt_row_affine = 1;
+    int opt_rot = 0;                                                                      // k_gemm: rotating load / MFMA phases across the wave groups of a workgroup (ROT variants)
     int opt_skew_attn = 0;                                                                // the same in the cross-attention kernel's fused q projection
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
@@ -425,7 +429,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
     g.dma_spread = h->opt_dma_spread;
-    g.skew = h->opt_skew;
+    g.rot = h->opt_rot;
     g.debug = h->opt_gemm_debug;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
@@ -475,7 +479,7 @@ int gemm_partial(Ctx& c, const bf16_t* A, int lda, const WRef& w, int M, int N) 
         if (o >= 0) tile = o;
     }
     const int shape_bit = K >= 4 * N ? 4 : K >= 2 * N ? 2 : 1;
-    c.panel = (h->opt_gemm_panel & shape_bit) && M <= 2048;
+    c.panel = (h->opt_gemm_panel & shape_bit) && M <= 1024;
     gemm(c, A, lda, w, nullptr, h->p.part, h->D, M, N, EPI_PARTIAL, tile, s, (long)h->Mp * h->D);
     return s;
 }
@@ -813,7 +817,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         r.M = M; r.D = D; r.L = h->L;
         r.cur_step = cur; r.row_slot = row_slot; r.wt = h->opt_wt;
         r.variant = h->opt_row_variant;
-        r.affine = h->opt_row_affine;
+        r.affine = h->opt_row_affine && M <= 1024;
         return r;
     };
     auto row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
@@ -850,7 +854,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         g.row.slab_sc1 = 1;
         g.panel_cnt = p.sync; g.dev_err = p.sync + 1000; g.fuse_flags = h->opt_fuse_flags;
-        g.skew = h->opt_skew;
+        g.rot = h->opt_rot;
         if (panel) { g.xcd_panel = 1; g.fuse_flags = 8; g.wt = 0; }
         if (g.fuse_flags & 1) g.wt = 0;
         if (g.fuse_flags & 2) g.row.slab_sc1 = 0;
@@ -1253,13 +1257,14 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.skew = h ? h->opt_skew : 0;
+    g.rot = h ? h->opt_rot : 0;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
     g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.dma_spread = h ? h->opt_dma_spread : 0; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
-    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: k_gemm2 experiment bits (GemmArgs.debug)
+    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: k_gemm2 experiment bits (GemmArgs.debug); bit 2 (4000 + v): rotating-phase variant
+    if (g.debug & 4) g.rot = 1;
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.epi > EPI_GEGLU || g.tile > 63) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
@@ -1336,7 +1341,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
     else if (!strcmp(name, "fuse_flags")) h->opt_fuse_flags = value;
     else if (!strcmp(name, "fuse_mask")) h->opt_fuse_mask = value;
-    else if (!strcmp(name, "skew")) h->opt_skew = value;
+    else if (!strcmp(name, "rot")) h->opt_rot = value;
     else if (!strcmp(name, "skew_attn")) h->opt_skew_attn = value;
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;

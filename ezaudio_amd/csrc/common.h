@@ -154,9 +154,9 @@ struct GemmArgs {
     // tile whose workgroups turn out to span XCDs falls back to the agent-scope protocol inside the same launch (gemm.hip).
     // panel_cnt words per M tile: [0] arrive (agent protocol), [1] passed, [2..3] 64-bit per-XCC arrival bytes, [4] second arrive.
     int xcd_panel;
-    // k_gemm skewed refill (SK variants of the step's tiles): the wave groups of a workgroup issue their LDS-DMA refill at different
-    // points of a K tile, so one group's issue stall lies under the other groups' MFMAs (gemm.hip)
-    int skew;
+    // k_gemm rotating phases (ROT variants of the step's tiles): the wave groups of a workgroup run one barrier interval apart, one
+    // group loading (fragment reads + LDS-DMA refill) while another issues MFMAs from registers (gemm.hip)
+    int rot;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 

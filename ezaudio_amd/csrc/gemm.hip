@@ -154,19 +154,23 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int
 
 // SP: the LDS-DMA pieces of a refill are issued one k-step apart behind that k-step's fragment reads (true) or as one burst
 // right behind the barrier (false; round 1's order, kept for A/B through GemmArgs.dma_spread)
-// SK (skewed refill): the waves of a workgroup do not all issue their share of the LDS-DMA refill at the same point of a K tile.
-// In lockstep (SK = 0, or SP) every wave queues its pieces behind the barrier at once: the CU accepts one 1-KB piece per ~17
-// cycles (tools/_run/ingest_bench: ~140 GB/s per CU), a wave's own ds_reads and MFMAs wait in order behind its stalled pieces, and
-// then all waves of a SIMD want the matrix pipe together -- a K tile costs (pieces x 17) + (MFMA time of ALL the SIMD's waves),
-// which reproduces the measured 0.55 / 0.87 / 1.3 us per tile of the 128x128 / 64x288 / 128x288 configurations.  With SK the waves
-// that share a SIMD (wave w runs on SIMD w % 4: group = w / 4) refill at DIFFERENT points -- group 0 behind the barrier, group 1
-// after its second k-step (the last group of a 3-group workgroup after its last) -- so one group's issue stall lies under the other
-// groups' MFMAs.  Same loads, same counted waits (a wave's pieces of tile t + NS - 1 are issued during tile t wherever they sit), same results.
+// ROT (rotating phases): the lockstep loop below serialises everything a K tile needs -- measured with the ABL variants on the
+// 128x288 tile, per K tile: MFMAs 0.51 us (the matrix pipe at full rate), LDS-DMA refill 0.34, fragment reads 0.10, barrier 0.12, loop 0.09:
+// 1.23 us, the sum -- because all waves of a SIMD do the same thing at the same time.  ROT splits the workgroup into G = waves / 4
+// groups (wave w runs on SIMD w % 4: one wave of every group per SIMD) that are one barrier interval apart: in any interval ONE group
+// pulls a whole K tile's fragments into registers and issues its share of the refill (LOAD), ONE group issues that tile's MFMAs from
+// registers (MFMA), the third (12-wave tiles) idles; s_barrier separates the intervals, so the alternation is enforced, not hoped for.
+//   interval t G + g     : group g  LOAD(t)   = ds_read all 4 k-steps of tile t | LDS-DMA own pieces of tile t + NS - 1
+//   interval t G + g + 1 : group g  MFMA(t)
+// Hazards: a wave waits (counted vmcnt) for its OWN pieces of tile t + 1 at the end of its sub-phase G - 1 - g of tile t, i.e. before the
+// barrier that precedes group 0's LOAD(t + 1); the slot of tile t + NS - 1 is the slot of tile t - 1, whose last reader (group G - 1,
+// interval t G - 1) has drained its reads (lgkmcnt(0)) before the barrier that precedes group 0's LOAD(t).  Same loads, same MFMA
+// order per accumulator: results are bit-identical to the lockstep form.
 // ABL (timing experiments only, results are garbage): 1 = no MFMAs, 2 = no fragment reads, 4 = no refill, 8 = no barrier
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP, bool SK, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP, bool ROT, int ABL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
-    static_assert(!(SP && SK), "skewed refill is a variant of the burst form");
+    static_assert(!(SP && ROT) && !(ROT && ABL), "rotating phases are a variant of the plain burst form");
     constexpr int LPT = (BM + BN) * 8 / NT;          // LDS-DMA instructions per thread per tile
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
@@ -225,8 +229,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
     auto stage = [&](int t) {  // K tile t (relative) -> ring slot t % NS
         char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
-        // (the skewed-refill variants are plain-GEMM only: no data-dependent branch in the middle of their MFMA stream)
-        const long a_off = (!SK && a.conv_cpb) ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
+        // (the rotating-phase variants are plain-GEMM only)
+        const long a_off = (!ROT && a.conv_cpb) ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
                                                : (long)(kb + t) * (BK * 2);
         stage_tile<BM, NT>(gA + a_off, aoff, dst, tid);
         stage_tile<BN, NT>(gW + t * (BK * 2), boff, dst + A_BYTES, tid);
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int a_base = wm * TM * 128, b_base = A_BYTES + wn * TN * 128;
 
     // top of a K tile: its LDS-DMA has landed for this wave (counted vmcnt: younger tiles keep flying), then for every wave
-    auto tile_top = [&](int t) {
+    auto wait_landed = [&](int t) {
         // tile t has landed once at most (tiles still allowed in flight) * LPT loads are outstanding
         const int younger = nt - 1 - t;  // tiles issued after t (capped by the prefetch distance NS - 2 here)
         if constexpr (((BM + BN) * 8) % NT != 0) {
@@ -285,20 +289,21 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             static_assert(MAXY * LPT < 64, "ring too deep for the 6-bit vmcnt");  // deeper rings wait conservatively (at most 5 tiles in flight)
             wait_tiles<LPT, MAXY>(younger);
         }
+    };
+    auto tile_top = [&](int t) {
+        wait_landed(t);
         if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
     };
     // one K tile: 4 k-steps of MFMAs with fragment double buffering (the ds_reads of k-step ks+1 are issued before the MFMAs
     // of k-step ks); RF: tile t + NS - 1 is staged into the slot of tile t-1 on the way
     bf16x8 abl_frag;
     if constexpr (ABL & 2) { abl_frag = *reinterpret_cast<const bf16x8*>(smem + lane * 16); asm volatile("" : "+v"(abl_frag)); }
-    // POS: where this wave issues the refill (SK): 0 = behind the barrier, 1 = after the MFMAs of k-step 1, 2 = after those of k-step 3
-    auto ktile = [&](int t, auto RF, auto POS) {
+    auto ktile = [&](int t, auto RF) {
         constexpr bool rf = decltype(RF)::value && !(ABL & 4);
-        constexpr int pos = decltype(POS)::value;
         f32x16 (&acc_r)[FM][FN] = acc;
         const char* cT = smem + ((ABL & 2) ? 0 : (t % NS)) * STAGE_BYTES;
         long ra_off = 0;
-        if constexpr (rf && pos == 0) {
+        if constexpr (rf) {
             if constexpr (SP) ra_off = a_offset(t + NS - 1); else stage(t + NS - 1);
         }
         bf16x8 af[2][FM], bfr[2][FN];
@@ -345,13 +350,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);
             }
-            if constexpr (rf && pos != 0) {
-                if ((pos == 1 && ks == 1) || (pos == 2 && ks == 3)) {   // this group's refill point: behind the MFMAs just queued
-                    __builtin_amdgcn_sched_barrier(0);
-                    stage(t + NS - 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
         }
         // keep the accumulators resident in AGPRs across the back edge: without this hipcc copies all of them to VGPRs
         // and back around every barrier (64+ v_accvgpr moves per K tile, and the copy-out waits for the MFMAs to drain)
@@ -362,19 +360,67 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     };
     // steady state (every tile refills the ring) and drain (the last NS - 1 tiles): two loops, each with ONE straight-line body
     const int nt_refill = nt - (NS - 1) > 0 ? nt - (NS - 1) : 0;
-    auto kloop = [&](auto POS) {
+    if constexpr (!ROT) {
         int t = 0;
-        for (; t < nt_refill; ++t) { tile_top(t); ktile(t, std::true_type{}, POS); }
-        for (; t < nt; ++t) { tile_top(t); ktile(t, std::false_type{}, POS); }
-    };
-    if constexpr (SK) {
-        constexpr int NG = (WM * WN + 3) / 4;   // groups of 4 waves: one wave per SIMD each
-        const int grp = wave_u >> 2;
-        if (grp == 0) kloop(std::integral_constant<int, 0>{});
-        else if (NG == 2 || grp == 1) kloop(std::integral_constant<int, 1>{});
-        else kloop(std::integral_constant<int, 2>{});
+        for (; t < nt_refill; ++t) { tile_top(t); ktile(t, std::true_type{}); }
+        for (; t < nt; ++t) { tile_top(t); ktile(t, std::false_type{}); }
     } else {
-        kloop(std::integral_constant<int, 0>{});
+        constexpr int G = (WM * WN + 3) / 4;   // groups of 4 waves: one wave per SIMD each
+        static_assert(G == 2 || G == 3, "rotating phases: 8-, 9- or 12-wave tiles");
+        const int ntG = nt * G;
+        auto rot = [&](auto GRP) {
+            constexpr int g = decltype(GRP)::value;
+            constexpr int SW = G - 1 - g;   // sub-phase of tile t at whose end this wave makes sure its pieces of tile t + 1 have landed
+            f32x16 (&acc_r)[FM][FN] = acc;
+            if (nt <= 0) return;
+            wait_landed(0);
+            __builtin_amdgcn_s_barrier();   // tile 0 is visible to every wave
+#pragma unroll
+            for (int b = 0; b < g; ++b) __builtin_amdgcn_s_barrier();   // this group starts g intervals late
+            for (int t = 0; t < nt; ++t) {
+                const int gi = t * G + g;
+                // ---- LOAD(t): the whole K tile's fragments -> registers, then this wave's share of the refill
+                const char* cT = smem + (t % NS) * STAGE_BYTES;
+                bf16x8 af[4][FM], bfr[4][FN];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks] + a_base + i * 4096);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(cT + foff[ks] + b_base + j * 4096);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + NS - 1 < nt) stage(t + NS - 1);
+                if constexpr (SW == 0) { if (t + 1 < nt) wait_landed(t + 1); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();      // global barrier index gi < ntG always
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA(t)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc_r[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc_r[i][j]));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SW == 1) { if (t + 1 < nt) wait_landed(t + 1); }
+                if (gi + 1 < ntG) __builtin_amdgcn_s_barrier();
+                if constexpr (G == 3) {   // idle interval
+                    if constexpr (SW == 2) { if (t + 1 < nt) wait_landed(t + 1); }
+                    if (gi + 2 < ntG) __builtin_amdgcn_s_barrier();
+                }
+            }
+        };
+        const int grp = wave_u >> 2;
+        if (grp == 0) rot(std::integral_constant<int, 0>{});
+        else if (G == 2 || grp == 1) rot(std::integral_constant<int, 1>{});
+        else rot(std::integral_constant<int, G - 1>{});
     }
 
     // ---- epilogue (lane <-> output element mapping: see store_tile) ----
@@ -742,7 +788,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
 }
 
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool SK = false, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool ROT = false, int ABL = 0>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
@@ -775,11 +821,11 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     if (dev < 0 || dev >= 32) return 1;
     if constexpr (NS > 0) {
         if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP, SK, ABL>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP, ROT, ABL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP, SK, ABL>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP, ROT, ABL>), grid, dim3(64 * WM * WN), SMEM, st, a);
     } else {
         if (!attr_set[dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
@@ -813,12 +859,14 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 template <int EPI>
 int launch_e(const GemmArgs& a, hipStream_t st) {
     const bool sp = a.dma_spread != 0;
-    const bool sk = a.skew != 0 && !sp && !a.conv_cpb;   // skewed-refill variants exist for the burst form of the step's tiles
-    if ((a.debug >> 4) && (a.tile == 13 || a.tile == 9) && (EPI == EPI_GEGLU || EPI == EPI_PARTIAL)) {   // timing ablations (tools/_run/ablate.py)
+    const bool sk = a.rot != 0 && !sp && !a.conv_cpb;   // rotating-phase variants exist for the step's tiles
+#ifdef EZ_ABLATE   // timing ablations of the K loop (tools/ablate_gemm.py; build with EZAUDIO_ABLATE=1): not part of the product library
+    if ((a.debug >> 4) && (a.tile == 13 || a.tile == 9) && (EPI == EPI_GEGLU || EPI == EPI_PARTIAL)) {
 #define EZ_ABL(n) case n: return a.tile == 13 ? launch_t<128, 288, 4, 3, 3, EPI, false, false, n>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false, false, n>(a, st);
         switch (a.debug >> 4) { EZ_ABL(1) EZ_ABL(2) EZ_ABL(3) EZ_ABL(4) EZ_ABL(5) EZ_ABL(6) EZ_ABL(7) EZ_ABL(8) EZ_ABL(12) EZ_ABL(15) EZ_ABL(9) EZ_ABL(11) default: break; }
 #undef EZ_ABL
     }
+#endif
     switch (a.tile) {
         case 0: return launch_t<128, 128, 2, 2, 4, EPI>(a, st);
         case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
@@ -851,7 +899,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         const bool sp = a.dma_spread != 0;
         if (a.hn.dh == 72) {
             if (a.tile != 1) return launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
-            if (a.skew && !sp) return launch_t<64, 288, 1, 9, 3, EPI_QKV, false, true>(a, st);
+            if (a.rot && !sp) return launch_t<64, 288, 1, 9, 3, EPI_QKV, false, true>(a, st);
             return sp ? launch_t<64, 288, 1, 9, 3, EPI_QKV, true>(a, st) : launch_t<64, 288, 1, 9, 3, EPI_QKV, false>(a, st);
         }
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
@@ -865,7 +913,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
             return 1;
         // panel placement: one workgroup per CU on EVERY XCD (32 CUs each), M tile tm on XCD tm % 8
         if (a.xcd_panel && (long)((a.N + 127) / 128) * a.splitk * (((a.M + 127) / 128 + 7) / 8) > 32) return 1;
-        if (a.skew && !a.dma_spread) return launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false, true>(a, st);
+        if (a.rot && !a.dma_spread) return launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false, true>(a, st);
         return a.dma_spread ? launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);

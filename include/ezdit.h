@@ -219,7 +219,16 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *     wave per row)
  *   dma_spread 0/1 (GEMM: LDS-DMA refill pieces issued one k-step apart / as one burst), cn_overlap 0/1 (fused sampler: ControlNet
  *     branch on a side stream next to the backbone's in-blocks)
- *   fuse_row 0/1 (M <= 2048: residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch)
+ *   fuse_row 0/1/2 (M <= 2048: residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch; 1 = agent-scope
+ *     hand-off under any placement, 2 = all workgroups of an M tile on one XCD and the hand-off through that XCD's L2, with the
+ *     agent-scope protocol as the in-launch fallback when the arrival word shows another placement), fuse_mask (shapes mode 2 applies to:
+ *     1 D x D projections, 2 skip_linear, 4 MLP-out), fuse_flags (A/B bits of mode 1)
+ *   gemm_panel (bit mask over the same shapes, M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
+ *     row_affine 0/1 (the row kernel processes row panel p on XCD p % 8): a panel's slabs / residual stream / LayerNorm output stay in
+ *     one XCD's L2 across the kernel boundary.  Placement only.
+ *   rot 0/1 (GEMM: the wave groups of a workgroup run one barrier interval apart, one loading while another issues MFMAs),
+ *     skew_attn 0/1 (cross-attention q projection: the second wave of every SIMD refills behind its MFMAs).  Same results bit for bit.
+ *   gemm_debug (k_gemm2 experiment bits)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 

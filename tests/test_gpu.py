@@ -86,6 +86,20 @@ def t_(a, dev='cuda:0'):
     (500, 300, 192, 41 * 4 + 1, 3),
     (4000, 1152, 2304, 42 * 4 + 1, 2),  # 256x128
     (130, 128, 64, 42 * 4 + 0, 1),
+    (1000, 1152, 1152, 50 * 4 + 1, 3),  # 128x128, 8 waves, ring 4
+    # rotating-phase (ROT) variants: 4000 + v.  Two wave groups (8 waves) and three (12 waves); slices shorter than the ring,
+    # single tiles, ragged M / N: the per-group barrier counts must balance for every K-tile count
+    (1000, 1152, 1152, 4000 + 9 * 4 + 1, 3),
+    (1000, 1152, 4608, 4000 + 9 * 4 + 1, 3),
+    (1000, 1152, 1152, 4000 + 9 * 4 + 1, 9),   # 2 K tiles per slice
+    (300, 256, 192, 4000 + 9 * 4 + 1, 2),      # uneven split: 1 + 2 tiles
+    (130, 128, 64, 4000 + 9 * 4 + 0, 1),       # single K tile
+    (1000, 1152, 1152, 4000 + 13 * 4 + 0, 1),
+    (1000, 1152, 1152, 4000 + 13 * 4 + 1, 6),  # 3 K tiles per slice
+    (500, 300, 192, 4000 + 13 * 4 + 1, 2),
+    (130, 288, 64, 4000 + 13 * 4 + 0, 1),
+    (1000, 1152, 1152, 4000 + 25 * 4 + 0, 1),  # 128x64 ring 4
+    (200, 300, 128, 4000 + 50 * 4 + 1, 1),     # ring 4, two K tiles
 ])
 def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     g = torch.Generator().manual_seed(M + N + K)
@@ -97,7 +111,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     ref = A.float().double() @ W[:N].float().double().T
     Ad, Wd, bd = A.to(dev), W.to(dev), bias.to(dev)
     Mp = (M + 127) // 128 * 128
-    epi = variant % 4
+    epi = variant % 1000 % 4
     if epi == 0:
         out = torch.full((M, N), float('nan'), device=dev)
         rc = lib.ezdit_test_gemm(None, variant, Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), out.data_ptr(), N, M, N, K, 1, None)
@@ -115,7 +129,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13, 40, 41, 42])
+@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13, 40, 41, 42, 1013])   # 1013: tile 13, rotating-phase variant
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
@@ -129,7 +143,8 @@ def test_gemm_geglu_epilogue(lib, dev, tile):
     ref = val * torch.nn.functional.gelu(gate)
     out = torch.zeros(M, inner, dtype=torch.bfloat16, device=dev)
     Ad, Wd, bd = A.to(dev), Wi.to(dev), bi.to(dev)   # keep the device tensors alive across the launch
-    rc = lib.ezdit_test_gemm(None, tile * 4 + 2, Ad.data_ptr(), D, Wd.data_ptr(), D, bd.data_ptr(), out.data_ptr(),
+    variant = (4000 if tile >= 1000 else 0) + (tile % 1000) * 4 + 2
+    rc = lib.ezdit_test_gemm(None, variant, Ad.data_ptr(), D, Wd.data_ptr(), D, bd.data_ptr(), out.data_ptr(),
                              inner, M, 2 * inner, D, 1, None)
     assert rc == 0
     torch.cuda.synchronize()
@@ -410,8 +425,12 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1)),
-                                        ('attn_two_pass', (0, 1))])
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, dma_spread=0, fuse_row=0, attn_two_pass=0, gemm_panel=3, row_affine=1, rot=0, skew_attn=0)
+
+
+@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1, 2)),
+                                        ('attn_two_pass', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)), ('rot', (0, 1)),
+                                        ('skew_attn', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -423,25 +442,29 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     for v in values:
         assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
         outs.append(_forward(m, inp, 499, kw).cpu().numpy())
-    assert lib.ezdit_set_option(m._h, opt.encode(), 0 if opt in ('fuse_row', 'dma_spread', 'attn_two_pass') else 1) == 0   # shipped defaults
-    if opt in ('attn_xcd', 'dma_spread', 'fuse_row'):   # placement / issue order / launch structure only: bitwise identical
-        np.testing.assert_array_equal(outs[0], outs[1])
+    assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0   # shipped defaults
+    if opt not in ('row_variant', 'attn_two_pass'):   # placement / issue order / launch structure / wave phasing only: bitwise identical
+        for o in outs[1:]:
+            np.testing.assert_array_equal(outs[0], o)
     else:   # row_variant, attn_two_pass: same math, different rounding points
         assert rel_l2(outs[0], outs[1]) < 1e-2
         for o in outs:
             assert rel_l2(o, g['pred_t499']) < REL_TOL
 
 
-def test_fused_residual_gemm_handoff_is_stable_under_repetition(lib, dev):
-    """The residual GEMMs of the XL model exchange split-K slabs between workgroups INSIDE a launch (write-through stores, arrival
-    counter, one acquire).  A broken hand-off shows as rare stale rows, so: the shipped XL shape (88 hand-offs per forward), many
+@pytest.mark.parametrize('mode', [1, 2])
+def test_fused_residual_gemm_handoff_is_stable_under_repetition(lib, dev, mode):
+    """The residual GEMMs of the XL model exchange split-K slabs between workgroups INSIDE a launch.  Mode 1: write-through stores, arrival
+    counter, one agent-scope acquire, any placement.  Mode 2: all workgroups of an M tile on one XCD, slabs handed over through that XCD's L2
+    (plain stores, L1-bypassing loads) once the arrival word shows that they really share an XCC, the agent-scope protocol otherwise.
+    A broken hand-off shows as rare stale rows, so: the shipped XL shape (88 hand-offs per forward), many
     repetitions, every output bit compared with the two-launch path, then the device error flag."""
     cfg, sd, inp, kw, g, meta = golden_case('xl')
     m = get_model('xl', meta['seed_w'])
     assert lib.ezdit_set_option(m._h, b'fuse_row', 0) == 0
     ref = _forward(m, inp, 499, kw).clone()
     n_unfused = m.last_launch_count
-    assert lib.ezdit_set_option(m._h, b'fuse_row', 1) == 0
+    assert lib.ezdit_set_option(m._h, b'fuse_row', mode) == 0
     for rep in range(25):
         out = _forward(m, inp, 499, kw)
         assert torch.equal(out, ref), rep
