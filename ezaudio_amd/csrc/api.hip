@@ -133,7 +133,14 @@ struct ezdit_handle {
     // 4.442 ms/step (+1.2 %, three boxes +0.9 ... +1.5 %), L 3.611 -> 3.518 (+2.7 %); the MLP-out shape gains nothing more and re-reads W
     // 8x (94 vs 66 MB fetched per launch), so it keeps the box placement.
     int opt_gemm_panel = 3, opt_row_affine = 1;
-    int opt_rot = 0;                                                                      // k_gemm: rotating load / MFMA phases across the wave groups of a workgroup (ROT variants)
+    // bf16 GEMM epilogues (GEGLU output, split-K slabs, q / k heads of the fused QKV GEMM) staged through LDS and written as whole 16-byte
+    // chunks: in the MFMA C layout a lane owns one row, so a direct store instruction scatters 4-8 bytes into 32-64 different lines.
+    // Bit-identical; XL 4.384 -> 4.281 ms/step (+2.4 %), L +1.8 % for the GEGLU / slab part alone.
+    int opt_epi_lds = 1;
+    int opt_qkv_affine = 0;   // fused QKV GEMM: every tile on the XCD whose attention workgroups read it (single prompt: B * H / 4 == 8)
+    // k_gemm: rotating load / MFMA phases across the wave groups of a workgroup (ROT variants); bit mask over the GEMM kinds:
+    // 1 D x D split-K, 2 skip (K = 2D), 4 MLP-out (K = 4D), 8 GEGLU, 16 fused QKV, 32 fp32-output
+    int opt_rot = 0;
     int opt_skew_attn = 0;                                                                // the same in the cross-attention kernel's fused q projection
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
@@ -429,10 +436,14 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
     g.dma_spread = h->opt_dma_spread;
-    g.rot = h->opt_rot;
+    {   // rot is a bit mask over the GEMM kinds: 1 D x D split-K, 2 skip (K = 2D), 4 MLP-out (K = 4D), 8 GEGLU, 16 fused QKV, 32 fp32-output
+        const int kind = epi == EPI_PARTIAL ? (g.K >= 4 * N ? 4 : g.K >= 2 * N ? 2 : 1) : epi == EPI_GEGLU ? 8 : epi == EPI_QKV ? 16 : 32;
+        g.rot = (h->opt_rot & kind) != 0;
+    }
     g.debug = h->opt_gemm_debug;
+    g.epi_lds = h->opt_epi_lds;
     g.rows_per_b = 1;
-    if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
+    if (c.hn) { g.hn = *c.hn; c.hn = nullptr; g.xcd_qkv = h->opt_qkv_affine && h->opt_attn_xcd; }
     if (c.panel) { g.xcd_panel = 1; c.panel = false; }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
         g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
@@ -854,7 +865,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         g.row.slab_sc1 = 1;
         g.panel_cnt = p.sync; g.dev_err = p.sync + 1000; g.fuse_flags = h->opt_fuse_flags;
-        g.rot = h->opt_rot;
+        g.rot = (h->opt_rot & shape_bit) != 0;
+        g.epi_lds = h->opt_epi_lds;
         if (panel) { g.xcd_panel = 1; g.fuse_flags = 8; g.wt = 0; }
         if (g.fuse_flags & 1) g.wt = 0;
         if (g.fuse_flags & 2) g.row.slab_sc1 = 0;
@@ -1265,6 +1277,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: k_gemm2 experiment bits (GemmArgs.debug); bit 2 (4000 + v): rotating-phase variant
     if (g.debug & 4) g.rot = 1;
+    if (g.debug & 8) g.epi_lds = 1;
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.epi > EPI_GEGLU || g.tile > 63) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
@@ -1345,6 +1358,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "skew_attn")) h->opt_skew_attn = value;
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
+    else if (!strcmp(name, "qkv_affine")) h->opt_qkv_affine = value;
+    else if (!strcmp(name, "epi_lds")) h->opt_epi_lds = value;
     else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;

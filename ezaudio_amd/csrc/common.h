@@ -157,6 +157,9 @@ struct GemmArgs {
     // k_gemm rotating phases (ROT variants of the step's tiles): the wave groups of a workgroup run one barrier interval apart, one
     // group loading (fragment reads + LDS-DMA refill) while another issues MFMAs from registers (gemm.hip)
     int rot;
+    // EPI_QKV: place every tile on the XCD whose attention workgroups consume it (single prompt: B * H / 4 == 8; gemm.hip)
+    int xcd_qkv;
+    int epi_lds;   // k_gemm bf16 epilogues (GEGLU output, bf16 slabs): park the tile in the dead ring and write whole rows, 16 bytes per lane
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 

@@ -139,6 +139,85 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, f32x16 (&acc)[FM][
     }
 }
 
+// bf16 epilogues (GEGLU output, bf16 split-K slabs) through LDS: in the C layout a lane owns ONE row and 4 consecutive columns, so a
+// direct store instruction writes 8 bytes into each of 32 different 128-byte lines (4608 line requests for a 128 x 144 tile).  Parking the
+// tile in the (dead) ring and writing rows with 16 bytes per lane needs ~300.  Same values, same rounding.
+// NPASS = 2: the tile goes out in two row halves (one wave row each) where it does not fit the LDS in one piece (256 x 256 slabs).
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, int EPI, int NPASS = 1>
+__device__ __forceinline__ void store_tile_lds(const GemmArgs& a, f32x16 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid, int z) {
+    static_assert(EPI == EPI_GEGLU || EPI == EPI_PARTIAL, "bf16 outputs only");
+    constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;   // output columns of the tile
+    static_assert(OC % 8 == 0, "16-byte row chunks");
+    constexpr int PITCH = OC + 8;                         // bf16 elements per LDS row
+    constexpr int RP = BM / NPASS;                        // rows per pass
+    static_assert(NPASS == 1 || RP == TM, "a pass is one wave row");
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+    const int row_in = lane & 31, hi = lane >> 5;
+    __syncthreads();   // every wave is done with the last K tile: the ring is dead
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    if (pass > 0) __syncthreads();   // the previous half has been copied out
+    if (NPASS == 1 || wm == pass) {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int r = (NPASS == 1 ? wm * TM : 0) + i * 32 + row_in;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if constexpr (EPI == EPI_GEGLU) {
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const int cv = col0 + wn * TN + j * 32 + 8 * g + 4 * hi;     // packed column of the value (its gate: + 8)
+                    const int oc = (wn * TN + j * 32 + 8 * g) / 2 + 4 * hi;       // inner index within the tile
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+                    if (a.bias && cv < a.N) {
+                        bv = *reinterpret_cast<const float4*>(a.bias + cv);
+                        bg = *reinterpret_cast<const float4*>(a.bias + cv + 8);
+                    }
+                    const float v0 = acc[i][j][4 * g + 0] + bv.x, g0 = acc[i][j][4 * g + 4] + bg.x;
+                    const float v1 = acc[i][j][4 * g + 1] + bv.y, g1 = acc[i][j][4 * g + 5] + bg.y;
+                    const float v2 = acc[i][j][4 * g + 2] + bv.z, g2 = acc[i][j][4 * g + 6] + bg.z;
+                    const float v3 = acc[i][j][4 * g + 3] + bv.w, g3 = acc[i][j][4 * g + 7] + bg.w;
+                    uint2 o;
+                    o.x = pack_bf2(v0 * gelu_erf(g0), v1 * gelu_erf(g1));
+                    o.y = pack_bf2(v2 * gelu_erf(g2), v3 * gelu_erf(g3));
+                    *reinterpret_cast<uint2*>(tile + r * PITCH + oc) = o;
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = wn * TN + j * 32 + 8 * g + 4 * hi;
+                    uint2 o;
+                    o.x = pack_bf2(acc[i][j][4 * g], acc[i][j][4 * g + 1]);
+                    o.y = pack_bf2(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    *reinterpret_cast<uint2*>(tile + r * PITCH + c) = o;
+                }
+            }
+        }
+    }
+    }
+    __syncthreads();
+    constexpr int CPR = OC / 8;   // 16-byte chunks per row
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (EPI == EPI_PARTIAL ? (long)z * a.slab_stride : 0);
+    const int ocol0 = EPI == EPI_GEGLU ? col0 / 2 : col0;
+    const int ncols = EPI == EPI_GEGLU ? a.N / 2 : a.N;
+    for (int q = tid; q < RP * CPR; q += NT) {
+        const int r = q / CPR, c = (q % CPR) * 8;
+        const int grow = row0 + pass * RP + r, gcol = ocol0 + c;
+        if (grow < a.M && gcol < ncols) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + r * PITCH + c);
+            bf16_t* dst = out + (long)grow * a.ldo + gcol;
+            if (gcol + 8 <= ncols) {
+                if (a.wt) st16_wt(dst, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+                else *reinterpret_cast<uint4*>(dst) = v;
+            } else {   // ragged last chunk (N is a multiple of 4 for every caller)
+                const bf16_t* src = tile + r * PITCH + c;
+                for (int e = 0; e < ncols - gcol; ++e) dst[e] = src[e];
+            }
+        }
+    }
+  }
+}
+
 // XCD-aware tile map shared by both kernels: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the
 // (M tiles x N tiles x K splits) grid, M tiles fastest inside.  Returns false for a padding slot of a ragged box.
 __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn, int& z) {
@@ -197,6 +276,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         tm = xcd + 8 * (l / G);
         tn = (l % G) / a.splitk;
         z = (l % G) % a.splitk;
+    } else if (EPI == EPI_QKV && a.xcd_qkv) {
+        // consumer placement: the attention kernel runs the 4 consecutive (batch, head) pairs 4x .. 4x + 3 on XCD x (launch_attention, ppx = 4),
+        // and one N tile of this GEMM is q, k or v of exactly such a group of 4 heads: XCD x = (batch b, head group hg) computes the
+        // M tiles of batch b for the N tiles {q, k, v} x hg, so what attention reads was written into the L2 it reads from
+        const int hq = a.hn.H / 4;
+        const int b = xcd / hq, hg = xcd % hq;
+        const int t0 = (b * a.hn.L + BM - 1) / BM;
+        const int t1 = b + 1 < a.hn.B ? ((b + 1) * a.hn.L + BM - 1) / BM : tilesM;
+        tm = t0 + l % a.bm;
+        tn = (l / a.bm) * hq + hg;
+        z = 0;
+        if (tm >= t1 || l / a.bm >= 3) return;
     } else {
         const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
         const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
@@ -432,7 +523,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         static_assert((BN == 288 || BN == 256) && BM == 64, "EPI_QKV is built for 64 x (4 heads) tiles");
         constexpr int DH = BN / 4, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
         float* tile = reinterpret_cast<float*>(smem);            // [BM][PITCH] fp32, reuses the ring
-        static_assert(BM * PITCH * 4 <= NS * STAGE_BYTES, "epilogue tile must fit the ring");
+        bf16_t* qk_st = reinterpret_cast<bf16_t*>(smem + BM * PITCH * 4);   // [BM][4][DH] bf16: normalised q / k heads on their way out
+        static_assert(BM * PITCH * 4 + BM * BN * 2 <= NS * STAGE_BYTES && (BM * PITCH * 4) % 16 == 0 && (DH * 2) % 16 == 0, "epilogue tile + staging must fit the ring");
         __syncthreads();                                          // every wave is done with the last K tile
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -492,10 +584,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                         v[i] = v[i] * cs[i] + sign * other * sn[i];
                     }
                 }
-                if (ok) {
+                if (a.epi_lds) {   // park the bf16 head in LDS: written out below as whole 16-byte chunks (a head is 9 or 8 of them)
+                    bf16_t* dst = qk_st + (r * 4 + hh) * DH + sub * E;
+#pragma unroll
+                    for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
+                } else if (ok) {
                     bf16_t* dst = dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + sub * E;
 #pragma unroll
                     for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
+                }
+            }
+            if (a.epi_lds) {
+                // the direct form writes 4 bytes per lane, 36 bytes apart: 64 separate segments per store instruction (~5000 line requests
+                // per tile); from LDS every lane moves 16 contiguous bytes of one (row, head)
+                __syncthreads();
+                constexpr int CP = DH * 2 / 16;
+                for (int q = tid; q < BM * 4 * CP; q += NT) {
+                    const int c8 = q % CP, hh = (q / CP) & 3, r = q / (CP * 4);
+                    const int m = row0 + r;
+                    if (m < a.M) {
+                        const int b = m / hn.L, l = m % hn.L;
+                        *reinterpret_cast<uint4*>(dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + c8 * 8) =
+                            *reinterpret_cast<const uint4*>(qk_st + (r * 4 + hh) * DH + c8 * 8);
+                    }
                 }
             }
         } else {
@@ -533,7 +644,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
         // deadlock on this kernel's own dispatch; it is bounded anyway and reports through dev_err.
         // fuse_flags (A/B): 1 = plain slab stores + ONE agent-scope release per workgroup instead of write-through stores;
         //                   2 = plain slab loads behind the acquire instead of sc1 loads; 4 = coarser poll (s_sleep 32)
-        store_tile<FM, FN, TM, TN, EPI_PARTIAL>(a, acc, row0, col0, wm, wn, lane, z);
+        if (a.epi_lds) store_tile_lds<BM, BN, FM, FN, TM, TN, NT, EPI_PARTIAL>(a, acc, smem, row0, col0, wm, wn, lane, tid, z);
+        else store_tile<FM, FN, TM, TN, EPI_PARTIAL>(a, acc, row0, col0, wm, wn, lane, z);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const unsigned total = (unsigned)(tilesN * a.splitk);
@@ -610,6 +722,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
             for (int r = first + wave_u * (int)total; r < rows; r += WM * WN * (int)total) row_wave<false>(a.row, row0 + r, lane);
         }
     } else {
+        constexpr bool lds_ok = (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) && BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE_BYTES;
+        if constexpr (lds_ok) {
+            if (a.epi_lds && (EPI == EPI_GEGLU || a.part_bf16)) {
+                store_tile_lds<BM, BN, FM, FN, TM, TN, NT, EPI>(a, acc, smem, row0, col0, wm, wn, lane, tid, z);
+                return;
+            }
+        }
         store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
     }
 }
@@ -784,6 +903,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     }
 #undef EZ_READ_KS
 #undef EZ_MFMA_KS
+    if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
+        constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;
+        constexpr int NPASS = BM * (OC + 8) * 2 <= 2 * STAGE_BYTES ? 1 : 2;
+        static_assert((BM / NPASS) * (OC + 8) * 2 <= 2 * STAGE_BYTES, "epilogue tile must fit the two stages");
+        if (a.epi_lds && (EPI == EPI_GEGLU || a.part_bf16)) {
+            store_tile_lds<BM, BN, FM, FN, TM, TN, NT, EPI, NPASS>(a, acc, smem, row0, col0, wm, wn, lane, tid, z);
+            return;
+        }
+    }
     store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
 }
 
@@ -812,6 +940,17 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
     if ((EPI == EPI_PARTIAL_ROW || EPI == EPI_PARTIAL) && a.xcd_panel && NS > 0) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
     else a.xcd_panel = 0;
+    if (EPI == EPI_QKV && a.xcd_qkv && a.hn.H % 4 == 0 && a.hn.B * (a.hn.H / 4) == 8 && tilesN == 3 * (a.hn.H / 4) && S == 1) {
+        int nmax = 0;   // M tiles per batch element (a tile belongs to the batch element of its first row)
+        for (int b = 0; b < a.hn.B; ++b) {
+            const int t0 = (b * a.hn.L + BM - 1) / BM, t1 = b + 1 < a.hn.B ? ((b + 1) * a.hn.L + BM - 1) / BM : tilesM;
+            nmax = t1 - t0 > nmax ? t1 - t0 : nmax;
+        }
+        a.bm = nmax;
+        grid.x = 8 * 3 * nmax;
+    } else {
+        a.xcd_qkv = 0;
+    }
     constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device

@@ -226,7 +226,8 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   gemm_panel (bit mask over the same shapes, M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
  *     row_affine 0/1 (the row kernel processes row panel p on XCD p % 8): a panel's slabs / residual stream / LayerNorm output stay in
  *     one XCD's L2 across the kernel boundary.  Placement only.
- *   rot 0/1 (GEMM: the wave groups of a workgroup run one barrier interval apart, one loading while another issues MFMAs),
+ *   rot (GEMM: the wave groups of a workgroup run one barrier interval apart, one loading while another issues MFMAs; bit mask over
+ *     the GEMM kinds: 1 D x D split-K, 2 skip_linear, 4 MLP-out, 8 GEGLU, 16 fused QKV, 32 fp32-output),
  *     skew_attn 0/1 (cross-attention q projection: the second wave of every SIMD refills behind its MFMAs).  Same results bit for bit.
  *   gemm_debug (k_gemm2 experiment bits)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */

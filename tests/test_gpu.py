@@ -129,7 +129,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13, 40, 41, 42, 1013])   # 1013: tile 13, rotating-phase variant
+@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13, 40, 41, 42, 1013, 2013, 2012, 3013, 2040, 2041, 2042])   # + 1000: rotating phases, + 2000: LDS-staged epilogue
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
@@ -143,7 +143,7 @@ def test_gemm_geglu_epilogue(lib, dev, tile):
     ref = val * torch.nn.functional.gelu(gate)
     out = torch.zeros(M, inner, dtype=torch.bfloat16, device=dev)
     Ad, Wd, bd = A.to(dev), Wi.to(dev), bi.to(dev)   # keep the device tensors alive across the launch
-    variant = (4000 if tile >= 1000 else 0) + (tile % 1000) * 4 + 2
+    variant = 4000 * (tile // 1000) + (tile % 1000) * 4 + 2
     rc = lib.ezdit_test_gemm(None, variant, Ad.data_ptr(), D, Wd.data_ptr(), D, bd.data_ptr(), out.data_ptr(),
                              inner, M, 2 * inner, D, 1, None)
     assert rc == 0
@@ -425,12 +425,13 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, dma_spread=0, fuse_row=0, attn_two_pass=0, gemm_panel=3, row_affine=1, rot=0, skew_attn=0)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, dma_spread=0, fuse_row=0, attn_two_pass=0, gemm_panel=3, row_affine=1, rot=0, skew_attn=0, epi_lds=1,
+                    qkv_affine=0)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1, 2)),
-                                        ('attn_two_pass', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)), ('rot', (0, 1)),
-                                        ('skew_attn', (0, 1))])
+                                        ('attn_two_pass', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)), ('rot', (0, 63)),
+                                        ('skew_attn', (0, 1)), ('epi_lds', (0, 1)), ('qkv_affine', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
