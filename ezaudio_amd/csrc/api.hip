@@ -137,10 +137,13 @@ struct ezdit_handle {
     // chunks: in the MFMA C layout a lane owns one row, so a direct store instruction scatters 4-8 bytes into 32-64 different lines.
     // Bit-identical; XL 4.384 -> 4.281 ms/step (+2.4 %), L +1.8 % for the GEGLU / slab part alone.
     int opt_epi_lds = 1;
-    int opt_qkv_affine = 0;   // fused QKV GEMM: every tile on the XCD whose attention workgroups read it (single prompt: B * H / 4 == 8)
+    int opt_qkv_affine = 1;   // fused QKV GEMM: every tile on the XCD whose attention workgroups read it (single prompt: B * H / 4 == 8); +0.2 ... 0.5 %
     // k_gemm: rotating load / MFMA phases across the wave groups of a workgroup (ROT variants); bit mask over the GEMM kinds:
     // 1 D x D split-K, 2 skip (K = 2D), 4 MLP-out (K = 4D), 8 GEGLU, 16 fused QKV, 32 fp32-output
     int opt_rot = 0;
+    // cross-attention q projection: two K tiles per ring slot, barrier and counted wait (a wave's work per K tile is 3 MFMAs: the loop is its
+    // fixed cost per iteration).  Bit-identical; XL 4.319 -> 4.285 ms/step (+0.8 %), L +1.1 %.
+    int opt_attn_xk2 = 1;
     int opt_skew_attn = 0;                                                                // the same in the cross-attention kernel's fused q projection
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
@@ -971,7 +974,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (fuse_q2) {
             at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
-            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.skew = h->opt_skew_attn;
+            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.skew = h->opt_skew_attn; at.xk2 = h->opt_attn_xk2;
         } else {
             gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
@@ -1356,6 +1359,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_mask")) h->opt_fuse_mask = value;
     else if (!strcmp(name, "rot")) h->opt_rot = value;
     else if (!strcmp(name, "skew_attn")) h->opt_skew_attn = value;
+    else if (!strcmp(name, "attn_xk2")) h->opt_attn_xk2 = value;
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
     else if (!strcmp(name, "qkv_affine")) h->opt_qkv_affine = value;

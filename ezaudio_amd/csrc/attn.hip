@@ -55,7 +55,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     // fused projection (NKH == 4): 3-deep ring of [64 rows of x | DN rows of W] K tiles, then 4 partial [64][DS] fp32 tiles
     constexpr int DN = DV >= 96 ? 96 : 64;    // W rows staged per K tile (32-row MFMA fragments covering dh)
     constexpr int DS = DQK;                   // columns kept of each partial
-    constexpr int PSTAGE = (64 + DN) * 128, PRING = 3 * PSTAGE;
+    constexpr int PSTAGE = (64 + DN) * 128, PRING = 6 * PSTAGE;   // 3 ring slots of TWO K tiles each (a.xk2) or 3 of one
     constexpr int PRED = 4 * 64 * DS * 4, PQS = 64 * DQK * 2;
     constexpr int SMEM = NKH == 4 ? (2 * BUF > PRED + PQS ? (2 * BUF > PRING ? 2 * BUF : PRING) : (PRED + PQS > PRING ? PRED + PQS : PRING)) : 2 * BUF;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -118,6 +118,41 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
             const uint32_t fo = r32 * 128 + (((2 * kq + hi) ^ ((r32 >> 1) & 7)) << 4);
+            if (a.xk2 && (nt & 1) == 0) {
+                // double-width stages: one barrier and one counted wait per TWO K tiles (128 of K).  The per-tile work of a wave is 3 MFMAs, so
+                // the loop is its fixed cost per iteration (wait + barrier + refill issue), which halves; the ring holds 3 x 40 KB.
+                const int ns = nt >> 1;
+                auto stage2 = [&](int sidx) {
+                    char* dst = smem + (sidx % 3) * 2 * PSTAGE + wave_u * 1024;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        stage_tile<64, NT>(gA + (long)(2 * sidx + sub) * 128, aoff, dst + sub * PSTAGE, tid);
+                        stage_tile<DN, NT>(gW + (long)(2 * sidx + sub) * 128, boff, dst + sub * PSTAGE + 64 * 128, tid);
+                    }
+                };
+                if (ns > 1) stage2(1);   // the prologue above (tiles 0 and 1 into slots 0 and PSTAGE) IS stage 0 of this layout
+                for (int sidx = 0; sidx < ns; ++sidx) {
+                    if (sidx + 1 < ns) {
+                        if (two) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    if (sidx + 2 < ns) stage2(sidx + 2);
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const char* cT = smem + (sidx % 3) * 2 * PSTAGE + sub * PSTAGE;
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(cT + fo + mh * 4096);
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(cT + 64 * 128 + fo + j * 4096);
+                            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[j], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[j]));
+                }
+            } else
             for (int t = 0; t < nt; ++t) {
                 if (t + 1 < nt) {   // tile t + 1 may stay in flight
                     if (two) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");

@@ -183,7 +183,8 @@ struct AttnArgs {
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
     int two_pass;               // allow the two-pass form (k_attn2) where it applies: 128 < Lk <= 512 keys, plain q operand, 8 waves
-    int skew;                   // fused projection: skewed refill (see GemmArgs.skew)
+    int skew;                   // fused projection: waves 4-7 refill behind their MFMAs instead of behind the barrier
+    int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 

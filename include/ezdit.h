@@ -229,6 +229,8 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   rot (GEMM: the wave groups of a workgroup run one barrier interval apart, one loading while another issues MFMAs; bit mask over
  *     the GEMM kinds: 1 D x D split-K, 2 skip_linear, 4 MLP-out, 8 GEGLU, 16 fused QKV, 32 fp32-output),
  *     skew_attn 0/1 (cross-attention q projection: the second wave of every SIMD refills behind its MFMAs).  Same results bit for bit.
+ *   epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks), qkv_affine 0/1 (fused QKV GEMM: every tile
+ *     on the XCD whose attention workgroups read it), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
  *   gemm_debug (k_gemm2 experiment bits)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);

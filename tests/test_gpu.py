@@ -426,12 +426,12 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
 
 
 DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, dma_spread=0, fuse_row=0, attn_two_pass=0, gemm_panel=3, row_affine=1, rot=0, skew_attn=0, epi_lds=1,
-                    qkv_affine=0)
+                    qkv_affine=1, attn_xk2=1)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1, 2)),
                                         ('attn_two_pass', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)), ('rot', (0, 63)),
-                                        ('skew_attn', (0, 1)), ('epi_lds', (0, 1)), ('qkv_affine', (0, 1))])
+                                        ('skew_attn', (0, 1)), ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
