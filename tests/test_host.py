@@ -230,3 +230,65 @@ def test_source_hash_tracks_kernel_sources():
     from ezaudio_amd.build import source_hash
     h = source_hash()
     assert len(h) == 16 and h == source_hash()
+
+
+def test_rotating_phase_schedule_is_hazard_free_model():
+    """Executable restatement of the ROT schedule of k_gemm (csrc/gemm.hip): G wave groups one barrier interval apart, group g in interval
+    t G + g reads the fragments of K tile t and issues its LDS-DMA pieces of tile t + NS - 1, in interval t G + g + 1 it issues the MFMAs, and
+    at the end of its sub-phase G - 1 - g of tile t it waits for its own pieces of tile t + 1.  The model replays the per-group programs
+    against one global barrier counter and checks, for every (G, NS, nt): all groups execute the same number of barriers; a tile is read
+    only after EVERY group has waited for its pieces of that tile before an earlier barrier; a ring slot is refilled only after the last
+    reader of its previous tile has passed a barrier behind its reads."""
+    for G in (2, 3):
+        for NS in (3, 4):
+            for nt in range(1, 12):
+                ntG = nt * G
+                # per group: list of (barrier_index_after_which_the_event_happens, kind, tile); events between barrier k-1 and barrier k have time k
+                events = []          # (time, group, kind, tile)
+                n_barriers = []
+                for g in range(G):
+                    SW = G - 1 - g
+                    k = 0            # barriers executed so far by this group
+                    issued = list(range(min(nt, NS - 1)))           # prologue tiles (all groups)
+                    for t in issued:
+                        events.append((0, g, 'issue', t))
+                    events.append((0, g, 'wait', 0))                # wait_landed(0)
+                    k += 1                                          # the "tile 0 visible" barrier
+                    k += g                                          # idle intervals
+                    for t in range(nt):
+                        gi = t * G + g
+                        events.append((k, g, 'read', t))
+                        if t + NS - 1 < nt:
+                            events.append((k, g, 'issue', t + NS - 1))
+                        if SW == 0 and t + 1 < nt:
+                            events.append((k, g, 'wait', t + 1))
+                        k += 1                                      # barrier gi (always < ntG)
+                        events.append((k, g, 'mfma', t))
+                        if SW == 1 and t + 1 < nt:
+                            events.append((k, g, 'wait', t + 1))
+                        if gi + 1 < ntG:
+                            k += 1
+                        if G == 3:
+                            if SW == 2 and t + 1 < nt:
+                                events.append((k, g, 'wait', t + 1))
+                            if gi + 2 < ntG:
+                                k += 1
+                    n_barriers.append(k)
+                assert len(set(n_barriers)) == 1, (G, NS, nt, n_barriers)          # nobody waits for a wave that never arrives
+                assert n_barriers[0] == ntG + 1
+                wait_time = {(g, t): tm for tm, g, kind, t in events if kind == 'wait'}
+                issue_time = {(g, t): tm for tm, g, kind, t in events if kind == 'issue'}
+                read_time = {(g, t): tm for tm, g, kind, t in events if kind == 'read'}
+                for t in range(nt):
+                    first_read = min(read_time[(g, t)] for g in range(G))
+                    for g in range(G):
+                        assert issue_time[(g, t)] <= wait_time[(g, t)]                  # a wave waits for pieces it has issued
+                        assert wait_time[(g, t)] < first_read, (G, NS, nt, t, g)        # RAW: landed + a barrier before anyone reads
+                    if t >= NS:                                                          # tile t reuses the slot of tile t - NS
+                        last_read_prev = max(read_time[(g, t - NS)] for g in range(G))
+                        first_issue = min(issue_time[(g, t)] for g in range(G))
+                        assert last_read_prev < first_issue, (G, NS, nt, t)             # WAR: a barrier between last read and refill
+                    # the counted wait: when group g waits for tile t it has issued exactly the tiles up to min(nt - 1, t + NS - 2)
+                    for g in range(G):
+                        issued_by_then = [tt for (gg, tt), tm in issue_time.items() if gg == g and tm <= wait_time[(g, t)]]
+                        assert max(issued_by_then) == min(nt - 1, t + NS - 2), (G, NS, nt, t, g)
