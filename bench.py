@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
-GEGLU_VARIANT = 13 * 4 + 2  # ezdit_test_gemm: tile config 12 (128x288, 12 waves: what the step uses at M <= 2048), GEGLU epilogue
+GEGLU_VARIANT = 8000 + 13 * 4 + 2  # ezdit_test_gemm: tile config 13 (128x288, 12 waves, ring 3: what the step uses at M <= 2048), GEGLU epilogue staged through LDS (8000: the shipped epi_lds form)
 
 
 def load_yaml(path):
