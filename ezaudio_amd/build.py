@@ -49,7 +49,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'ezdit.h')]
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.h')] + [os.path.join(HERE, '..', 'include', 'ezdit.h')]
     hipcc = _hipcc()
     jobs = []
     for src in SOURCES:

@@ -108,6 +108,7 @@ struct ezdit_handle {
     int opt_tile_partial_big = 40, opt_tile_f32_big = 10, opt_geglu_big = 40, opt_split_big = 0;
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
     int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
+    int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp) at M <= 2048: bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); the residual GEMMs select it through tile_partial = 62
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 0;                                                                       // write-through (sc1) output stores
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
@@ -931,7 +932,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64) && D % (4 * h->dh) == 0) {
             // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
             c.hn = &hn;
-            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, h->opt_qkv_waves9);
+            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, ((h->opt_gemm_pp & 2) && M <= 2048) ? 61 : h->opt_qkv_waves9);
         } else {
             gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32,
                  (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
@@ -1005,7 +1006,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU,
-             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? 13 : h->opt_geglu_big));
+             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? ((h->opt_gemm_pp & 1) ? 60 : 13) : h->opt_geglu_big));
         STOPCHK();
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
         const float* b2 = w.b2;
@@ -1267,6 +1268,9 @@ int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream
 }
 
 // ------------------------------------------------------------------------------------------------------
+static unsigned long long* g_gemm_ts = nullptr;
+int ezdit_debug_gemm_timestamps(void* dev_buf) { g_gemm_ts = static_cast<unsigned long long*>(dev_buf); return EZDIT_OK; }
+
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                     int ldo, int M, int N, int K, int splitk, ezdit_stream stream) {
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
@@ -1281,8 +1285,10 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: k_gemm2 experiment bits (GemmArgs.debug); bit 2 (4000 + v): rotating-phase variant
     if (g.debug & 4) g.rot = 1;
     if (g.debug & 8) g.epi_lds = 1;
+    if (g.debug & 16) g.part_bf16 = 1;   // 16000 + v: bf16 split-K slabs
+    g.ts = g_gemm_ts;
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
-    if (g.epi > EPI_GEGLU || g.tile > 63) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
+    if (g.epi > EPI_GEGLU || g.tile > 127) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     (void)hipGetLastError();
     if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "gemm variant %d not supported", variant);
@@ -1367,6 +1373,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
+    else if (!strcmp(name, "gemm_pp")) h->opt_gemm_pp = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;

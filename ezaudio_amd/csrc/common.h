@@ -159,6 +159,7 @@ struct GemmArgs {
     int rot;
     // EPI_QKV: place every tile on the XCD whose attention workgroups consume it (single prompt: B * H / 4 == 8; gemm.hip)
     int xcd_qkv;
+    unsigned long long* ts;   // test hook (k_gemm_pp): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
     int epi_lds;   // k_gemm bf16 epilogues (GEGLU output, bf16 slabs): park the tile in the dead ring and write whole rows, 16 bytes per lane
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)

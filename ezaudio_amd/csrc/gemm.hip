@@ -21,31 +21,11 @@
 //     (launch-boundary reduce, see rowops.hip), so no atomics and bitwise-deterministic results.
 #include "common.h"
 #include "rowbody.h"
+#include "gemm_pp.h"
 
 #include <type_traits>
 
 namespace {
-
-// exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
-// fp32-rounding class and far below the bf16 rounding of the result): ~14 VALU instead of ~40 for erff -- the GEGLU
-// epilogue evaluates it 16x per lane and the kernel is instruction-issue bound.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float erf_abs = 1.0f - p * t * e;
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // wait until at most `younger` (0 .. MAXY) whole tiles of PER loads each are still in flight
 template <int PER, int MAXY>
@@ -216,19 +196,6 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& a, f32x16 (&acc)[
         }
     }
   }
-}
-
-// XCD-aware tile map shared by both kernels: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the
-// (M tiles x N tiles x K splits) grid, M tiles fastest inside.  Returns false for a padding slot of a ragged box.
-__device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn, int& z) {
-    const int xcd = blockIdx.x & 7;
-    const int l = blockIdx.x >> 3;
-    const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
-    const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
-    tm = xm * a.bm + lm;
-    tn = xn * a.bn + ln;
-    z = xz * a.bz + lz;
-    return tm < tilesM && tn < tilesN && z < a.splitk;
 }
 
 // SP: the LDS-DMA pieces of a refill are issued one k-step apart behind that k-step's fragment reads (true) or as one burst
@@ -915,6 +882,52 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
     store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
 }
 
+// choose the 8-box partition (pm x pn x pz boxes of bm x bn x bz tiles, one box per XCD) with the smallest per-XCD operand footprint
+// (bytes of A + W one XCD touches); returns the grid size
+int pick_boxes(GemmArgs& a, int BM, int BN) {
+    const int tilesM = (a.M + BM - 1) / BM;
+    const int tilesN = (a.N + BN - 1) / BN;
+    const int S = a.splitk;
+    double best = 1e30;
+    for (int pm = 1; pm <= 8; pm *= 2)
+        for (int pn = 1; pm * pn <= 8; pn *= 2) {
+            const int pz = 8 / (pm * pn);
+            if (pz > S && pz != 1) continue;
+            if (a.xcd_map == 0 && !(pm == 1 && pn == 8)) continue;
+            const int bm = (tilesM + pm - 1) / pm, bn = (tilesN + pn - 1) / pn, bz = (S + pz - 1) / pz;
+            const double rows = (double)(bm * BM < a.M ? bm * BM : a.M) + (double)(bn * BN < a.N ? bn * BN : a.N);
+            double fp = rows * ((double)a.K * bz / S) * 2.0;
+            const int slots = bm * bn * bz * 8, work = tilesM * tilesN * S;
+            fp *= (double)slots / work;                       // ragged boxes waste launch slots and unbalance XCDs
+            if (pm == 1 && pn == 8) fp *= 0.9;               // near-ties keep the weight stream disjoint across XCDs
+            if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
+        }
+    return 8 * a.bm * a.bn * a.bz;
+}
+
+// ping-pong kernel (gemm_pp.h): 8 waves, two groups one barrier interval apart
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR = 0>
+int launch_pp(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    a.xcd_qkv = 0;
+    dim3 grid(pick_boxes(a, BM, BN), 1, 1);
+    if (EPI == EPI_PARTIAL && a.xcd_panel && BM == 128) grid.x = 8 * ((a.N + BN - 1) / BN) * a.splitk * (((a.M + BM - 1) / BM + 7) / 8);   // M tile tm -> XCD tm % 8 (gemm_pp.h)
+    else a.xcd_panel = 0;
+    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096;
+    static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
+    static bool attr_set[32] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return 1;
+    if (!attr_set[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_pp<BM, BN, WM, WN, NS, EPI, SCHED, VAR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((k_gemm_pp<BM, BN, WM, WN, NS, EPI, SCHED, VAR>), grid, dim3(512), SMEM, st, a);
+    return 0;
+}
+
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
 template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool ROT = false, int ABL = 0>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
@@ -1025,6 +1038,43 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
         case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
         case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
         case 50: return sk ? launch_t<128, 128, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 4, EPI, false>(a, st);   // tile 9 with a 4-deep ring (128 KB)
+        // ---- ping-pong kernel (k_gemm_pp): ids 60+; a.debug bits 8.. select the A/B variant (VAR) in the experiment builds
+        //   60  128x288  4x2 waves (32x144)  ring 3  156 KB  SCHED 1   GEGLU GEMM at M <= 2048
+        //   61  128x144  4x1 per group       ring 4  136 KB  SCHED 2 (k-split)
+        //   62  128x128  4x2 waves (32x64)   ring 3   96 KB  SCHED 1
+        //   63  64x128   2x2 per group       ring 4   96 KB  SCHED 2
+        //   64  128x144  4x1 per group       ring 3  102 KB  SCHED 2
+        //   65  128x128  2x2 per group (64x64) ring 4 128 KB SCHED 2
+#ifdef EZ_ABLATE   // timing ablations of the ping-pong K loop (VAR bits 8 / 16 / 32, gemm_pp.h): experiment builds only
+#define EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_)                                                    \
+            case 8: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 8>(a, st);                \
+            case 16: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 16>(a, st);              \
+            case 32: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 32>(a, st);              \
+            case 24: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 24>(a, st);              \
+            case 40: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 40>(a, st);              \
+            case 48: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 48>(a, st);              \
+            case 56: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 56>(a, st);
+#else
+#define EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_)
+#endif
+#define EZ_PPX(BM_, BN_, WM_, WN_, NS_, SC_, ABL_)                                                 \
+        switch (a.debug >> 8) {                                                                    \
+            case 0: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 0>(a, st);                \
+            ABL_                                                                                   \
+            default: return 1;                                                                     \
+        }
+#define EZ_PP(BM_, BN_, WM_, WN_, NS_, SC_) EZ_PPX(BM_, BN_, WM_, WN_, NS_, SC_, )
+#define EZ_PPA(BM_, BN_, WM_, WN_, NS_, SC_) EZ_PPX(BM_, BN_, WM_, WN_, NS_, SC_, EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_))
+        case 60: EZ_PPA(128, 288, 4, 2, 3, 1)
+        case 61: EZ_PPA(128, 144, 4, 1, 4, 2)
+        case 62: EZ_PP(128, 128, 4, 2, 3, 1)
+        case 63: EZ_PP(64, 128, 2, 2, 4, 2)
+        case 64: EZ_PP(128, 144, 4, 1, 3, 2)
+        case 65: EZ_PP(128, 128, 2, 2, 4, 2)
+#undef EZ_PP
+#undef EZ_PPA
+#undef EZ_PPX
+#undef EZ_PP_ABL
         default: break;
     }
     return 1;   // unknown tile id: refuse (the caller reports EZDIT_E_UNSUPPORTED) instead of silently running another configuration
@@ -1034,6 +1084,11 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
 
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.K <= 0 || a.K % BK) return 1;
+    if (a.epi == EPI_QKV && a.tile >= 60) {   // ping-pong kernel, k-split schedule: 128 x (2 whole heads), ring 4
+        if (a.hn.dh == 72) return launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2>(a, st);
+        if (a.hn.dh == 64) return launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2>(a, st);
+        return 1;
+    }
     if (a.epi == EPI_QKV) {   // tiles that hold four whole heads: 64x288 (head_dim 72, 6 waves) or 64x256 (head_dim 64, 8 waves)
         const bool sp = a.dma_spread != 0;
         if (a.hn.dh == 72) {

@@ -1,0 +1,696 @@
+// Ping-pong bf16 MFMA GEMM for M <= ~2000 rows:  C[M,N] = A[M,K] . W[N,K]^T  (nn.Linear layout, both K-contiguous)
+//
+// Same math as k_gemm (gemm.hip; reference: the aten::linear calls of src/models/utils/attention.py:127-129,148,
+// src/models/utils/modules.py:263-277,341-374, src/models/blocks.py:124-128), different K loop.
+//
+// Why: in k_gemm all waves of a workgroup do the same thing at the same time (refill -> fragment reads -> MFMAs -> barrier), so
+// the parts of a K tile add up (measured 1.23 us per 128x288 tile against 0.51 us of MFMAs).  Here a
+// workgroup is 8 waves = TWO GROUPS of 4 (wave w and w + 4 share a SIMD) that run one barrier interval apart: in every
+// interval one group is in its LOAD phase (all fragments of a K tile -> registers, its share of the LDS-DMA refill) and the
+// other in its MFMA phase (36 MFMAs straight out of registers), so each SIMD always has one wave feeding the matrix pipe and one
+// wave feeding the memory pipes.  v_mfma_f32_16x16x32_bf16 (wave tiles that are multiples of 16, e.g. 32 x 144).
+//
+//   SCHED 1 (both groups walk every K tile; wave tile = 1/8 of the block):      interval  2t    2t+1   2t+2
+//       group 0                                                                           LOAD(t) MFMA(t) LOAD(t+1)
+//       group 1                                                                           MFMA(t-1) LOAD(t) MFMA(t)
+//   SCHED 2 (k-split: group g takes the K tiles t = g mod 2; wave tile = 1/4 of the block, the two partial sums are
+//       exchanged through LDS once, after the loop, each group keeping half of the wave tile's rows): interval i = LOAD(i) by
+//       group i & 1, MFMA(i - 1) by the other group.  A ring slot is read in ONE interval, which leaves NS - 1 tiles in flight.
+//
+// LDS image of a K tile (BK = 64): rows [A tile | W tile], 128 B each, filled by global_load_lds (16 B per lane) with the bank
+// swizzle on the SOURCE address (chunk c of row r lands in slot c ^ ((r >> 1) & 7), as in k_gemm); a stage is a whole number
+// of 4-KB pieces (one piece = one LDS-DMA instruction of every thread of a group = 32 rows); a ragged tail piece re-fetches a
+// clamped row into padding so that every wave issues the same number of loads (uniform vmcnt accounting).
+//
+// Hazards (all waits are counted vmcnt on the issuing wave followed by a barrier the readers pass; reads are drained with
+// lgkmcnt(0) before the barrier that precedes the next LDS-DMA into the slot):
+//   SCHED 1: tile u's pieces are issued in LOAD(u - PD) of each group (PD = NS - 1), waited for by group 0 at the end of
+//            MFMA(u - 1) and by group 1 at the end of LOAD(u - 1) -- both before the barrier that opens group 0's LOAD(u).
+//            Slot (u % NS) was last read in group 1's LOAD(u - NS), one barrier before group 0's LOAD(u - PD) issues into it.
+//   SCHED 2: tile u is issued in interval u - PD by that interval's LOAD group, which waits for it at the end of interval u - 1.
+#pragma once
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `younger` x PER loads are in flight (younger in [0, MAXY])
+template <int PER, int MAXY>
+__device__ __forceinline__ void wait_younger(int younger) {
+    if constexpr (MAXY >= 3) { if (younger >= 3) { wait_vmcnt<3 * PER>(); return; } }
+    if constexpr (MAXY >= 2) { if (younger >= 2) { wait_vmcnt<2 * PER>(); return; } }
+    if constexpr (MAXY >= 1) { if (younger >= 1) { wait_vmcnt<PER>(); return; } }
+    wait_vmcnt<0>();
+}
+
+// exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
+// fp32-rounding class and far below the bf16 rounding of the result): ~14 VALU instead of ~40 for erff
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erf_abs = 1.0f - p * t * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+// XCD-aware tile map shared by the GEMM kernels: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the
+// (M tiles x N tiles x K splits) grid, M tiles fastest inside.  Returns false for a padding slot of a ragged box.
+__device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn, int& z) {
+    const int xcd = blockIdx.x & 7;
+    const int l = blockIdx.x >> 3;
+    const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
+    const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
+    tm = xm * a.bm + lm;
+    tn = xn * a.bn + ln;
+    z = xz * a.bz + lz;
+    return tm < tilesM && tn < tilesN && z < a.splitk;
+}
+
+// ---- copy a bf16 tile parked in LDS ([rows][pitch]) out to global memory as whole 16-byte row chunks ----
+template <int NT>
+__device__ __forceinline__ void copy_out_bf16(const bf16_t* tile, int pitch, int rows, int oc /* columns of the tile */, bf16_t* out, int ldo,
+                                              int grow0, int gcol0, int M, int ncols, int wt, int tid) {
+    const int cpr = oc / 8;
+    for (int q = tid; q < rows * cpr; q += NT) {
+        const int r = q / cpr, c = (q % cpr) * 8;
+        const int grow = grow0 + r, gcol = gcol0 + c;
+        if (grow < M && gcol < ncols) {
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + r * pitch + c);
+            bf16_t* dst = out + (long)grow * ldo + gcol;
+            if (gcol + 8 <= ncols) {
+                if (wt) st16_wt(dst, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+                else *reinterpret_cast<uint4*>(dst) = v;
+            } else {   // ragged last chunk (N is a multiple of 4 for every caller)
+                const bf16_t* src = tile + r * pitch + c;
+                for (int e = 0; e < ncols - gcol; ++e) dst[e] = src[e];
+            }
+        }
+    }
+}
+
+// ---- epilogues for the 16x16 C layout.  The MFMAs compute the TRANSPOSED tile (W fragment as the A operand), so a lane owns ONE
+// output row m = lane & 15 of a 16 x 16 fragment and FOUR CONSECUTIVE columns 4 * (lane >> 4) + {0..3}.
+// acc[i][j]: i-th 16-row x j-th 16-column fragment of the wave tile at (wm * TM, wn * TN) of the workgroup tile.
+template <int FM, int FN, int TM, int TN, int EPI>
+__device__ __forceinline__ void pp_store_direct(const GemmArgs& a, f32x4 (&acc)[FM][FN], int row0, int col0, int wm, int wn, int lane, int z) {
+    static_assert(EPI == EPI_F32 || EPI == EPI_PARTIAL, "fp32 outputs");
+    const int m_in = lane & 15, cg = lane >> 4;
+    float* out = reinterpret_cast<float*>(a.out);
+    if constexpr (EPI == EPI_PARTIAL) out += (long)z * a.slab_stride;
+    // every global operand of the epilogue is requested up front, unconditionally (clamped addresses): a load inside the bounds
+    // check makes hipcc wait vmcnt(0) once per fragment -- 18 dependent L2 round trips in the first build of this kernel
+    float4 b4[FN], g4[FN];
+    const int ncl = a.N - 4;   // N is a multiple of 4 for every caller
+    if constexpr (EPI == EPI_F32) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            int col = col0 + wn * TN + j * 16 + 4 * cg;
+            col = col < ncl ? col : ncl;
+            b4[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = row0 + wm * TM + i * 16 + m_in;
+        const int rowc = row < a.M ? row : a.M - 1;
+        float4 r4[FN];
+        if constexpr (EPI == EPI_F32) {
+            if (a.resid) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    int col = col0 + wn * TN + j * 16 + 4 * cg;
+                    col = col < ncl ? col : ncl;
+                    r4[j] = *reinterpret_cast<const float4*>(a.resid + (long)rowc * a.ldr + col);
+                }
+                if (a.gate) {
+                    const int slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[rowc / a.rows_per_b] : 0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        int col = col0 + wn * TN + j * 16 + 4 * cg;
+                        col = col < ncl ? col : ncl;
+                        g4[j] = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int col = col0 + wn * TN + j * 16 + 4 * cg;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if constexpr (EPI == EPI_F32) {
+                v.x += b4[j].x; v.y += b4[j].y; v.z += b4[j].z; v.w += b4[j].w;
+                if (a.resid) {
+                    if (a.gate) { v.x *= g4[j].x; v.y *= g4[j].y; v.z *= g4[j].z; v.w *= g4[j].w; }
+                    v.x += r4[j].x; v.y += r4[j].y; v.z += r4[j].z; v.w += r4[j].w;
+                }
+            }
+            if (row < a.M && col < a.N) {
+                float* dst = out + (long)row * a.ldo + col;
+                if (a.wt) st16_wt(dst, v); else *reinterpret_cast<float4*>(dst) = v;
+            }
+        }
+    }
+}
+
+// bf16 outputs (GEGLU activations, bf16 split-K slabs) through LDS: the tile is parked in the dead ring and leaves as whole rows, 16
+// bytes per lane (a direct store would scatter 8 bytes into each of 16 lines per instruction).
+// GEGLU: W rows are interleaved 8 value / 8 gate, so a 16-column fragment holds inner indices 8 j' .. 8 j' + 7: values in the lanes
+// with cg = lane >> 4 in {0, 1}, their gates in the lanes cg + 2 (= lane ^ 32).  Each lane of a pair finishes two of the four outputs
+// (branch-free: both lanes evaluate  mul * gelu(arg)  with their own selection of mul / arg).
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, int EPI>
+__device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid, int z,
+                                             unsigned long long* ts = nullptr) {
+    static_assert(EPI == EPI_GEGLU || EPI == EPI_PARTIAL, "bf16 outputs only");
+    constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;   // output columns of the tile
+    static_assert(OC % 8 == 0, "16-byte row chunks");
+    constexpr int PITCH = OC + 8;
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+    const int m_in = lane & 15, cg = lane >> 4;
+    float4 b4[FN];
+    if constexpr (EPI == EPI_GEGLU) {   // bias of this lane's packed columns: requested up front, unconditionally (clamped)
+        const int ncl = a.N - 4;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            int cp = col0 + wn * TN + j * 16 + 4 * cg;
+            cp = cp < ncl ? cp : ncl;
+            b4[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    uint32_t pk[FM][FN];
+    if constexpr (EPI == EPI_GEGLU) {
+        // the math runs out of registers BEFORE the barrier that frees the ring: the group that finished its MFMAs one interval earlier
+        // overlaps its GELUs with the other group's last MFMA phase.  Exchange: v_permlane32_swap swaps the upper 32 lanes of its first
+        // operand with the lower 32 lanes of its second; with (x0, x2) [and (x1, x3)] as operands the value lane ends up with
+        // (v0, g0), the gate lane with (v2, g2): BOTH evaluate  first * gelu(second), no selects, no LDS.
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const float x0 = acc[i][j][0] + b4[j].x, x1 = acc[i][j][1] + b4[j].y, x2 = acc[i][j][2] + b4[j].z, x3 = acc[i][j][3] + b4[j].w;
+                const auto e0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x2), false, false);
+                const auto e1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
+                pk[i][j] = pack_bf2(__uint_as_float(e0[0]) * gelu_erf(__uint_as_float(e0[1])), __uint_as_float(e1[0]) * gelu_erf(__uint_as_float(e1[1])));
+            }
+    }
+    __syncthreads();   // every wave is done with the last K tile: the ring is dead
+    if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
+    const bool is_val = cg < 2;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int r = wm * TM + i * 16 + m_in;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            if constexpr (EPI == EPI_GEGLU) {
+                // value lane: outputs 0, 1 of its four columns; gate lane (cg - 2 names the same columns): outputs 2, 3
+                const int oc = (wn * TN + j * 16) / 2 + 4 * (cg & 1) + (is_val ? 0 : 2);   // inner index within the tile
+                *reinterpret_cast<uint32_t*>(tile + r * PITCH + oc) = pk[i][j];
+            } else {
+                const int c = wn * TN + j * 16 + 4 * cg;
+                uint2 o;
+                o.x = pack_bf2(acc[i][j][0], acc[i][j][1]);
+                o.y = pack_bf2(acc[i][j][2], acc[i][j][3]);
+                *reinterpret_cast<uint2*>(tile + r * PITCH + c) = o;
+            }
+        }
+    }
+    if (ts && lane == 0) ts[5] = __builtin_readcyclecounter();
+    __syncthreads();
+    if (ts && lane == 0) ts[6] = __builtin_readcyclecounter();
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (EPI == EPI_PARTIAL ? (long)z * a.slab_stride : 0);
+    copy_out_bf16<NT>(tile, PITCH, BM, OC, out, a.ldo, row0, EPI == EPI_GEGLU ? col0 / 2 : col0, a.M, EPI == EPI_GEGLU ? a.N / 2 : a.N, a.wt, tid);
+}
+
+// fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile
+// holds NH = BN / head_dim WHOLE heads of q, of k or of v (D is a multiple of BN), parked in LDS as fp32 so that head boundaries need not
+// coincide with MFMA fragments; per-head LayerNorm + RoPE of q / k -> [B][H][Lp][DQK], V -> V^T [B][H][DV][Lp].
+template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT>
+__device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid) {
+    constexpr int NH = BN / DH, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
+    static_assert(NH * DH == BN && DH % 4 == 0 && (DH * 2) % 16 == 0, "whole heads");
+    float* tile = reinterpret_cast<float*>(smem);                        // [BM][PITCH] fp32, reuses the ring
+    bf16_t* qk_st = reinterpret_cast<bf16_t*>(smem + BM * PITCH * 4);    // [BM][NH][DH] bf16: normalised q / k heads on their way out
+    static_assert((BM * PITCH * 4) % 16 == 0, "staging alignment");
+    const int m_in = lane & 15, cg = lane >> 4;
+    __syncthreads();                                                      // every wave is done with the ring
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<f32x4*>(tile + (wm * TM + i * 16 + m_in) * PITCH + wn * TN + j * 16 + 4 * cg) = acc[i][j];
+    __syncthreads();
+    const HeadNormArgs& hn = a.hn;
+    const int D = hn.H * DH;
+    const int part = col0 / D;                 // 0 q, 1 k, 2 v
+    const int head0 = (col0 % D) / DH;         // first head of this tile
+    if (part < 2) {
+        // 4 lanes per (row, head): each owns DH / 4 contiguous channels; LN via two xor-shuffles, RoPE partner (i +- DH/2) in lane ^ 2
+        constexpr int E = DH / 4;
+        const float* w = part == 0 ? hn.qn_w : hn.kn_w;
+        const float* bb = part == 0 ? hn.qn_b : hn.kn_b;
+        bf16_t* dstbase = part == 0 ? hn.q : hn.k;
+        for (int it = tid; it < BM * NH * 4; it += NT) {
+            const int sub = it & 3, hh = (it >> 2) % NH, r = (it >> 2) / NH;
+            const int m = row0 + r;
+            const int mm = m < a.M ? m : a.M - 1;
+            const int l = mm % hn.L;
+            const float* src = tile + r * PITCH + hh * DH + sub * E;
+            float v[E];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                const float2 t2 = *reinterpret_cast<const float2*>(src + 2 * i);
+                v[2 * i] = t2.x; v[2 * i + 1] = t2.y;
+            }
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < E; ++i) s1 += v[i];
+            s1 += __shfl_xor(s1, 1, 64);
+            s1 += __shfl_xor(s1, 2, 64);
+            const float mean = s1 * (1.f / DH);
+            float q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < E; ++i) { const float d = v[i] - mean; q2 += d * d; }
+            q2 += __shfl_xor(q2, 1, 64);
+            q2 += __shfl_xor(q2, 2, 64);
+            const float rstd = rsqrtf(q2 * (1.f / DH) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < E; ++i) v[i] = (v[i] - mean) * rstd * w[sub * E + i] + bb[sub * E + i];
+            if (hn.rope_cos) {
+                const float* cs = hn.rope_cos + (long)l * (DH / 2) + (sub & 1) * E;
+                const float* sn = hn.rope_sin + (long)l * (DH / 2) + (sub & 1) * E;
+                const float sign = (sub & 2) ? 1.f : -1.f;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float other = __shfl_xor(v[i], 2, 64);
+                    v[i] = v[i] * cs[i] + sign * other * sn[i];
+                }
+            }
+            bf16_t* dst = qk_st + (r * NH + hh) * DH + sub * E;   // written out below as whole 16-byte chunks (a head is 9 or 8 of them)
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
+        }
+        __syncthreads();
+        constexpr int CP = DH * 2 / 16;
+        for (int q = tid; q < BM * NH * CP; q += NT) {
+            const int c8 = q % CP, hh = (q / CP) % NH, r = q / (CP * NH);
+            const int m = row0 + r;
+            if (m < a.M) {
+                const int b = m / hn.L, l = m % hn.L;
+                *reinterpret_cast<uint4*>(dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + c8 * 8) =
+                    *reinterpret_cast<const uint4*>(qk_st + (r * NH + hh) * DH + c8 * 8);
+            }
+        }
+    } else {
+        // V^T[b][h][d][l]: consecutive lanes take consecutive ROW PAIRS (l, l + 1) of one channel d -> contiguous 4-byte stores
+        // (row0, L and Lp are even, so a pair never straddles a batch element and is 4-byte aligned)
+        if ((hn.L & 1) == 0) {
+            for (int it = tid; it < (BM / 2) * BN; it += NT) {
+                const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * DH + d
+                const int m = row0 + r;
+                if (m < a.M) {
+                    const int b = m / hn.L, l = m % hn.L;
+                    const int hh = cc / DH, d = cc % DH;
+                    *reinterpret_cast<uint32_t*>(hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l) =
+                        pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
+                }
+            }
+        } else {
+            for (int it = tid; it < BM * BN; it += NT) {
+                const int r = it % BM, cc = it / BM;
+                const int m = row0 + r;
+                if (m < a.M) {
+                    const int b = m / hn.L, l = m % hn.L;
+                    const int hh = cc / DH, d = cc % DH;
+                    hn.vt[(((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l] = f2bf(tile[r * PITCH + cc]);
+                }
+            }
+        }
+    }
+}
+
+// VAR bits: timing ablations only (results are garbage; EZ_ABLATE builds): 8 = no MFMAs, 16 = no fragment reads, 32 = no LDS-DMA refill
+// inside the loop.  Measured and dropped (MI355X, 128x288 tile, cycles per K tile): s_setprio(1) over the MFMA phase 1809 vs 1793,
+// over the LOAD phase 1806, static priority for group 1 1819 -- priorities do not move this loop.
+// GemmArgs.ts (test hook, nullable): wave 0 of every workgroup records s_memtime at kernel start, loop start, loop end, kernel end
+template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR>
+__global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
+    static_assert(SCHED == 1 || SCHED == 2, "schedule");
+    static_assert(WM * WN == (SCHED == 1 ? 8 : 4), "SCHED 1: 8 waves tile the block; SCHED 2: each group of 4 tiles it");
+    constexpr int NT = 512, NTG = 256;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static_assert(BM % 32 == 0 && TM % 16 == 0 && TN % 16 == 0 && TM * WM == BM && TN * WN == BN, "tile geometry");
+    static_assert(SCHED == 1 || FM % 2 == 0, "SCHED 2 splits the wave tile's row fragments between the groups after the loop");
+    constexpr int NP = (BM + BN + 31) / 32;    // 4-KB pieces (32 rows) per stage
+    constexpr int PA = BM / 32;                // pieces [0, PA) come from A, [PA, NP) from W
+    constexpr int STAGE = NP * 4096;
+    constexpr int PD = NS - 1;                 // prefetch distance in K tiles
+    static_assert(NS >= 3 && NS <= 5, "ring depth");
+    static_assert(NS * STAGE <= 160 * 1024, "LDS budget of a CU");
+    constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wg = wave & 3;
+    const int tg = tid & (NTG - 1);
+    const int wt = SCHED == 1 ? wave : wg;     // position among the waves that tile the block
+    const int wm = wt / WN, wn = wt % WN;
+
+    const int tilesM = (a.M + BM - 1) / BM;
+    const int tilesN = (a.N + BN - 1) / BN;
+    int tm, tn, z;
+    if (EPI == EPI_PARTIAL && a.xcd_panel) {
+        // panel placement: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8), so the tile's
+        // slabs and the row kernel that reduces them (row panel p on XCD p % 8) stay inside that XCD's L2
+        const int G = tilesN * a.splitk, l = blockIdx.x >> 3;
+        tm = (blockIdx.x & 7) + 8 * (l / G);
+        tn = (l % G) / a.splitk;
+        z = (l % G) % a.splitk;
+        if (tm >= tilesM) return;
+    } else if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nk = a.K / BK;
+    const int kb = nk * z / a.splitk;
+    const int ke = nk * (z + 1) / a.splitk;
+    const int nt = ke - kb;
+
+    unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
+    if (ts && lane == 0) ts[0] = __builtin_readcyclecounter();
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- loop-invariant addressing: byte offset of this thread's chunk of piece p (K offset excluded) ----
+    constexpr int PMAX = P0;
+    uint32_t poff[PMAX];
+    const int pbeg = (SCHED == 1 && grp == 1) ? P0 : 0;
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int p = pbeg + i;
+        const int q = p * NTG + tg;
+        const int row = q >> 3, c = q & 7;
+        if (p < PA) {
+            int grow = row0 + row;
+            grow = grow < a.M ? grow : a.M - 1;
+            poff[i] = (uint32_t)(grow * a.lda + ((c ^ ((row >> 1) & 7)) << 3)) * 2u;
+        } else {
+            const int r2 = row - BM;
+            int gr = col0 + r2;
+            gr = gr < a.wrows ? gr : a.wrows - 1;
+            poff[i] = (uint32_t)(gr * a.ldw + ((c ^ ((r2 >> 1) & 7)) << 3)) * 2u;
+        }
+    }
+    const char* gA = reinterpret_cast<const char*>(a.A) + (long)kb * (BK * 2);
+    const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * (BK * 2);
+
+    // issue this wave's LDS-DMA instructions of K tile t: pieces [PB, PE) of the tile (compile-time range)
+    auto issue = [&](int t, auto PB_, auto PE_) {
+        constexpr int PB = decltype(PB_)::value, PE = decltype(PE_)::value;
+        char* dst = smem + (t % NS) * STAGE + wg * 1024;
+        const long koff = (long)t * (BK * 2);
+#pragma unroll
+        for (int p = PB; p < PE; ++p) {
+            const char* src = (p < PA ? gA : gW) + koff + poff[p - PB];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + p * 4096), 16, 0, 0);
+        }
+    };
+
+    // fragment read offsets: row (lane & 15) of a 16-row fragment, k-step ks (32 of K) -> 16-byte slot (4 ks + (lane >> 4)) ^ ((row >> 1) & 7);
+    // fragment bases are multiples of 16 rows, so two per-lane offsets serve every A and W fragment
+    const int r16 = lane & 15, kq = lane >> 4;
+    uint32_t foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = r16 * 128 + (((4 * ks + kq) ^ (r16 >> 1)) << 4);
+    const int a_base = wm * TM * 128, b_base = BM * 128 + wn * TN * 128;
+
+    // one LDS-DMA instruction: piece p (index within the tile) of K tile t; pi = its index in this thread's poff[]
+    auto issue_piece = [&](int t, int p, int pi) {
+        char* dst = smem + (t % NS) * STAGE + wg * 1024;
+        const char* src = (p < PA ? gA : gW) + (long)t * (BK * 2) + poff[pi];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + p * 4096), 16, 0, 0);
+    };
+    bf16x8 af[FM][2], bfr[FN][2];
+    if constexpr (VAR & 16) {
+        const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(smem + lane * 16);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) { af[i][ks] = f0; asm volatile("" : "+v"(af[i][ks])); }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) { bfr[j][ks] = f0; asm volatile("" : "+v"(bfr[j][ks])); }
+        }
+    }
+    // LOAD phase: all fragments of tile t -> registers, with the refill pieces [PB, PE) of tile tr issued BETWEEN the reads (one piece
+    // every few reads): a wave blocked at the vector-memory port still has LDS reads in flight (measured 1793 -> 1594 cycles per K
+    // tile on the 128x288 tile against pieces-behind-reads; pieces-before-reads: 1882)
+    auto load_phase = [&](int t, int tr, bool refill, auto PB_, auto PE_) {
+        constexpr int PB = decltype(PB_)::value, PE = decltype(PE_)::value, PG = PE - PB;
+        constexpr int NR = 2 * (FM + FN), STRIDE = NR / (PG > 0 ? PG : 1) > 0 ? NR / (PG > 0 ? PG : 1) : 1;
+        const char* cT = smem + (t % NS) * STAGE;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int ks = r / (FM + FN), idx = r % (FM + FN);
+            if constexpr (!(VAR & 16)) {
+                if (idx < FM) af[idx][ks] = *reinterpret_cast<const bf16x8*>(cT + foff[ks] + a_base + idx * 2048);
+                else bfr[idx - FM][ks] = *reinterpret_cast<const bf16x8*>(cT + foff[ks] + b_base + (idx - FM) * 2048);
+            }
+            if constexpr (!(VAR & 32)) {
+                if ((r + 1) % STRIDE == 0 && (r + 1) / STRIDE - 1 < PG) {
+                    if (refill) issue_piece(tr, PB + (r + 1) / STRIDE - 1, (r + 1) / STRIDE - 1);
+                }
+            }
+        }
+        if constexpr (!(VAR & 32)) {
+#pragma unroll
+            for (int q = NR / STRIDE; q < PG; ++q)
+                if (refill) issue_piece(tr, PB + q, q);
+        }
+    };
+    auto mfmas = [&]() {
+        if constexpr (VAR & 8) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[i][ks]));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[j][ks]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j][ks]), "v"(af[i][ks]));
+    };
+    auto fence_lds = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if constexpr (SCHED == 1) {
+        auto run = [&](auto G_) {
+            constexpr int G = decltype(G_)::value;
+            constexpr int PB = G == 0 ? 0 : P0, PE = G == 0 ? P0 : NP, PG = PE - PB;   // this group's pieces of every tile
+            static_assert(PG * (PD - 1) < 64, "vmcnt range");
+            using IB = std::integral_constant<int, PB>;
+            using IE = std::integral_constant<int, PE>;
+            // prologue: tiles 0 .. PD-1; tile 0 must be complete (every wave's share) before interval 0
+#pragma unroll
+            for (int t = 0; t < PD; ++t)
+                if (t < nt) issue(t, IB{}, IE{});
+            wait_younger<PG, PD - 1>((nt < PD ? nt : PD) - 1);
+            barrier();
+            if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
+            auto step = [&](int t, auto RF_) {
+                constexpr bool rf = decltype(RF_)::value;   // steady state: tile t + PD exists and is issued here
+                // ---- LOAD(t)
+                load_phase(t, t + PD, rf, IB{}, IE{});
+                if constexpr (G == 1) {
+                    // own share of tile t + 1 landed (group 0 reads it right after the barrier below)
+                    if constexpr (rf) wait_vmcnt<PG * (PD - 1)>();
+                    else if (t + 1 < nt) wait_younger<PG, PD - 1>(nt - 2 - t);
+                }
+                fence_lds();
+                barrier();
+                // ---- MFMA(t)
+                mfmas();
+                if constexpr (G == 0) {
+                    if constexpr (rf) wait_vmcnt<PG * (PD - 1)>();
+                    else if (t + 1 < nt) wait_younger<PG, PD - 1>(nt - 2 - t);
+                    barrier();
+                } else {
+                    if (rf || t + 1 < nt) barrier();
+                }
+            };
+            if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
+            int t = 0;
+            for (; t + PD < nt; ++t) step(t, std::true_type{});
+            for (; t < nt; ++t) step(t, std::false_type{});
+            if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
+        };
+        if (grp == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    } else {
+        // SCHED 2: tile u is issued (all NP pieces) by group (u + PD) & 1, in interval u - PD (prologue: before interval 0)
+        using IB = std::integral_constant<int, 0>;
+        using IE = std::integral_constant<int, NP>;
+        static_assert(NP * ((PD - 1) / 2 + 1) < 64, "vmcnt range");
+        // own tiles that are younger than tile u and already issued at the end of interval u - 1: u + 2, u + 4, ... <= min(u - 1 + PD, nt - 1)
+        auto own_younger = [&](int u) {
+            const int last = u - 1 + PD < nt - 1 ? u - 1 + PD : nt - 1;
+            return last >= u + 2 ? (last - u) / 2 : 0;
+        };
+        auto run = [&](auto G_) {
+            constexpr int G = decltype(G_)::value;
+#pragma unroll
+            for (int u = 0; u < PD; ++u)
+                if (((u + PD) & 1) == G && u < nt) issue(u, IB{}, IE{});
+            if constexpr ((PD & 1) == G) {   // owner of tile 0
+                const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
+                wait_younger<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0);
+            }
+            barrier();
+            // end of interval i: the owner of tile i + 1 -- group (i + 1 + PD) & 1 -- makes sure it has landed.  Group G's LOAD intervals are
+            // i = G mod 2, so it owns tile i + 1 at the end of its LOAD intervals iff PD is odd, at the end of its MFMA (and idle) intervals
+            // iff PD is even: a compile-time fact, no parity test in the loop
+            auto end_wait = [&](int i, auto RF_) {
+                constexpr bool rf = decltype(RF_)::value;
+                if constexpr (rf) {
+                    // steady state (i + PD <= nt - 1): own younger tiles are i + 3 .. i + PD (PD odd) or .. i - 1 + PD (PD even)
+                    wait_vmcnt<NP * ((PD - 1) / 2)>();
+                } else {
+                    if (i + 1 < nt) wait_younger<NP, (PD - 1) / 2>(own_younger(i + 1));
+                }
+            };
+            if constexpr (G == 1) {   // interval 0
+                if constexpr (PD % 2 == 0) end_wait(0, std::false_type{});
+                barrier();
+            }
+            auto step = [&](int t, auto RF_) {
+                constexpr bool rf = decltype(RF_)::value;   // t + 1 + PD <= nt - 1: both intervals of this step are steady
+                // ---- interval t: LOAD(t)
+                load_phase(t, t + PD, rf || t + PD < nt, IB{}, IE{});
+                if constexpr (PD % 2 == 1) end_wait(t, RF_);
+                fence_lds();
+                barrier();
+                // ---- interval t + 1: MFMA(t)
+                mfmas();
+                if (rf || t + 1 < nt) {
+                    if constexpr (PD % 2 == 0) end_wait(t + 1, RF_);
+                    barrier();
+                }
+            };
+            if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
+            int t = G;
+            for (; t + 1 + PD < nt; t += 2) step(t, std::true_type{});
+            for (; t < nt; t += 2) step(t, std::false_type{});
+            if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
+        };
+        if (grp == 0) run(std::integral_constant<int, 0>{});
+        else run(std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue ----
+    // the last MFMA's result is not interlocked against the VALU reads below (inline asm, see mfmas): 20 wait states tied to the accumulators
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    if constexpr (SCHED == 2) {
+        // exchange the two groups' partial sums through the (dead) ring: group g keeps the row fragments [g * FM/2, (g + 1) * FM/2) of its
+        // wave tile and parks the others for its partner wave (same wg, other group); lane-linear 16-byte accesses
+        constexpr int HF = FM / 2;
+        static_assert(8 * HF * FN * 1024 <= NS * STAGE, "exchange area must fit the ring");
+        __syncthreads();
+        f32x4* xw = reinterpret_cast<f32x4*>(smem) + (long)(wave ^ 4) * (HF * FN * 64);   // what the partner will read
+        f32x4* xr = reinterpret_cast<f32x4*>(smem) + (long)wave * (HF * FN * 64);
+        // (compile-time register indices on both sides of a uniform branch: a runtime-indexed accumulator array would live in scratch)
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) xw[(i * FN + j) * 64 + lane] = acc[HF + i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) xw[(i * FN + j) * 64 + lane] = acc[i][j];
+        }
+        __syncthreads();
+        f32x4 half[HF][FN];
+        // group 0 (even K tiles) + group 1 (odd K tiles): IEEE addition is commutative, so the sum does not depend on which wave adds
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) half[i][j] = acc[i][j] + xr[(i * FN + j) * 64 + lane];
+        } else {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) half[i][j] = acc[HF + i][j] + xr[(i * FN + j) * 64 + lane];
+        }
+        // from here on: 2 WM x WN waves, wave tile TM/2 x TN
+        const int ewm = wm * 2 + grp;
+        if constexpr (EPI == EPI_QKV) {
+            static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
+            static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");
+            pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT>(a, half, smem, row0, col0, ewm, wn, lane, tid);
+        }
+        if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
+            constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
+            if constexpr (lds_ok) {
+                if (EPI == EPI_GEGLU || a.part_bf16) {
+                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, ts);
+                    if (ts && lane == 0) ts[3] = __builtin_readcyclecounter();
+                    return;
+                }
+            }
+        }
+        if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) pp_store_direct<HF, FN, TM / 2, TN, EPI>(a, half, row0, col0, ewm, wn, lane, z);
+    } else {
+        if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
+            constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
+            if constexpr (lds_ok) {
+                if (EPI == EPI_GEGLU || a.part_bf16) {
+                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, ts);
+                    if (ts && lane == 0) ts[3] = __builtin_readcyclecounter();
+                    return;
+                }
+            }
+        }
+        if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) pp_store_direct<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
+    }
+    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
+}
+
+}  // namespace

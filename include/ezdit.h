@@ -194,6 +194,9 @@ int ezvae_sample(const float* dev_enc, const float* dev_noise, float* dev_z, int
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw,
                     const float* dev_bias, void* dev_out, int ldo, int M, int N, int K, int splitk,
                     ezdit_stream stream);
+/* test hook: ezdit_test_gemm launches of the ping-pong kernel record, per workgroup, eight 64-bit shader-clock stamps (kernel start, K-loop
+ * start, K-loop end, kernel end, then epilogue internals) into dev_buf ([workgroups][8] uint64; NULL switches it off). */
+int ezdit_debug_gemm_timestamps(void* dev_buf);
 int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, const void* dev_vt,
                          const uint8_t* dev_kmask, void* dev_out, int B, int Lq, int Lk, int Lqp, int Lkp,
                          ezdit_stream stream);
