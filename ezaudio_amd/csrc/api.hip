@@ -51,7 +51,7 @@ struct BlkW {   // per-block parameters used on the per-step path (no string / m
     WRef wskip, wqkv, wo, wq2, wo2, w1, w2, zw;
 };
 struct WsPtrs {  // workspace regions used on the per-step path, resolved once at ezdit_bind_workspace
-    int* ints; unsigned* sync; float *rope_cos, *rope_sin, *coef, *cfgpart;
+    int* ints; float *rope_cos, *rope_sin, *coef, *cfgpart;
     bf16_t* ape; float *h, *skips; bf16_t *u, *ucat; float* qkv; bf16_t *q, *k, *vt, *ao, *act; float *part, *y, *pred;
     uint8_t* kmask; bf16_t *kc, *vct; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
@@ -114,19 +114,8 @@ struct ezdit_handle {
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
-    // self-attention over 129..512 keys: all K tiles requested at once, exact softmax (k_attn2).  Measured equal to the flash loop
-    // on MI355X (XL 4.504 vs 4.484 ms, L 3.540 vs 3.555 ms per step): the kernel is not bound by its tile loop.  Option, off.
-    int opt_attn_two_pass = 0;
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
-    int opt_fuse_flags = 0;
     int opt_gemm_debug = 0;   // k_gemm2 experiments: bit 0 = s_setprio(1) over the first MFMA cluster of a K tile, bit 1 = static priority for waves 4-7
-    // measured on MI355X (XL, one prompt): 5.00 ms/step fused vs 4.46 ms with the separate row kernel (+5.4 us per hand-off: the
-    // write-through slab stores, the counter round trip and the acquire cost more than the 1.6 us kernel boundary they replace;
-    // release-fence, plain-load and coarse-poll variants are no better) -> kept as an option, OFF by default
-    int opt_fuse_row = 0;                                                                 // residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch (M <= 2048)
-    // fuse_row 2: panel placement (all workgroups of an M tile on one XCD) + hand-off through that XCD's L2 (GemmArgs.xcd_panel);
-    // fuse_mask selects the shapes: 1 = D x D projections (attn-out, cross-out), 2 = skip_linear (K = 2D), 4 = MLP-out (K = 4D)
-    int opt_fuse_mask = 7;
     // XCD affinity of the residual path at M <= 1024 (placement only, results bit-identical): gemm_panel = shapes (1 D x D, 2 skip, 4 MLP-out)
     // whose split-K GEMM puts ALL workgroups of an M tile on XCD tm % 8; row_affine = the row kernel processes row panel p on XCD p % 8, so
     // a panel's slabs, residual stream and LayerNorm output stay in one XCD's L2 (the L2 keeps its lines across kernel boundaries: a
@@ -139,18 +128,11 @@ struct ezdit_handle {
     // Bit-identical; XL 4.384 -> 4.281 ms/step (+2.4 %), L +1.8 % for the GEGLU / slab part alone.
     int opt_epi_lds = 1;
     int opt_qkv_affine = 1;   // fused QKV GEMM: every tile on the XCD whose attention workgroups read it (single prompt: B * H / 4 == 8); +0.2 ... 0.5 %
-    // k_gemm: rotating load / MFMA phases across the wave groups of a workgroup (ROT variants); bit mask over the GEMM kinds:
-    // 1 D x D split-K, 2 skip (K = 2D), 4 MLP-out (K = 4D), 8 GEGLU, 16 fused QKV, 32 fp32-output
-    int opt_rot = 0;
     // cross-attention q projection: two K tiles per ring slot, barrier and counted wait (a wave's work per K tile is 3 MFMAs: the loop is its
     // fixed cost per iteration).  Bit-identical; XL 4.319 -> 4.285 ms/step (+0.8 %), L +1.1 %.
     int opt_attn_xk2 = 1;
-    int opt_skew_attn = 0;                                                                // the same in the cross-attention kernel's fused q projection
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
-    // GEMM: LDS-DMA refill pieces issued one k-step apart (1) or as one burst behind the barrier (0).  In situ on MI355X the two are
-    // within noise (XL 4.546 vs 4.529 ms, L 3.592 vs 3.576 ms per step): the K loop is not bound by vector-memory issue.  Burst kept.
-    int opt_dma_spread = 0;
     int opt_row_variant = 1;                                                              // row kernel: 0 = one workgroup per row, 1 = one wave per row
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
@@ -331,7 +313,6 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     const long Mc = (long)B * Lc, Mcp = rup(Mc, 128);
     const int nblk = h->nblk;
     add("ints", 256 * sizeof(int));                       // [0] cur_step, [8] CFG arrival counter, [16..] row_slot (<= 240 rows)
-    add("sync", 1024 * sizeof(int));                      // per-M-tile (arrive, passed) counters of the fused residual GEMM, one 128-byte line each (<= 16 tiles), [1000] device error flag
     add("rope_cos", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("rope_sin", (size_t)h->cfg.max_len * (h->dh / 2) * 4);
     add("coef", (size_t)(n_slots > 0 ? n_slots : 1) * 8 * 4);
@@ -439,11 +420,6 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.xcd_map = h->opt_xcd_map;
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
     g.wt = h->opt_wt;
-    g.dma_spread = h->opt_dma_spread;
-    {   // rot is a bit mask over the GEMM kinds: 1 D x D split-K, 2 skip (K = 2D), 4 MLP-out (K = 4D), 8 GEGLU, 16 fused QKV, 32 fp32-output
-        const int kind = epi == EPI_PARTIAL ? (g.K >= 4 * N ? 4 : g.K >= 2 * N ? 2 : 1) : epi == EPI_GEGLU ? 8 : epi == EPI_QKV ? 16 : 32;
-        g.rot = (h->opt_rot & kind) != 0;
-    }
     g.debug = h->opt_gemm_debug;
     g.epi_lds = h->opt_epi_lds;
     g.rows_per_b = 1;
@@ -528,7 +504,7 @@ void resolve_weights(ezdit_handle* h) {
 void resolve_workspace(ezdit_handle* h) {
     WsPtrs& p = h->p;
     memset(&p, 0, sizeof p);
-    p.ints = h->buf<int>("ints"); p.sync = h->buf<unsigned>("sync"); p.rope_cos = h->buf<float>("rope_cos"); p.rope_sin = h->buf<float>("rope_sin");
+    p.ints = h->buf<int>("ints"); p.rope_cos = h->buf<float>("rope_cos"); p.rope_sin = h->buf<float>("rope_sin");
     p.coef = h->buf<float>("coef"); p.cfgpart = h->buf<float>("cfgpart");
     p.ape = h->buf<bf16_t>("ape"); p.h = h->buf<float>("h"); p.skips = h->buf<float>("skips"); p.u = h->buf<bf16_t>("u"); p.ucat = h->buf<bf16_t>("ucat");
     p.qkv = h->buf<float>("qkv"); p.q = h->buf<bf16_t>("q"); p.k = h->buf<bf16_t>("k"); p.vt = h->buf<bf16_t>("vt");
@@ -657,8 +633,8 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     resolve_workspace(h);
     h->steps_done = 0;
     h->ctx_ready = h->ts_ready = h->cond_ready = false;
-    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    drop_graph(h);
+    for (ezdit_handle* u : h->cn_users) drop_graph(u);   // a graph captured with this ControlNet attached points at its old buffers
     if (!h->pf_stream) {
         HIPCHK(hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking));
         h->pf_events.resize(2 * (h->nblk + 2));
@@ -779,20 +755,21 @@ int ezdit_set_step(ezdit_handle* h, int step, ezdit_stream stream) {
 // ------------------------------------------------------------------------------------------------------
 // cn_scale multiplies the ControlNet residuals `cn` (conditioning_scale, controlnet.py:313): the fused sampler passes the
 // attached ControlNet's scale, ezdit_forward passes 1 (the caller's residuals are already scaled, as DiTControlNet.forward returns them)
-// exclusive: no other kernel of this library runs next to this call (false while the ControlNet branch overlaps the backbone): only
-// then may the residual GEMMs wait on each other inside a launch (EPI_PARTIAL_ROW needs all its workgroups co-resident).
 // cn_ready (nullable): event the residuals `cn` become valid at; waited for right before their first consumer, so a ControlNet
 // forward on another stream overlaps the backbone's in-blocks and mid block (the two chains are independent until then,
 // src/inference_controlnet.py:89-99 + udit.py:345-348).
 static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, const float* gt, const uint8_t* gt_mask,
                         const float* const* cn, int n_cn, float cn_scale, float* out, hipStream_t st, hipEvent_t cn_ready = nullptr,
-                        bool exclusive = true) {
+                        const int* cur_override = nullptr) {
     const bool cn_mode = h->is_cn;  // ControlNet: in-blocks only, then one zero-Linear per skip (controlnet.py:303-315)
     Ctx c{h, st};
     const WsPtrs& p = h->p;
     const int D = h->D, M = h->M, nblk = h->nblk, nhalf = h->nhalf, Mp = h->Mp;
-    const int* cur = p.ints;
-    const int* row_slot = h->per_row ? cur + 16 : nullptr;
+    // device step counter that selects the modulation slot.  A ControlNet attached to the fused sampler reads the BACKBONE's counter
+    // (cur_override): only that one is advanced by the CFG / DDIM kernel, and the reference evaluates the ControlNet at the current t
+    // every step (src/inference_controlnet.py:92-96)
+    const int* cur = cur_override ? cur_override : p.ints;
+    const int* row_slot = h->per_row ? p.ints + 16 : nullptr;
     float* hA = p.h;
     float* skips = p.skips;
     bf16_t* u = p.u;
@@ -842,39 +819,13 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         launch_row(r, st);
         c.launched("k_row");
     };
-    // residual GEMM + its row operator: out = rowop(A . W^T as split-K slabs).  One launch (the GEMM's workgroups meet at a per-M-tile
-    // counter and then reduce the rows themselves) when the whole grid is co-resident and nothing runs beside it; else two launches.
+    // residual GEMM + its row operator: out = rowop(A . W^T as split-K slabs): two launches (the one-launch form with an in-launch
+    // hand-off measured slower in round 2 and was removed)
     auto resid = [&](const bf16_t* A, int lda, const WRef& w, int mode, const float* h_in, float* h_out, const float* bias, const float* gate,
                      long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp, int ld_u) {
-        const int K = w.ld;
-        const int s = pick_splitk(h, M, D, K);
-        const long wgs = (long)((M + 127) / 128) * ((D + 127) / 128) * s;
-        const int shape_bit = K >= 4 * D ? 4 : K >= 2 * D ? 2 : 1;
-        const bool panel = h->opt_fuse_row == 2;   // one XCD per M tile: needs a CU per workgroup on that XCD
-        const bool fuse = exclusive && h->opt_fuse_row && h->debug_stop == 0 && h->opt_slab_bf16 && M <= 2048 && wgs <= 240 && s <= 4 &&
-                          h->opt_tile_partial == 9 && h->opt_tile_p18 < 0 && h->opt_tile_p36 < 0 && h->opt_tile_p72 < 0 &&
-                          (!panel || ((h->opt_fuse_mask & shape_bit) && (long)((D + 127) / 128) * s * (((M + 127) / 128 + 7) / 8) <= 32));
-        if (!fuse) {
-            const int s2 = gemm_partial(c, A, lda, w, M, D);
-            if (c.bad() || (h->debug_stop > 0 && h->launches >= h->debug_stop)) return;
-            row(mode, h_in, h_out, s2, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
-            return;
-        }
-        GemmArgs g;
-        memset(&g, 0, sizeof g);
-        g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows;
-        g.out = part; g.ldo = D; g.slab_stride = (long)Mp * D;
-        g.M = M; g.N = D; g.K = K; g.splitk = s; g.epi = EPI_PARTIAL_ROW; g.tile = 9;
-        g.xcd_map = h->opt_xcd_map; g.part_bf16 = 1; g.wt = 1; g.dma_spread = h->opt_dma_spread; g.rows_per_b = 1;
-        g.row = make_row(mode, h_in, h_out, s, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
-        g.row.slab_sc1 = 1;
-        g.panel_cnt = p.sync; g.dev_err = p.sync + 1000; g.fuse_flags = h->opt_fuse_flags;
-        g.rot = (h->opt_rot & shape_bit) != 0;
-        g.epi_lds = h->opt_epi_lds;
-        if (panel) { g.xcd_panel = 1; g.fuse_flags = 8; g.wt = 0; }
-        if (g.fuse_flags & 1) g.wt = 0;
-        if (g.fuse_flags & 2) g.row.slab_sc1 = 0;
-        c.launched("k_gemm (residual + row)", launch_gemm(g, st));
+        const int s2 = gemm_partial(c, A, lda, w, M, D);
+        if (c.bad() || (h->debug_stop > 0 && h->launches >= h->debug_stop)) return;
+        row(mode, h_in, h_out, s2, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
     };
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
 
@@ -943,7 +894,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         AttnArgs at;
         memset(&at, 0, sizeof at);
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
-        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd; at.two_pass = h->opt_attn_two_pass;
+        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd;
         at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
@@ -975,7 +926,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (fuse_q2) {
             at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
-            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.skew = h->opt_skew_attn; at.xk2 = h->opt_attn_xk2;
+            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
         } else {
             gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
@@ -1130,6 +1081,11 @@ int ezdit_sampler_attach_controlnet(ezdit_handle* h, ezdit_handle* cn, float con
     if (cn && h->cn != cn) cn->cn_users.push_back(h);
     h->cn = cn;
     h->cn_scale = cn ? conditioning_scale : 1.0f;
+    if (cn && !h->cn_stream) {   // side stream + fork / join events of the overlapped ControlNet branch: created here, never inside a stream capture
+        HIPCHK(hipStreamCreateWithFlags(&h->cn_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->cn_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->cn_join, hipEventDisableTiming));
+    }
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
     if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
     return EZDIT_OK;
@@ -1160,7 +1116,6 @@ int ezdit_sampler_begin(ezdit_handle* h, float* latents, int P, const float* noi
     HIPCHK(hipMemcpyAsync(h->buf<float>("coef"), cf.data(), cf.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     launch_set_int(h->p.ints, 0, 0, st);
-    HIPCHK(hipMemsetAsync(h->p.sync, 0, 1024 * sizeof(int), st));   // counters of the fused residual GEMM + device error flag
     h->steps_done = 0;
     h->latents = latents; h->noise = noise; h->P = P; h->n_steps = n_steps;
     h->gscale = guidance_scale; h->grescale = guidance_rescale;
@@ -1182,16 +1137,12 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
         cn->ext_mask_embed = h->w_mask_embed;
         hipStream_t cst = st;
         if (h->opt_cn_overlap && h->debug_stop == 0) {   // fork: the ControlNet chain runs next to the backbone's first half
-            if (!h->cn_stream) {
-                HIPCHK(hipStreamCreateWithFlags(&h->cn_stream, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&h->cn_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&h->cn_join, hipEventDisableTiming));
-            }
+            if (!h->cn_stream) return fail(EZDIT_E_STATE, "side stream missing: attach the ControlNet through ezdit_sampler_attach_controlnet");
             HIPCHK(hipEventRecord(h->cn_fork, st));
             HIPCHK(hipStreamWaitEvent(h->cn_stream, h->cn_fork, 0));
             cst = h->cn_stream;
         }
-        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, cst, nullptr, cst == st);
+        int rc0 = forward_impl(cn, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, nullptr, 0, 1.0f, nullptr, cst, nullptr, h->p.ints);
         if (cst != st) {
             HIPCHK(hipEventRecord(h->cn_join, cst));
             cn_ready = h->cn_join;
@@ -1201,7 +1152,7 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
         n_cn = cn->nhalf;
         for (int i = 0; i < n_cn; ++i) cnp[i] = cn->p.cnres + (size_t)i * cn->Mp * cn->D;
     }
-    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st, cn_ready, cn_ready == nullptr);
+    int rc = forward_impl(h, h->latents, h->C, h->P, h->s_gt, h->s_gt_mask, n_cn ? cnp : nullptr, n_cn, h->cn_scale, pred, st, cn_ready);
     if (rc && cn_ready) (void)hipStreamWaitEvent(st, cn_ready, 0);
     if (rc) return rc;
     CfgDdimArgs a;
@@ -1276,14 +1227,12 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
     memset(&g, 0, sizeof g);
-    g.rot = h ? h->opt_rot : 0;
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.dma_spread = h ? h->opt_dma_spread : 0; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
-    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: k_gemm2 experiment bits (GemmArgs.debug); bit 2 (4000 + v): rotating-phase variant
-    if (g.debug & 4) g.rot = 1;
+    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: bits 0-1 k_gemm2 experiment bits (GemmArgs.debug), bit 3 LDS-staged bf16 epilogue, bit 4 bf16 slabs, bits 8.. k_gemm_pp ablation variant
     if (g.debug & 8) g.epi_lds = 1;
     if (g.debug & 16) g.part_bf16 = 1;   // 16000 + v: bf16 split-K slabs
     g.ts = g_gemm_ts;
@@ -1303,7 +1252,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     AttnArgs a;
     memset(&a, 0, sizeof a);
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
-    a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd; a.two_pass = h->opt_attn_two_pass;
+    a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
     (void)hipGetLastError();
@@ -1323,15 +1272,10 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** ptr, size_t* by
 }
 
 int ezdit_device_status(ezdit_handle* h, ezdit_stream stream) {
+    // No kernel of this library waits on another workgroup inside a launch any more (the in-launch split-K hand-off of round 2 was
+    // removed), so there is no device-side failure left to report: launch failures surface through the return codes of the calls.
+    (void)stream;
     if (!h || !h->ws) return fail(EZDIT_E_STATE, "bind workspace first");
-    unsigned flag = 0;
-    HIPCHK(hipMemcpyAsync(&flag, h->p.sync + 1000, sizeof flag, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    if (flag) {
-        (void)hipMemsetAsync(h->p.sync, 0, 1024 * sizeof(int), (hipStream_t)stream);
-        return fail(EZDIT_E_HIP, "a fused residual GEMM timed out waiting for its partner workgroups (another spinning kernel was "
-                                 "holding the GPU); results of this call are invalid -- set option fuse_row = 0 when sharing the GPU");
-    }
     return EZDIT_OK;
 }
 
@@ -1356,15 +1300,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "attn_xcd")) h->opt_attn_xcd = value;
-    else if (!strcmp(name, "attn_two_pass")) h->opt_attn_two_pass = value;
     else if (!strcmp(name, "row_variant")) h->opt_row_variant = value;
-    else if (!strcmp(name, "dma_spread")) h->opt_dma_spread = value;
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
-    else if (!strcmp(name, "fuse_row")) h->opt_fuse_row = value;
-    else if (!strcmp(name, "fuse_flags")) h->opt_fuse_flags = value;
-    else if (!strcmp(name, "fuse_mask")) h->opt_fuse_mask = value;
-    else if (!strcmp(name, "rot")) h->opt_rot = value;
-    else if (!strcmp(name, "skew_attn")) h->opt_skew_attn = value;
     else if (!strcmp(name, "attn_xk2")) h->opt_attn_xk2 = value;
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
@@ -1385,8 +1322,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;
     else if (!strcmp(name, "tile_qkv")) h->opt_tile_qkv = value;
     else return fail(EZDIT_E_INVALID, "unknown option %s", name);
-    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-    if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+    drop_graph(h);
+    for (ezdit_handle* u : h->cn_users) drop_graph(u);   // a backbone's captured step embeds the attached ControlNet's kernels and arguments
     return EZDIT_OK;
 }
 

@@ -107,9 +107,6 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             };
             // loads per tile of this wave: 1 (x) + 1 or 2 (W: the second pass covers chunks [NT, DN * 8))
             const bool two = (DN * 8 > NT) && (wave_u * 64 + NT < DN * 8);
-            // skewed refill (a.skew, see k_gemm): waves 4-7 -- the second wave of every SIMD -- issue their share of the refill behind
-            // their MFMAs instead of behind the barrier, so their issue stall lies under the first group's MFMAs and vice versa
-            const bool late = a.skew && wave_u >= 4;
             stage(0);
             if (nt > 1) stage(1);
             f32x16 acc[FN];
@@ -160,7 +157,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                if (t + 2 < nt && !late) stage(t + 2);
+                if (t + 2 < nt) stage(t + 2);
                 const char* cT = smem + (t % 3) * PSTAGE;
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(cT + fo + mh * 4096);
 #pragma unroll
@@ -170,7 +167,6 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[j]));
-                if (t + 2 < nt && late) stage(t + 2);
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[j]));
@@ -471,261 +467,6 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #undef LOAD_TILE
 #undef WRITE_TILE
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Two-pass form for SHORT key sequences (Lk <= 512 = 4 tiles of 128 keys: the 10 s latent of the shipped configurations),
-// 8 waves, same workgroup geometry, same operand layouts and the same key-sub-block merge as k_attn<DH, 4>.
-//
-// The flash loop above pays one global -> register -> LDS round trip and one barrier per key tile, in sequence: with 4 tiles
-// that chain (not the 44 MFMAs of a wave) is the kernel's duration.  With at most 512 keys none of it is needed:
-//   pass 1: ALL K tiles are requested at once (one latency instead of four), parked in LDS (4 x 22 KB), and every wave
-//           computes S^T for its 32-key sub-block of all tiles: 4 x 16 scores per lane stay in registers, so the row
-//           maximum is exact and the softmax needs no running rescale at all;
-//   pass 2: V^T tiles 0, 1 were requested together with K and land under pass 1; tiles 2, 3 are requested when their
-//           staging registers free up and land under P.V of tiles 0, 1.
-// Numerically this is the plain (non-online) softmax of the wave's keys; the merge over the 4 key sub-blocks is unchanged.
-template <int DH>
-__global__ __launch_bounds__(512) void k_attn2(AttnArgs a) {
-    constexpr int NT = 512, NKH = 4, TK = 128, MAXT = 4;
-    constexpr int DQK = HeadGeom<DH>::DQK;
-    constexpr int DV = HeadGeom<DH>::DV;
-    constexpr int NKS = DQK / 16;
-    constexpr int NDT = DV / 32;
-    constexpr int KSTR = DQK * 2 + 16;
-    constexpr int VSTR = TK * 2 + 8;
-    constexpr int KBYTES = TK * KSTR, VBYTES = DV * VSTR;
-    constexpr int KCH = TK * DQK * 2 / 16;
-    constexpr int VCPR = TK / 8;
-    constexpr int VCH = DV * VCPR;
-    constexpr int KPT = (KCH + NT - 1) / NT, VPT = (VCH + NT - 1) / NT;
-    constexpr int XO = 2 * NDT * 16 * 64;
-    constexpr int SMEM_KV = MAXT * KBYTES + 2 * VBYTES;
-    constexpr int SMEM_X = (NKH - 1) * (XO + 2 * 2 * 32) * 4;
-    constexpr int SMEM = SMEM_KV > SMEM_X ? SMEM_KV : SMEM_X;
-    static_assert(SMEM <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int qs = wave & 1, kh = wave >> 1;
-    const int r32 = lane & 31, hi = lane >> 5;
-    int qt, h, b;
-    if (a.xcd_map) {
-        const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3;
-        const int pair = xcd * a.ppx + sl / a.nq;
-        qt = sl % a.nq;
-        if (pair >= a.B * a.H) return;
-        b = pair / a.H; h = pair % a.H;
-    } else {
-        qt = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
-    }
-    const int q0 = qt * 64 + qs * 32;
-    const long bh = (long)b * a.H + h;
-    const bf16_t* Q = a.q + (bh * a.Lqp + q0 + r32) * DQK + 8 * hi;
-    const char* Kg = reinterpret_cast<const char*>(a.k + bh * a.Lkp * DQK);
-    const bf16_t* VTg = a.vt + bh * DV * (long)a.Lkp;
-    const uint8_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
-    const int ntiles = (a.Lk + TK - 1) / TK;   // <= MAXT (the launcher checks)
-
-    auto kchunk = [&](int i, int key0) -> uint4 {
-        int c = tid + NT * i;
-        c = c < KCH ? c : KCH - 1;
-        return *reinterpret_cast<const uint4*>(Kg + (long)key0 * DQK * 2 + c * 16);
-    };
-    auto vchunk = [&](int i, int key0) -> uint4 {
-        int c = tid + NT * i;
-        c = c < VCH ? c : VCH - 1;
-        return *reinterpret_cast<const uint4*>(VTg + (long)(c / VCPR) * a.Lkp + key0 + (c % VCPR) * 8);
-    };
-    auto kstore = [&](int i, char* kb, const uint4& val) {
-        const int c = tid + NT * i;
-        if (c < KCH) *reinterpret_cast<uint4*>(kb + (c / (DQK / 8)) * KSTR + (c % (DQK / 8)) * 16) = val;
-    };
-    auto vstore = [&](int i, char* vb, const uint4& val) {
-        const int c = tid + NT * i;
-        if (c < VCH) {
-            char* dst = vb + (c / VCPR) * VSTR + (c % VCPR) * 16;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
-            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(val.z, val.w);
-        }
-    };
-
-    // ---- everything pass 1 needs, and the first two V^T tiles, in flight at once (all indices below are compile-time) ----
-    bf16x8 qf[NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + 16 * ks);
-    uint4 kr[MAXT][KPT], vr[2][VPT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) kr[t][i] = t < ntiles ? kchunk(i, t * TK) : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < VPT; ++i) vr[t][i] = t < ntiles ? vchunk(i, t * TK) : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-        if (t < ntiles) {
-#pragma unroll
-            for (int i = 0; i < KPT; ++i) kstore(i, smem + t * KBYTES, kr[t][i]);
-        }
-    __syncthreads();
-
-    // ---- pass 1: S^T for this wave's 32-key sub-block of every tile; exact maximum; P in registers ----
-    const float c = 1.4426950408889634f * rsqrtf((float)DH);   // log2(e) / sqrt(dh)
-    f32x16 s[MAXT];
-    uint32_t tmask[MAXT];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        const int key0 = t * TK + kh * 32;
-        const int kidx = key0 + r32;
-        bool kv = t < ntiles && kidx < a.Lk;
-        if (km) kv = kv && (km[kidx < a.Lk ? kidx : 0] != 0);
-        tmask[t] = (uint32_t)__ballot(kv) >> (4 * hi);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-        if (t < ntiles && key0 < a.Lk) {   // wave-uniform
-            const char* kb = smem + t * KBYTES;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kh * 32 + r32) * KSTR + (2 * ks + hi) * 16);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(s[t]));   // see k_attn: MFMA -> VALU read hazard
-    float m = -1e30f;
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool v = (tmask[t] >> ((r & 3) + 8 * (r >> 2))) & 1u;
-            s[t][r] = v ? s[t][r] * c : -1e30f;
-            m = fmaxf(m, s[t][r]);
-        }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float lsum = 0.f;
-    bf16x8 pf[MAXT][2];
-#pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
-        float p[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool v = (tmask[t] >> ((r & 3) + 8 * (r >> 2))) & 1u;
-            p[r] = v ? __builtin_amdgcn_exp2f(s[t][r] - m) : 0.f;
-            lsum += p[r];
-        }
-#pragma unroll
-        for (int step = 0; step < 2; ++step) {
-            union { bf16x8 v; uint32_t u[4]; } pk;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pk.u[e] = pack_bf2(p[8 * step + 2 * e], p[8 * step + 2 * e + 1]);
-            pf[t][step] = pk.v;
-        }
-    }
-    lsum += __shfl_xor(lsum, 32, 64);
-
-    // ---- pass 2: O^T += V^T . P^T, two tiles at a time ----
-    f32x16 o[NDT];
-#pragma unroll
-    for (int tt = 0; tt < NDT; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[tt][r] = 0.f;
-    char* vb0 = smem + MAXT * KBYTES;
-    auto pv = [&](int t, const char* vb) {
-        if (t * TK + kh * 32 >= a.Lk) return;   // wave-uniform: nothing valid in this sub-block
-#pragma unroll
-        for (int step = 0; step < 2; ++step)
-#pragma unroll
-            for (int tt = 0; tt < NDT; ++tt) {
-                const char* vp = vb + (32 * tt + r32) * VSTR + (32 * kh + 16 * step + 4 * hi) * 2;
-                union { bf16x8 v; uint2 h2[2]; } vf;
-                vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
-                vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
-                o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, t == 0 ? pf[0][step] : t == 1 ? pf[1][step] : t == 2 ? pf[2][step] : pf[3][step], o[tt], 0, 0, 0);
-            }
-    };
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (t < ntiles) {
-#pragma unroll
-            for (int i = 0; i < VPT; ++i) vstore(i, vb0 + t * VBYTES, vr[t][i]);
-        }
-    __syncthreads();
-    if (ntiles > 2) {   // tiles 2, 3 fly while tiles 0, 1 are consumed
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < VPT; ++i) vr[t][i] = t + 2 < ntiles ? vchunk(i, (t + 2) * TK) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    pv(0, vb0);
-    if (ntiles > 1) pv(1, vb0 + VBYTES);
-    if (ntiles > 2) {
-        __syncthreads();   // every wave is done with V^T tiles 0, 1
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            if (t + 2 < ntiles) {
-#pragma unroll
-                for (int i = 0; i < VPT; ++i) vstore(i, vb0 + t * VBYTES, vr[t][i]);
-            }
-        __syncthreads();
-        pv(2, vb0);
-        if (ntiles > 3) pv(3, vb0 + VBYTES);
-    }
-
-    // ---- merge the key sub-blocks and store: identical to k_attn ----
-#pragma unroll
-    for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[tt]));
-    __syncthreads();   // K / V^T staging is dead: it becomes the exchange area
-    float* xo = reinterpret_cast<float*>(smem);
-    float* xml = reinterpret_cast<float*>(smem) + (NKH - 1) * XO;
-    if (kh >= 1) {
-        float* xo_w = xo + (kh - 1) * XO;
-        float* xml_w = xml + (kh - 1) * (2 * 2 * 32);
-#pragma unroll
-        for (int tt = 0; tt < NDT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xo_w[((qs * NDT + tt) * 16 + r) * 64 + lane] = o[tt][r];
-        if (hi == 0) {
-            xml_w[(qs * 2 + 0) * 32 + r32] = m;
-            xml_w[(qs * 2 + 1) * 32 + r32] = lsum;
-        }
-    }
-    __syncthreads();
-    if (kh >= 1) return;
-#pragma unroll
-    for (int j = 0; j < NKH - 1; ++j) {
-        const float* xo_r = xo + j * XO;
-        const float* xml_r = xml + j * (2 * 2 * 32);
-        const float m2 = xml_r[(qs * 2 + 0) * 32 + r32], l2 = xml_r[(qs * 2 + 1) * 32 + r32];
-        const float mm = fmaxf(m, m2);
-        const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
-        lsum = lsum * a1 + l2 * a2;
-        m = mm;
-#pragma unroll
-        for (int tt = 0; tt < NDT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[tt][r] = o[tt][r] * a1 + xo_r[((qs * NDT + tt) * 16 + r) * 64 + lane] * a2;
-    }
-    const float inv = 1.f / lsum;
-    const int qrow = q0 + r32;
-    if (qrow >= a.Lq) return;
-    bf16_t* orow = a.out + ((long)b * a.Lq + qrow) * a.ldo + h * DH;
-#pragma unroll
-    for (int tt = 0; tt < NDT; ++tt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 32 * tt + 8 * g + 4 * hi;
-            if (d < DH) {
-                uint2 v;
-                v.x = pack_bf2(o[tt][4 * g] * inv, o[tt][4 * g + 1] * inv);
-                v.y = pack_bf2(o[tt][4 * g + 2] * inv, o[tt][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + d) = v;
-            }
-        }
-}
-
 }  // namespace
 
 int launch_attention(const AttnArgs& a0, hipStream_t st) {
@@ -740,12 +481,6 @@ int launch_attention(const AttnArgs& a0, hipStream_t st) {
     if (a.Lkp % 128) nkh = 2;
     if (a.xu && nkh != 4) return 1;   // the fused projection exists in the 8-wave form only (needs Lkp % 128 == 0)
     if (a.dh != 64 && a.dh != 72) return 1;
-    // short key sequences without a fused query prologue (self-attention of the 10 s latent): the two-pass form
-    if (a.two_pass && nkh == 4 && !a.xu && !a.q_raw && a.Lk > 128 && a.Lk <= 512) {
-        if (a.dh == 64) hipLaunchKernelGGL((k_attn2<64>), grid, dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((k_attn2<72>), grid, dim3(512), 0, st, a);
-        return 0;
-    }
     if (a.dh == 64) {
         if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a);

@@ -49,7 +49,6 @@ enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
     EPI_GEGLU = 2,    // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
-    EPI_PARTIAL_ROW = 4,  // EPI_PARTIAL + the row kernel's work in the same launch (GemmArgs.row), see GemmArgs
     EPI_QKV = 3       // fused q|k|v projection (tile 64 x 4 whole heads: 64x288 for head_dim 72, 64x256 for 64): per-head LayerNorm + RoPE of q / k and
                       // V -> V^T straight into the attention layouts through LDS (GemmArgs.hn); nothing is written to `out`
 };
@@ -113,7 +112,6 @@ struct RowArgs {
     const int* cur_step; const int* row_slot;
     int wt;                // output stores are write-through (sc1)
     int variant;           // 0: one 256-thread workgroup per row; 1: one wave per row (no LDS, no barriers)
-    int slab_sc1;          // the slabs were written write-through by OTHER workgroups of this launch: read them past the L1 (sc1)
     int affine;            // wave-per-row form: rows [128 p, 128 p + 128) are processed on XCD p % 8 (see k_row_w)
 };
 
@@ -143,20 +141,9 @@ struct GemmArgs {
     int wt;                       // output stores are write-through (sc1)
     HeadNormArgs hn;              // EPI_QKV only (x / ldx / *_col unused)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
-    int dma_spread;               // k_gemm: issue the LDS-DMA pieces of the refill one k-step apart instead of as one burst behind the barrier
-    // EPI_PARTIAL_ROW: the split-K reduce + bias + gated residual + LayerNorm of `row` runs INSIDE this launch.  The workgroups of
-    // one M tile (N tiles x K splits of them) publish their slabs write-through, meet at an arrival counter, and then each
-    // takes a share of the tile's rows (one wave per row).  panel_cnt: 2 words per M tile (arrive, passed), zero between launches, 32 words apart;
-    // (the last workgroup through resets them); dev_err: set to 1 if a wait times out (never hang).
-    RowArgs row; unsigned* panel_cnt; unsigned* dev_err; int fuse_flags;
-    // fuse_flags & 8 (with xcd_panel = 1): all workgroups of an M tile are dealt to ONE XCD and hand their slabs over through that
-    // XCD's L2 (plain stores, L1-bypassing loads, no write-back / invalidate); the arrival word records every arriver's XCC id, and a
-    // tile whose workgroups turn out to span XCDs falls back to the agent-scope protocol inside the same launch (gemm.hip).
-    // panel_cnt words per M tile: [0] arrive (agent protocol), [1] passed, [2..3] 64-bit per-XCC arrival bytes, [4] second arrive.
+    // split-K slabs with all workgroups of an M tile (N tiles x K splits) on ONE XCD (M tile tm -> XCD tm % 8): the slabs and the row kernel
+    // that reduces them (row panel p on XCD p % 8, RowArgs.affine) stay inside that XCD's L2
     int xcd_panel;
-    // k_gemm rotating phases (ROT variants of the step's tiles): the wave groups of a workgroup run one barrier interval apart, one
-    // group loading (fragment reads + LDS-DMA refill) while another issues MFMAs from registers (gemm.hip)
-    int rot;
     // EPI_QKV: place every tile on the XCD whose attention workgroups consume it (single prompt: B * H / 4 == 8; gemm.hip)
     int xcd_qkv;
     unsigned long long* ts;   // test hook (k_gemm_pp): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
@@ -183,8 +170,6 @@ struct AttnArgs {
     // run on ONE XCD (hardware deals workgroup i to XCD i % 8), so each pair's K / V^T is fetched into exactly one L2.
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
-    int two_pass;               // allow the two-pass form (k_attn2) where it applies: 128 < Lk <= 512 keys, plain q operand, 8 waves
-    int skew;                   // fused projection: waves 4-7 refill behind their MFMAs instead of behind the barrier
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported

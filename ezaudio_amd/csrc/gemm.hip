@@ -20,9 +20,9 @@
 //   * split-K (blockIdx.z) writes raw fp32 slabs; the row kernel that follows reduces them
 //     (launch-boundary reduce, see rowops.hip), so no atomics and bitwise-deterministic results.
 #include "common.h"
-#include "rowbody.h"
 #include "gemm_pp.h"
 
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -198,25 +198,14 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& a, f32x16 (&acc)[
   }
 }
 
-// SP: the LDS-DMA pieces of a refill are issued one k-step apart behind that k-step's fragment reads (true) or as one burst
-// right behind the barrier (false; round 1's order, kept for A/B through GemmArgs.dma_spread)
-// ROT (rotating phases): the lockstep loop below serialises everything a K tile needs -- measured with the ABL variants on the
-// 128x288 tile, per K tile: MFMAs 0.51 us (the matrix pipe at full rate), LDS-DMA refill 0.34, fragment reads 0.10, barrier 0.12, loop 0.09:
-// 1.23 us, the sum -- because all waves of a SIMD do the same thing at the same time.  ROT splits the workgroup into G = waves / 4
-// groups (wave w runs on SIMD w % 4: one wave of every group per SIMD) that are one barrier interval apart: in any interval ONE group
-// pulls a whole K tile's fragments into registers and issues its share of the refill (LOAD), ONE group issues that tile's MFMAs from
-// registers (MFMA), the third (12-wave tiles) idles; s_barrier separates the intervals, so the alternation is enforced, not hoped for.
-//   interval t G + g     : group g  LOAD(t)   = ds_read all 4 k-steps of tile t | LDS-DMA own pieces of tile t + NS - 1
-//   interval t G + g + 1 : group g  MFMA(t)
-// Hazards: a wave waits (counted vmcnt) for its OWN pieces of tile t + 1 at the end of its sub-phase G - 1 - g of tile t, i.e. before the
-// barrier that precedes group 0's LOAD(t + 1); the slot of tile t + NS - 1 is the slot of tile t - 1, whose last reader (group G - 1,
-// interval t G - 1) has drained its reads (lgkmcnt(0)) before the barrier that precedes group 0's LOAD(t).  Same loads, same MFMA
-// order per accumulator: results are bit-identical to the lockstep form.
-// ABL (timing experiments only, results are garbage): 1 = no MFMAs, 2 = no fragment reads, 4 = no refill, 8 = no barrier
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP, bool ROT, int ABL = 0>
+// Lockstep kernel: every wave refills (burst of LDS-DMA pieces behind the barrier), reads its fragments and issues its MFMAs in the same
+// order, one raw s_barrier per K tile, counted vmcnt.  Used where the ping-pong kernel (gemm_pp.h) has no configuration: the split-K
+// residual GEMMs (tile 9), the small fp32-output GEMMs (tile 25), the VAE convolutions (tile 6), the GEGLU / fused-QKV fall-backs.
+// (Round 2's A/B variants of this loop -- refill spread over the k-steps, rotating wave-group phases, in-launch split-K reduce + row
+// operator, timing ablations -- measured equal or slower and were removed in round 3; DESIGN.md keeps their numbers.)
+template <int BM, int BN, int WM, int WN, int NS, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     constexpr int NT = 64 * WM * WN;
-    static_assert(!(SP && ROT) && !(ROT && ABL), "rotating phases are a variant of the plain burst form");
     constexpr int LPT = (BM + BN) * 8 / NT;          // LDS-DMA instructions per thread per tile
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int FM = TM / 32, FN = TN / 32;
@@ -236,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int xcd = blockIdx.x & 7;
     const int l = blockIdx.x >> 3;
     int tm, tn, z;
-    if ((EPI == EPI_PARTIAL_ROW || EPI == EPI_PARTIAL) && a.xcd_panel) {
+    if (EPI == EPI_PARTIAL && a.xcd_panel) {
         // panel placement: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8), so the
         // tile's slabs, arrival word and row operator stay inside that XCD's L2 (see the hand-off below)
         const int G = tilesN * a.splitk;
@@ -287,32 +276,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
     auto stage = [&](int t) {  // K tile t (relative) -> ring slot t % NS
         char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
-        // (the rotating-phase variants are plain-GEMM only)
-        const long a_off = (!ROT && a.conv_cpb) ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
-                                               : (long)(kb + t) * (BK * 2);
+        const long a_off = a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
+                                      : (long)(kb + t) * (BK * 2);
         stage_tile<BM, NT>(gA + a_off, aoff, dst, tid);
         stage_tile<BN, NT>(gW + t * (BK * 2), boff, dst + A_BYTES, tid);
-    };
-    // one LDS-DMA instruction (piece p: A pieces first, then W pieces) of K tile t.  Issuing the pieces one k-step apart, behind
-    // the fragment reads of that k-step, keeps the wave out of a burst on the CU's single vector-memory port: in lockstep all
-    // waves otherwise stall at issue together, with their first LDS reads (and so every MFMA of the tile) queued behind the burst.
-    constexpr int LA_ = (BM * 8 + NT - 1) / NT, LB_ = (BN * 8 + NT - 1) / NT, NP_ = LA_ + LB_;
-    auto a_offset = [&](int t) -> long {
-        return a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
-                          : (long)(kb + t) * (BK * 2);
-    };
-    auto stage_piece = [&](int t, long a_off, int p) {
-        char* dst = smem + (t % NS) * STAGE_BYTES + wave_u * 1024;
-        if (p < LA_) {
-            if ((BM * 8) % NT != 0 && p * NT + tid >= BM * 8) return;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + a_off + aoff[p]),
-                                             (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
-        } else {
-            const int q = p - LA_;
-            if ((BN * 8) % NT != 0 && q * NT + tid >= BN * 8) return;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + (long)t * (BK * 2) + boff[q]),
-                                             (__attribute__((address_space(3))) void*)(dst + A_BYTES + q * NT * 16), 16, 0, 0);
-        }
     };
 #pragma unroll
     for (int t = 0; t < NS - 1; ++t)
@@ -350,36 +317,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     };
     auto tile_top = [&](int t) {
         wait_landed(t);
-        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
+        __builtin_amdgcn_s_barrier();  // every wave's part of tile t is in LDS; everyone is done with tile t-1
     };
     // one K tile: 4 k-steps of MFMAs with fragment double buffering (the ds_reads of k-step ks+1 are issued before the MFMAs
     // of k-step ks); RF: tile t + NS - 1 is staged into the slot of tile t-1 on the way
-    bf16x8 abl_frag;
-    if constexpr (ABL & 2) { abl_frag = *reinterpret_cast<const bf16x8*>(smem + lane * 16); asm volatile("" : "+v"(abl_frag)); }
     auto ktile = [&](int t, auto RF) {
-        constexpr bool rf = decltype(RF)::value && !(ABL & 4);
+        constexpr bool rf = decltype(RF)::value;
         f32x16 (&acc_r)[FM][FN] = acc;
-        const char* cT = smem + ((ABL & 2) ? 0 : (t % NS)) * STAGE_BYTES;
-        long ra_off = 0;
-        if constexpr (rf) {
-            if constexpr (SP) ra_off = a_offset(t + NS - 1); else stage(t + NS - 1);
-        }
+        const char* cT = smem + (t % NS) * STAGE_BYTES;
+        if constexpr (rf) stage(t + NS - 1);
         bf16x8 af[2][FM], bfr[2][FN];
-        if constexpr (ABL & 2) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i) { af[0][i] = abl_frag; af[1][i] = abl_frag; }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) { bfr[0][j] = abl_frag; bfr[1][j] = abl_frag; }
-        } else {
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + a_base + i * 4096);
 #pragma unroll
         for (int j = 0; j < FN; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(cT + foff[0] + b_base + j * 4096);
         __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
-        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3 && !(ABL & 2)) {
+            if (ks < 3) {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
                     af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + a_base + i * 4096);
@@ -387,27 +342,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                 for (int j = 0; j < FN; ++j)
                     bfr[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(cT + foff[ks + 1] + b_base + j * 4096);
             }
-            if constexpr (rf && SP) {   // this k-step's share of the refill: pieces [ks * NP / 4, (ks + 1) * NP / 4)
-#pragma unroll
-                for (int p = ks * NP_ / 4; p < (ks + 1) * NP_ / 4; ++p) stage_piece(t + NS - 1, ra_off, p);
-            }
-            if constexpr (ABL & 1) {   // keep the fragments alive, issue no MFMA
-#pragma unroll
-                for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(af[ks & 1][i]));
-#pragma unroll
-                for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bfr[ks & 1][j]));
-            } else {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
-            }
             // pin the order: next k-step's LDS reads first, then this k-step's MFMAs (hides the ds_read latency)
-            if constexpr (ABL == 0) {
             if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, FM + FN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, FM * FN, 0);
-            }
         }
         // keep the accumulators resident in AGPRs across the back edge: without this hipcc copies all of them to VGPRs
         // and back around every barrier (64+ v_accvgpr moves per K tile, and the copy-out waits for the MFMAs to drain)
@@ -418,67 +360,10 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     };
     // steady state (every tile refills the ring) and drain (the last NS - 1 tiles): two loops, each with ONE straight-line body
     const int nt_refill = nt - (NS - 1) > 0 ? nt - (NS - 1) : 0;
-    if constexpr (!ROT) {
+    {
         int t = 0;
         for (; t < nt_refill; ++t) { tile_top(t); ktile(t, std::true_type{}); }
         for (; t < nt; ++t) { tile_top(t); ktile(t, std::false_type{}); }
-    } else {
-        constexpr int G = (WM * WN + 3) / 4;   // groups of 4 waves: one wave per SIMD each
-        static_assert(G == 2 || G == 3, "rotating phases: 8-, 9- or 12-wave tiles");
-        const int ntG = nt * G;
-        auto rot = [&](auto GRP) {
-            constexpr int g = decltype(GRP)::value;
-            constexpr int SW = G - 1 - g;   // sub-phase of tile t at whose end this wave makes sure its pieces of tile t + 1 have landed
-            f32x16 (&acc_r)[FM][FN] = acc;
-            if (nt <= 0) return;
-            wait_landed(0);
-            __builtin_amdgcn_s_barrier();   // tile 0 is visible to every wave
-#pragma unroll
-            for (int b = 0; b < g; ++b) __builtin_amdgcn_s_barrier();   // this group starts g intervals late
-            for (int t = 0; t < nt; ++t) {
-                const int gi = t * G + g;
-                // ---- LOAD(t): the whole K tile's fragments -> registers, then this wave's share of the refill
-                const char* cT = smem + (t % NS) * STAGE_BYTES;
-                bf16x8 af[4][FM], bfr[4][FN];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>(cT + foff[ks] + a_base + i * 4096);
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>(cT + foff[ks] + b_base + j * 4096);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (t + NS - 1 < nt) stage(t + NS - 1);
-                if constexpr (SW == 0) { if (t + 1 < nt) wait_landed(t + 1); }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();      // global barrier index gi < ntG always
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- MFMA(t)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j)
-                            acc_r[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc_r[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc_r[i][j]));
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (SW == 1) { if (t + 1 < nt) wait_landed(t + 1); }
-                if (gi + 1 < ntG) __builtin_amdgcn_s_barrier();
-                if constexpr (G == 3) {   // idle interval
-                    if constexpr (SW == 2) { if (t + 1 < nt) wait_landed(t + 1); }
-                    if (gi + 2 < ntG) __builtin_amdgcn_s_barrier();
-                }
-            }
-        };
-        const int grp = wave_u >> 2;
-        if (grp == 0) rot(std::integral_constant<int, 0>{});
-        else if (G == 2 || grp == 1) rot(std::integral_constant<int, 1>{});
-        else rot(std::integral_constant<int, G - 1>{});
     }
 
     // ---- epilogue (lane <-> output element mapping: see store_tile) ----
@@ -601,92 +486,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
                     }
                 }
             }
-        }
-    } else if constexpr (EPI == EPI_PARTIAL_ROW) {
-        // ---- split-K slabs + the row operator in ONE launch (replaces the k_row launch that used to follow every residual GEMM) ----
-        // Hand-off protocol (placement independent, cdna_hip_programming.md Guideline 16): slabs are stored write-through (sc1), every
-        // storing wave drains its stores, ONE lane arrives on the M tile's counter; ONE lane polls it relaxed and performs ONE agent-scope
-        // acquire; then each workgroup reduces its share of the tile's rows, reading the other workgroups' slabs past the L1.
-        // All workgroups of the launch are co-resident (the launcher refuses grids above one workgroup per CU), so the wait cannot
-        // deadlock on this kernel's own dispatch; it is bounded anyway and reports through dev_err.
-        // fuse_flags (A/B): 1 = plain slab stores + ONE agent-scope release per workgroup instead of write-through stores;
-        //                   2 = plain slab loads behind the acquire instead of sc1 loads; 4 = coarser poll (s_sleep 32)
-        if (a.epi_lds) store_tile_lds<BM, BN, FM, FN, TM, TN, NT, EPI_PARTIAL>(a, acc, smem, row0, col0, wm, wn, lane, tid, z);
-        else store_tile<FM, FN, TM, TN, EPI_PARTIAL>(a, acc, row0, col0, wm, wn, lane, z);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const unsigned total = (unsigned)(tilesN * a.splitk);
-        unsigned* cnt = a.panel_cnt + 32 * tm;   // one 128-byte line per M tile: arrivals and pollers of different tiles never share a line
-        if (a.fuse_flags & 8) {
-            // ---- same-XCD fast path, placement INDEPENDENT in its result.  Slabs are plain stores (they stay, dirty, in the
-            // storing XCD's L2) and every workgroup arrives by adding 1 to ITS XCC's byte of one 64-bit word (words 2, 3 of the
-            // tile's line; the arrival count is the sum of the bytes).  When the word shows that all `total` workgroups of the
-            // tile run on this XCC -- what the panel placement arranges, the dispatcher willing -- the slabs are read straight
-            // out of the shared L2 with L1-bypassing (sc1) loads: no write-back, no invalidate, no fabric round trip.  Any other
-            // placement takes the agent-scope protocol after all: release (write-back), second counter (word 4), acquire.
-            if (tid == 0) {
-                const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
-                unsigned long long* aw = reinterpret_cast<unsigned long long*>(cnt + 2);
-                __hip_atomic_fetch_add(aw, 1ull << (8 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned long long v = 0;
-                unsigned spins = 0;
-                for (;;) {
-                    v = __hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned long long t2 = (v & 0x00ff00ff00ff00ffull) + ((v >> 8) & 0x00ff00ff00ff00ffull);
-                    t2 = (t2 & 0x0000ffff0000ffffull) + ((t2 >> 16) & 0x0000ffff0000ffffull);
-                    if ((unsigned)(t2 + (t2 >> 32)) >= total) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 17)) { __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                }
-                if (v != ((unsigned long long)total << (8 * xcc))) {
-                    // the tile's workgroups span XCDs (or the wait timed out): make the slabs visible the placement-independent way
-                    __hip_atomic_store(a.dev_err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostic only: "slow path taken"
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(cnt + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    spins = 0;
-                    while (__hip_atomic_load(cnt + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if (++spins > (1u << 17)) { __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                const unsigned passed = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (passed == total - 1) {   // everyone is through both waits: re-arm the tile's words for the next launch
-                    __hip_atomic_store(aw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cnt + 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        } else if (tid == 0) {
-            if (a.fuse_flags & 1) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // hipcc may drop the wait behind buffer_wbl2 (ROCm 7.2)
-            }
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) {
-                if (a.fuse_flags & 4) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 22)) {   // ~0.5 s: another spinning kernel holds the CUs our partners need
-                    __hip_atomic_store(a.dev_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            // the last workgroup through the wait re-arms the counters for the next launch (nobody polls them any more)
-            const unsigned passed = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (passed == total - 1) {
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();
-        const int rows = a.M - row0 < BM ? a.M - row0 : BM;
-        const int first = tn * a.splitk + z;   // this workgroup's position among the `total` workgroups of the M tile
-        if (a.row.skip) {
-            for (int r = first + wave_u * (int)total; r < rows; r += WM * WN * (int)total) row_wave<true>(a.row, row0 + r, lane);
-        } else {
-            for (int r = first + wave_u * (int)total; r < rows; r += WM * WN * (int)total) row_wave<false>(a.row, row0 + r, lane);
         }
     } else {
         constexpr bool lds_ok = (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) && BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE_BYTES;
@@ -915,43 +714,28 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     else a.xcd_panel = 0;
     constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
-    static bool attr_set[32] = {};
+    static std::atomic<bool> attr_set[32];   // per (kernel, device); two host threads may race here on first use (harmless double set)
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return 1;
-    if (!attr_set[dev]) {
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_pp<BM, BN, WM, WN, NS, EPI, SCHED, VAR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
-        attr_set[dev] = true;
+        attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((k_gemm_pp<BM, BN, WM, WN, NS, EPI, SCHED, VAR>), grid, dim3(512), SMEM, st, a);
     return 0;
 }
 
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
-template <int BM, int BN, int WM, int WN, int NS, int EPI, bool SP = true, bool ROT = false, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int NS, int EPI>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     const int S = a.splitk;
-    // choose the 8-box partition with the smallest per-XCD operand footprint (bytes of A + W one XCD touches)
-    double best = 1e30;
-    for (int pm = 1; pm <= 8; pm *= 2)
-        for (int pn = 1; pm * pn <= 8; pn *= 2) {
-            const int pz = 8 / (pm * pn);
-            if (pz > S && pz != 1) continue;
-            if (a.xcd_map == 0 && !(pm == 1 && pn == 8)) continue;
-            const int bm = (tilesM + pm - 1) / pm, bn = (tilesN + pn - 1) / pn, bz = (S + pz - 1) / pz;
-            const double rows = (double)(bm * BM < a.M ? bm * BM : a.M) + (double)(bn * BN < a.N ? bn * BN : a.N);
-            double fp = rows * ((double)a.K * bz / S) * 2.0;
-            const int slots = bm * bn * bz * 8, work = tilesM * tilesN * S;
-            fp *= (double)slots / work;                       // ragged boxes waste launch slots and unbalance XCDs
-            if (pm == 1 && pn == 8) fp *= 0.9;               // near-ties keep the weight stream disjoint across XCDs
-            if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
-        }
-    dim3 grid(8 * a.bm * a.bn * a.bz, 1, 1);
-    if ((EPI == EPI_PARTIAL_ROW || EPI == EPI_PARTIAL) && a.xcd_panel && NS > 0) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
+    dim3 grid(pick_boxes(a, BM, BN), 1, 1);
+    if (EPI == EPI_PARTIAL && a.xcd_panel && NS > 0) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
     else a.xcd_panel = 0;
     if (EPI == EPI_QKV && a.xcd_qkv && a.hn.H % 4 == 0 && a.hn.B * (a.hn.H / 4) == 8 && tilesN == 3 * (a.hn.H / 4) && S == 1) {
         int nmax = 0;   // M tiles per batch element (a tile belongs to the batch element of its first row)
@@ -967,85 +751,47 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device
-    static bool attr_set[32] = {};
+    static std::atomic<bool> attr_set[32];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return 1;
     if constexpr (NS > 0) {
-        if (!attr_set[dev]) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI, SP, ROT, ABL>),
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
-            attr_set[dev] = true;
+            attr_set[dev].store(true, std::memory_order_release);
         }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI, SP, ROT, ABL>), grid, dim3(64 * WM * WN), SMEM, st, a);
+        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
     } else {
-        if (!attr_set[dev]) {
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
-            attr_set[dev] = true;
+            attr_set[dev].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
     }
     return 0;
 }
 
-// tile / pipeline configurations (GemmArgs.tile); ids are stable (round 1's experimental ids 11, 14-24, 26-32 were retired)
-//   id  tile     waves  ring  LDS     note
-//   0   128x128  2x2    4     128 KB
-//   1   128x64   2x2    3      72 KB
-//   2   128x128  2x2    2      64 KB  2 workgroups / CU
-//   3   128x64   2x2    4      96 KB
-//   4   128x128  2x2    3      96 KB
-//   5   128x64   2x2    2      48 KB  3 workgroups / CU
-//   6   128x64   4x1    2      48 KB  GEGLU-capable 128x64 (VAE default)
-//   7   128x128  4x2    2      64 KB  8 waves
-//   8   256x128  4x2    2      96 KB  8 waves, wave tile 64x64
-//   9   128x128  4x2    3      96 KB  8 waves: split-K residual GEMMs at M <= 2048 (dma_spread 0: burst refill, for A/B)
-//   10  256x128  4x2    3     144 KB  8 waves
-//   12  128x288  4x3    2     104 KB  12 waves: N = 9216 -> 8 x 32 = 256 workgroups at M = 1000 (89 flop/B ingest)
-//   13  128x288  4x3    3     156 KB  same, ring 3: GEGLU GEMM at M <= 2048 (dma_spread 0: burst refill)
-//   25  128x64   4x2    4      96 KB  8 waves: small fp32-output GEMMs
-//   40  256x256  2x4    -     128 KB  k_gemm2: two stages with early release (wave tile 128x64), for M > 2048
-//   41  192x256  2x4    -     112 KB  k_gemm2, wave tile 96x64: M = 4000 x N = 9216 -> 21 x 36 = 756 workgroups = 2.95 rounds of 256 CUs
-//   42  256x128  4x2    -      96 KB  k_gemm2, wave tile 64x64
+// tile / pipeline configurations (GemmArgs.tile); ids are stable (retired: round 1's experimental ids 11, 14-24, 26-32; in round 3 the
+// lockstep ids 0-5, 7, 8, 10, 12, 50, which no caller selected any more)
+//   id  tile     waves  ring  LDS     kernel     note
+//   6   128x64   4x1    2      48 KB  k_gemm     GEGLU-capable 128x64 (VAE default)
+//   9   128x128  4x2    3      96 KB  k_gemm     8 waves: split-K residual GEMMs at M <= 2048
+//   13  128x288  4x3    3     156 KB  k_gemm     12 waves: GEGLU GEMM fall-back (gemm_pp bit 0 off)
+//   25  128x64   4x2    4      96 KB  k_gemm     8 waves: small fp32 GEMMs
+//   40  256x256  2x4    -     128 KB  k_gemm2    two stages with early release (wave tile 128x64), for M > 2048
+//   41  192x256  2x4    -     112 KB  k_gemm2    wave tile 96x64: M = 4000 x N = 9216 -> 21 x 36 = 756 workgroups = 2.95 rounds of 256 CUs
+//   42  256x128  4x2    -      96 KB  k_gemm2    wave tile 64x64
+//   60  128x288  4x2 (32x144)         ring 3  156 KB  k_gemm_pp SCHED 1   GEGLU GEMM at M <= 2048
+//   61  128x144  4x1 per group        ring 4  144 KB  k_gemm_pp SCHED 2 (k-split); fused QKV GEMM (two heads of 72 per tile)
+//   62  128x128  4x2 (32x64)          ring 3   96 KB  k_gemm_pp SCHED 1
+//   63  64x128   2x2 per group        ring 4   96 KB  k_gemm_pp SCHED 2
+//   64  128x144  4x1 per group        ring 3  108 KB  k_gemm_pp SCHED 2
+//   65  128x128  2x2 per group (64x64) ring 4 128 KB  k_gemm_pp SCHED 2
 template <int EPI>
 int launch_e(const GemmArgs& a, hipStream_t st) {
-    const bool sp = a.dma_spread != 0;
-    const bool sk = a.rot != 0 && !sp && !a.conv_cpb;   // rotating-phase variants exist for the step's tiles
-#ifdef EZ_ABLATE   // timing ablations of the K loop (tools/ablate_gemm.py; build with EZAUDIO_ABLATE=1): not part of the product library
-    if ((a.debug >> 4) && (a.tile == 13 || a.tile == 9) && (EPI == EPI_GEGLU || EPI == EPI_PARTIAL)) {
-#define EZ_ABL(n) case n: return a.tile == 13 ? launch_t<128, 288, 4, 3, 3, EPI, false, false, n>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false, false, n>(a, st);
-        switch (a.debug >> 4) { EZ_ABL(1) EZ_ABL(2) EZ_ABL(3) EZ_ABL(4) EZ_ABL(5) EZ_ABL(6) EZ_ABL(7) EZ_ABL(8) EZ_ABL(12) EZ_ABL(15) EZ_ABL(9) EZ_ABL(11) default: break; }
-#undef EZ_ABL
-    }
-#endif
-    switch (a.tile) {
-        case 0: return launch_t<128, 128, 2, 2, 4, EPI>(a, st);
-        case 1: return launch_t<128, 64, 2, 2, 3, EPI>(a, st);
-        case 2: return launch_t<128, 128, 2, 2, 2, EPI>(a, st);
-        case 3: return launch_t<128, 64, 2, 2, 4, EPI>(a, st);
-        case 4: return launch_t<128, 128, 2, 2, 3, EPI>(a, st);
-        case 5: return launch_t<128, 64, 2, 2, 2, EPI>(a, st);
-        case 6: return launch_t<128, 64, 4, 1, 2, EPI>(a, st);
-        case 7: return launch_t<128, 128, 4, 2, 2, EPI>(a, st);
-        case 8: return launch_t<256, 128, 4, 2, 2, EPI>(a, st);
-        case 9: return sp ? launch_t<128, 128, 4, 2, 3, EPI, true>(a, st) : sk ? launch_t<128, 128, 4, 2, 3, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI, false>(a, st);
-        case 10: return launch_t<256, 128, 4, 2, 3, EPI>(a, st);
-        case 12: return launch_t<128, 288, 4, 3, 2, EPI>(a, st);
-        case 13: return sp ? launch_t<128, 288, 4, 3, 3, EPI, true>(a, st) : sk ? launch_t<128, 288, 4, 3, 3, EPI, false, true>(a, st) : launch_t<128, 288, 4, 3, 3, EPI, false>(a, st);
-        case 25: return sp ? launch_t<128, 64, 4, 2, 4, EPI, true>(a, st) : sk ? launch_t<128, 64, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 64, 4, 2, 4, EPI, false>(a, st);
-        case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
-        case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
-        case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
-        case 50: return sk ? launch_t<128, 128, 4, 2, 4, EPI, false, true>(a, st) : launch_t<128, 128, 4, 2, 4, EPI, false>(a, st);   // tile 9 with a 4-deep ring (128 KB)
-        // ---- ping-pong kernel (k_gemm_pp): ids 60+; a.debug bits 8.. select the A/B variant (VAR) in the experiment builds
-        //   60  128x288  4x2 waves (32x144)  ring 3  156 KB  SCHED 1   GEGLU GEMM at M <= 2048
-        //   61  128x144  4x1 per group       ring 4  136 KB  SCHED 2 (k-split)
-        //   62  128x128  4x2 waves (32x64)   ring 3   96 KB  SCHED 1
-        //   63  64x128   2x2 per group       ring 4   96 KB  SCHED 2
-        //   64  128x144  4x1 per group       ring 3  102 KB  SCHED 2
-        //   65  128x128  2x2 per group (64x64) ring 4 128 KB SCHED 2
-#ifdef EZ_ABLATE   // timing ablations of the ping-pong K loop (VAR bits 8 / 16 / 32, gemm_pp.h): experiment builds only
+#ifdef EZ_ABLATE   // timing ablations of the ping-pong K loop (VAR bits 8 / 16 / 32, gemm_pp.h; a.debug >> 8 selects): experiment builds only
 #define EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_)                                                    \
             case 8: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 8>(a, st);                \
             case 16: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 16>(a, st);              \
@@ -1057,26 +803,30 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
 #else
 #define EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_)
 #endif
-#define EZ_PPX(BM_, BN_, WM_, WN_, NS_, SC_, ABL_)                                                 \
+#define EZ_PP(BM_, BN_, WM_, WN_, NS_, SC_)                                                        \
         switch (a.debug >> 8) {                                                                    \
             case 0: return launch_pp<BM_, BN_, WM_, WN_, NS_, EPI, SC_, 0>(a, st);                \
-            ABL_                                                                                   \
+            EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_)                                                \
             default: return 1;                                                                     \
         }
-#define EZ_PP(BM_, BN_, WM_, WN_, NS_, SC_) EZ_PPX(BM_, BN_, WM_, WN_, NS_, SC_, )
-#define EZ_PPA(BM_, BN_, WM_, WN_, NS_, SC_) EZ_PPX(BM_, BN_, WM_, WN_, NS_, SC_, EZ_PP_ABL(BM_, BN_, WM_, WN_, NS_, SC_))
-        case 60: EZ_PPA(128, 288, 4, 2, 3, 1)
-        case 61: EZ_PPA(128, 144, 4, 1, 4, 2)
+    switch (a.tile) {
+        case 6: return launch_t<128, 64, 4, 1, 2, EPI>(a, st);
+        case 9: return launch_t<128, 128, 4, 2, 3, EPI>(a, st);
+        case 13: return launch_t<128, 288, 4, 3, 3, EPI>(a, st);
+        case 25: return launch_t<128, 64, 4, 2, 4, EPI>(a, st);
+        case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
+        case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
+        case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
+        case 60: EZ_PP(128, 288, 4, 2, 3, 1)
+        case 61: EZ_PP(128, 144, 4, 1, 4, 2)
         case 62: EZ_PP(128, 128, 4, 2, 3, 1)
         case 63: EZ_PP(64, 128, 2, 2, 4, 2)
         case 64: EZ_PP(128, 144, 4, 1, 3, 2)
         case 65: EZ_PP(128, 128, 2, 2, 4, 2)
-#undef EZ_PP
-#undef EZ_PPA
-#undef EZ_PPX
-#undef EZ_PP_ABL
         default: break;
     }
+#undef EZ_PP
+#undef EZ_PP_ABL
     return 1;   // unknown tile id: refuse (the caller reports EZDIT_E_UNSUPPORTED) instead of silently running another configuration
 }
 
@@ -1089,28 +839,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         if (a.hn.dh == 64) return launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2>(a, st);
         return 1;
     }
-    if (a.epi == EPI_QKV) {   // tiles that hold four whole heads: 64x288 (head_dim 72, 6 waves) or 64x256 (head_dim 64, 8 waves)
-        const bool sp = a.dma_spread != 0;
-        if (a.hn.dh == 72) {
-            if (a.tile != 1) return launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
-            if (a.rot && !sp) return launch_t<64, 288, 1, 9, 3, EPI_QKV, false, true>(a, st);
-            return sp ? launch_t<64, 288, 1, 9, 3, EPI_QKV, true>(a, st) : launch_t<64, 288, 1, 9, 3, EPI_QKV, false>(a, st);
-        }
+    if (a.epi == EPI_QKV) {   // lockstep kernel, tiles that hold four whole heads: 64x288 (head_dim 72, 9 or 6 waves) or 64x256 (head_dim 64, 8 waves)
+        if (a.hn.dh == 72) return a.tile == 1 ? launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st) : launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
         return 1;
     }
-    if (a.epi == EPI_PARTIAL_ROW) {
-        // co-residency: one workgroup per CU (96 KB of LDS each), every workgroup of the grid must be able to run at once
-        const long wgs = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.splitk;
-        if (a.tile != 9 || !a.part_bf16 || !a.panel_cnt || !a.dev_err || wgs > 240 || a.row.nsplit != a.splitk || a.row.nsplit > RW_MAXS ||
-            a.row.D > RW * 256 || (a.row.D & 3))
-            return 1;
-        // panel placement: one workgroup per CU on EVERY XCD (32 CUs each), M tile tm on XCD tm % 8
-        if (a.xcd_panel && (long)((a.N + 127) / 128) * a.splitk * (((a.M + 127) / 128 + 7) / 8) > 32) return 1;
-        if (a.rot && !a.dma_spread) return launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false, true>(a, st);
-        return a.dma_spread ? launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, true>(a, st) : launch_t<128, 128, 4, 2, 3, EPI_PARTIAL_ROW, false>(a, st);
-    }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);
     if (a.epi == EPI_PARTIAL) return launch_e<EPI_PARTIAL>(a, st);
-    return launch_e<EPI_F32>(a, st);
+    if (a.epi == EPI_F32) return launch_e<EPI_F32>(a, st);
+    return 1;
 }

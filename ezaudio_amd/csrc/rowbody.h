@@ -1,5 +1,5 @@
-// Wave-per-row form of the row operator (split-K reduce + bias + gated residual + LayerNorm -> bf16 GEMM operand), shared by the
-// stand-alone row kernel (rowops.hip) and by the GEMM that runs it in its own launch (gemm.hip, EPI_PARTIAL_ROW).
+// Wave-per-row form of the row operator (split-K reduce + bias + gated residual + LayerNorm -> bf16 GEMM operand) of the row kernel
+// (rowops.hip).
 #pragma once
 #include "common.h"
 
@@ -59,13 +59,7 @@ __device__ __forceinline__ void row_wave(const RowArgs& a, int row, int lane) {
                 for (int sp = 0; sp < RW_MAXS; ++sp)
                     if (sp < a.nsplit) {
                         const bf16_t* sp_ptr = reinterpret_cast<const bf16_t*>(a.part) + sp * a.part_stride + (long)row * a.ld_part + cc * 4;
-                        if (a.slab_sc1) {   // written by another workgroup of THIS launch: an agent-scope load is served past the L1
-                            const unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(sp_ptr), __ATOMIC_RELAXED,
-                                                                             __HIP_MEMORY_SCOPE_AGENT);
-                            pb[j][sp] = make_uint2((unsigned)raw, (unsigned)(raw >> 32));
-                        } else {
-                            pb[j][sp] = *reinterpret_cast<const uint2*>(sp_ptr);
-                        }
+                        pb[j][sp] = *reinterpret_cast<const uint2*>(sp_ptr);
                     }
             } else if (a.nsplit > 0) {
                 pf[j] = ld4(a.part + (long)row * a.ld_part + cc * 4);

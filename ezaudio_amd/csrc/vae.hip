@@ -110,7 +110,7 @@ int ezvae_gemm(const void* A, int lda, const void* W, int ldw, int wrows, const 
     memset(&g, 0, sizeof g);
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = wrows; g.bias = bias;
     g.out = out; g.ldo = ldo; g.slab_stride = 0; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_F32; g.tile = tile;
-    g.debug = 0; g.conv_cpb = conv_cpb; g.conv_tap_bytes = conv_tap_bytes; g.resid = resid; g.ldr = ldr; g.xcd_map = 1; g.dma_spread = 0; g.part_bf16 = 0; g.wt = 0; memset(&g.hn, 0, sizeof g.hn);
+    g.debug = 0; g.conv_cpb = conv_cpb; g.conv_tap_bytes = conv_tap_bytes; g.resid = resid; g.ldr = ldr; g.xcd_map = 1; g.part_bf16 = 0; g.wt = 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     (void)hipGetLastError();
     if (launch_gemm(g, (hipStream_t)stream)) return ez_fail(EZDIT_E_UNSUPPORTED, "ezvae_gemm: tile %d / shape not supported", tile);

@@ -87,8 +87,7 @@ class LatentSampler:
         return self.latents
 
     def finish(self):
-        """Wait for the sampler stream and raise if the device reported a failure (a timed-out in-launch wait)."""
-        _lib.check(self.unet.lib.ezdit_device_status(self.unet._h, C.c_void_p(self.stream.cuda_stream)))
+        """Order the caller's stream behind the sampler stream and hand back the latents (no host synchronisation)."""
         torch.cuda.current_stream(self.unet.device).wait_stream(self.stream)
         return self.latents
 

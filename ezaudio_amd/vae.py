@@ -191,7 +191,7 @@ class OobleckDecoder(_OobleckNet):
         L, lat = zt.shape
         f32, bf16 = torch.float32, torch.bfloat16
         # conv_in: k7 pad 3
-        xb = self._buf('h3', L + 6, lat, bf16)
+        xb = self._buf('h3in', L + 6, lat, bf16)
         self._snake(zt.data_ptr(), lat, None, xb, 3, L, lat, st)
         c = w['conv_in']
         x = self._buf('x0', L, c['co'], f32)

@@ -202,9 +202,8 @@ int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, 
                          ezdit_stream stream);
 /* copy an internal fp32/bf16 buffer (by name, e.g. "h", "u", "q", "k", "vt", "mod") for debugging. */
 int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t* bytes);
-/* Synchronises `stream` and reports device-side failures of the calls issued so far: the residual GEMMs reduce their split-K slabs
- * inside the launch (option fuse_row), which makes their workgroups wait for each other; that is safe when nothing else spins on
- * the GPU, and bounded (about 0.5 s) otherwise -- a timed-out wait is reported here as EZDIT_E_HIP instead of hanging. */
+/* Kept for ABI stability: returns EZDIT_OK (EZDIT_E_STATE before a workspace is bound) without synchronising.  Round 2's in-launch
+ * split-K hand-off, the only device-side wait this library ever had, was removed; launch failures surface through return codes. */
 int ezdit_device_status(ezdit_handle* h, ezdit_stream stream);
 /* number of kernel launches issued by the last ezdit_forward (host counter). */
 int ezdit_last_launch_count(const ezdit_handle* h);
@@ -217,21 +216,14 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1 (write-through stores)
  *   fuse_qkv 0/1 (head-norm + RoPE + V^T in the QKV GEMM epilogue), qkv_waves9 0/1, fuse_q2 0/1/2 (cross-attention computes its
  *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
- *   attn_two_pass 0/1 (self-attention over 129..512 keys: all K tiles requested at once, exact softmax, V^T streamed under it)
  *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
  *     wave per row)
- *   dma_spread 0/1 (GEMM: LDS-DMA refill pieces issued one k-step apart / as one burst), cn_overlap 0/1 (fused sampler: ControlNet
- *     branch on a side stream next to the backbone's in-blocks)
- *   fuse_row 0/1/2 (M <= 2048: residual GEMMs run their split-K reduce + residual + LayerNorm in the same launch; 1 = agent-scope
- *     hand-off under any placement, 2 = all workgroups of an M tile on one XCD and the hand-off through that XCD's L2, with the
- *     agent-scope protocol as the in-launch fallback when the arrival word shows another placement), fuse_mask (shapes mode 2 applies to:
- *     1 D x D projections, 2 skip_linear, 4 MLP-out), fuse_flags (A/B bits of mode 1)
- *   gemm_panel (bit mask over the same shapes, M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
+ *   cn_overlap 0/1 (fused sampler: ControlNet branch on a side stream next to the backbone's in-blocks)
+ *   gemm_pp (ping-pong kernel k_gemm_pp at M <= 2048: bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; the residual GEMMs select it with
+ *     tile_partial = 62)
+ *   gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
  *     row_affine 0/1 (the row kernel processes row panel p on XCD p % 8): a panel's slabs / residual stream / LayerNorm output stay in
  *     one XCD's L2 across the kernel boundary.  Placement only.
- *   rot (GEMM: the wave groups of a workgroup run one barrier interval apart, one loading while another issues MFMAs; bit mask over
- *     the GEMM kinds: 1 D x D split-K, 2 skip_linear, 4 MLP-out, 8 GEGLU, 16 fused QKV, 32 fp32-output),
- *     skew_attn 0/1 (cross-attention q projection: the second wave of every SIMD refills behind its MFMAs).  Same results bit for bit.
  *   epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks), qkv_affine 0/1 (fused QKV GEMM: every tile
  *     on the XCD whose attention workgroups read it), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
  *   gemm_debug (k_gemm2 experiment bits)

@@ -151,6 +151,12 @@ def test_controlnet_fused_sampler_equals_stepwise_calls(lib):
     torch.cuda.synchronize()
     assert torch.isfinite(lat).all()
     assert rel_l2(lat.cpu().numpy(), tr[steps - 1]) < 5e-3
+    # ... and the rest of the 50 steps: the ControlNet must see the CURRENT timestep's modulation at every step (the reference passes t
+    # into it each step, src/inference_controlnet.py:92-96); a ControlNet pinned to the first timestep's slot drifts far beyond this gate
+    smp.run(50 - steps)
+    lat = smp.finish()
+    torch.cuda.synchronize()
+    assert rel_l2(lat.cpu().numpy(), tr[49]) < 2e-2
     # the fused run left conditioning_scale 0.8 attached to the backbone: the drop-in call surface (residuals already scaled by
     # DiTControlNet.forward, controlnet.py:313) must not apply it a second time
     x_probe = np.concatenate([init, init], 0)

@@ -51,27 +51,10 @@ def t_(a, dev='cuda:0'):
 # kernel level
 # ---------------------------------------------------------------------------------------------------
 # variant = tile_config * 4 + epilogue; epilogue 0 = fp32 (+bias), 1 = split-K partial slabs, 2 = GEGLU
-# tile_config: 0 128x128 ring 4 | 1 128x64 ring 3 | 2 128x128 ring 2 | 3 128x64 ring 4 | 4 128x128 ring 3 | 5 128x64 ring 2
+# tile_config: the table in csrc/gemm.hip (6, 9, 13, 25 lockstep k_gemm; 40-42 large-tile k_gemm2; 60-65 ping-pong k_gemm_pp)
 @pytest.mark.parametrize('M,N,K,variant,splitk', [
-    (1000, 1152, 1152, 0 * 4 + 0, 1),
-    (1000, 1152, 1152, 1 * 4 + 0, 1),
-    (1000, 3456, 1152, 2 * 4 + 0, 1),
-    (1000, 1152, 1152, 3 * 4 + 0, 1),
-    (1000, 1152, 1152, 4 * 4 + 0, 1),
-    (1000, 1152, 1152, 5 * 4 + 0, 1),
-    (200, 300, 192, 1 * 4 + 0, 1),      # ragged M and N
-    (1000, 1152, 4608, 1 * 4 + 1, 4),   # split-K 4 (MLP-out shape)
-    (1000, 1152, 1152, 0 * 4 + 1, 3),   # split-K 3: 6 K tiles per slice
-    (1000, 1152, 1152, 3 * 4 + 1, 9),   # 2 K tiles per slice: shorter than the ring
-    (130, 128, 64, 1 * 4 + 0, 1),       # single K tile
-    (130, 128, 128, 0 * 4 + 0, 1),      # two K tiles
-    (300, 256, 192, 4 * 4 + 1, 2),      # uneven split: 1 + 2 tiles
     (1000, 1152, 1152, 6 * 4 + 0, 1),   # 128x64, waves 4x1
-    (1000, 1152, 1152, 7 * 4 + 1, 2),   # 128x128, 8 waves
-    (1000, 1152, 1152, 8 * 4 + 0, 1),   # 256x128, 8 waves
     (1000, 1152, 1152, 9 * 4 + 1, 3),   # 128x128, 8 waves, ring 3
-    (1000, 1152, 1152, 12 * 4 + 0, 1),  # 128x288, 12 waves
-    (500, 300, 192, 12 * 4 + 1, 2),     # 128x288 ragged
     (1000, 1152, 1152, 13 * 4 + 0, 1),  # 128x288, ring 3
     (1000, 1152, 1152, 13 * 4 + 1, 6),  # 128x288, ring 3, 3 K tiles per slice
     # k_gemm2 (two LDS stages with early release): 256x256, 192x256, 256x128 tiles
@@ -86,20 +69,6 @@ def t_(a, dev='cuda:0'):
     (500, 300, 192, 41 * 4 + 1, 3),
     (4000, 1152, 2304, 42 * 4 + 1, 2),  # 256x128
     (130, 128, 64, 42 * 4 + 0, 1),
-    (1000, 1152, 1152, 50 * 4 + 1, 3),  # 128x128, 8 waves, ring 4
-    # rotating-phase (ROT) variants: 4000 + v.  Two wave groups (8 waves) and three (12 waves); slices shorter than the ring,
-    # single tiles, ragged M / N: the per-group barrier counts must balance for every K-tile count
-    (1000, 1152, 1152, 4000 + 9 * 4 + 1, 3),
-    (1000, 1152, 4608, 4000 + 9 * 4 + 1, 3),
-    (1000, 1152, 1152, 4000 + 9 * 4 + 1, 9),   # 2 K tiles per slice
-    (300, 256, 192, 4000 + 9 * 4 + 1, 2),      # uneven split: 1 + 2 tiles
-    (130, 128, 64, 4000 + 9 * 4 + 0, 1),       # single K tile
-    (1000, 1152, 1152, 4000 + 13 * 4 + 0, 1),
-    (1000, 1152, 1152, 4000 + 13 * 4 + 1, 6),  # 3 K tiles per slice
-    (500, 300, 192, 4000 + 13 * 4 + 1, 2),
-    (130, 288, 64, 4000 + 13 * 4 + 0, 1),
-    (1000, 1152, 1152, 4000 + 25 * 4 + 0, 1),  # 128x64 ring 4
-    (200, 300, 128, 4000 + 50 * 4 + 1, 1),     # ring 4, two K tiles
     # ping-pong kernel (k_gemm_pp): two wave groups one barrier interval apart.  SCHED 1 (60: 128x288, 62: 128x128) and the k-split
     # SCHED 2 (61 / 64: 128x144 ring 4 / 3, 63: 64x128, 65: 128x128); every K-tile count from 1 up (prologue, steady and drain paths, odd /
     # even tile counts of the two groups), ragged M / N, uneven K splits; + 16000: bf16 slabs through LDS
@@ -170,7 +139,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('tile', [2, 5, 6, 8, 12, 13, 40, 41, 42, 1013, 2013, 2012, 3013, 2040, 2041, 2042, 2060, 2061, 2062, 2064, 2065])   # + 1000: rotating phases, + 2000: LDS-staged epilogue; 60+: ping-pong kernel
+@pytest.mark.parametrize('tile', [6, 13, 40, 41, 42, 2013, 2040, 2041, 2042, 2060, 2061, 2062, 2063, 2064, 2065])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
@@ -225,19 +194,15 @@ def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked, nkh
     s = (q.double() @ k.double().transpose(2, 3)) * dh ** -0.5
     s = s.masked_fill(~mask[:, None, None, :], float('-inf'))
     ref = (torch.softmax(s, -1) @ v.double()).transpose(1, 2).reshape(B * Lq, D)
-    # two_pass 1: keys in (128, 512] with 8 waves take the two-pass kernel (all K tiles at once, exact softmax); 0: the flash loop
-    for two_pass in (1, 0):
-        assert lib.ezdit_set_option(m._h, b'attn_two_pass', two_pass) == 0
-        out.zero_()
-        rc = lib.ezdit_test_attention(m._h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
-                                      md.data_ptr() if masked else None, out.data_ptr(), B, Lq, Lk, Lqp, Lkp, None)
-        assert rc == 0
-        torch.cuda.synchronize()
-        got = out.float().cpu()[:, :D]
-        assert torch.isfinite(got).all()
-        assert rel_l2(got.numpy(), ref.numpy()) < 1.2e-2, two_pass  # P and O rounded to bf16
-        assert (got.double() - ref).abs().max().item() < 0.06, two_pass
-    assert lib.ezdit_set_option(m._h, b'attn_two_pass', 0) == 0
+    out.zero_()
+    rc = lib.ezdit_test_attention(m._h, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                  md.data_ptr() if masked else None, out.data_ptr(), B, Lq, Lk, Lqp, Lkp, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = out.float().cpu()[:, :D]
+    assert torch.isfinite(got).all()
+    assert rel_l2(got.numpy(), ref.numpy()) < 1.2e-2  # P and O rounded to bf16
+    assert (got.double() - ref).abs().max().item() < 0.06
     assert lib.ezdit_set_option(m._h, b'attn_nkh', 0) == 0
 
 
@@ -466,13 +431,11 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, dma_spread=0, fuse_row=0, attn_two_pass=0, gemm_panel=3, row_affine=1, rot=0, skew_attn=0, epi_lds=1,
-                    qkv_affine=1, attn_xk2=1)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9)
 
 
-@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('dma_spread', (0, 1)), ('fuse_row', (0, 1, 2)),
-                                        ('attn_two_pass', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)), ('rot', (0, 63)),
-                                        ('skew_attn', (0, 1)), ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1))])
+@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
+                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -485,35 +448,13 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
         assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
         outs.append(_forward(m, inp, 499, kw).cpu().numpy())
     assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0   # shipped defaults
-    if opt not in ('row_variant', 'attn_two_pass'):   # placement / issue order / launch structure / wave phasing only: bitwise identical
+    if opt not in ('row_variant', 'gemm_pp', 'tile_partial'):   # placement / issue order / launch structure only: bitwise identical
         for o in outs[1:]:
             np.testing.assert_array_equal(outs[0], o)
-    else:   # row_variant, attn_two_pass: same math, different rounding points
+    else:   # row_variant: same math, different rounding points; gemm_pp / tile_partial: another kernel (other MFMA shape, other fp32 summation order over K)
         assert rel_l2(outs[0], outs[1]) < 1e-2
         for o in outs:
             assert rel_l2(o, g['pred_t499']) < REL_TOL
-
-
-@pytest.mark.parametrize('mode', [1, 2])
-def test_fused_residual_gemm_handoff_is_stable_under_repetition(lib, dev, mode):
-    """The residual GEMMs of the XL model exchange split-K slabs between workgroups INSIDE a launch.  Mode 1: write-through stores, arrival
-    counter, one agent-scope acquire, any placement.  Mode 2: all workgroups of an M tile on one XCD, slabs handed over through that XCD's L2
-    (plain stores, L1-bypassing loads) once the arrival word shows that they really share an XCC, the agent-scope protocol otherwise.
-    A broken hand-off shows as rare stale rows, so: the shipped XL shape (88 hand-offs per forward), many
-    repetitions, every output bit compared with the two-launch path, then the device error flag."""
-    cfg, sd, inp, kw, g, meta = golden_case('xl')
-    m = get_model('xl', meta['seed_w'])
-    assert lib.ezdit_set_option(m._h, b'fuse_row', 0) == 0
-    ref = _forward(m, inp, 499, kw).clone()
-    n_unfused = m.last_launch_count
-    assert lib.ezdit_set_option(m._h, b'fuse_row', mode) == 0
-    for rep in range(25):
-        out = _forward(m, inp, 499, kw)
-        assert torch.equal(out, ref), rep
-    assert m.last_launch_count == n_unfused - (3 * 29 + 14)      # one row-kernel launch less per residual GEMM
-    assert lib.ezdit_device_status(m._h, None) == 0
-    assert lib.ezdit_set_option(m._h, b'fuse_row', 0) == 0   # the shipped default (the fused form measured slower, DESIGN.md)
-    assert rel_l2(ref.cpu().numpy(), g['pred_t499']) < REL_TOL
 
 
 def test_unsupported_kernel_configuration_is_an_error_not_a_silent_skip(lib, dev):

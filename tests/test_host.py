@@ -180,8 +180,8 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
     _, h = _handle(lib, 'xs')
     names = ['tile_partial', 'tile_f32', 'tile_qkv', 'tile_p18', 'tile_p36', 'tile_p72', 'geglu_tile', 'tile_partial_big', 'tile_f32_big',
              'geglu_big', 'split18', 'split36', 'split72', 'split_big', 'xcd_map', 'slab_bf16', 'wt', 'fuse_qkv', 'qkv_waves9', 'fuse_q2',
-             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'dma_spread', 'cn_overlap', 'fuse_row', 'attn_two_pass',
-             'fuse_mask', 'fuse_flags', 'gemm_panel', 'row_affine', 'rot', 'skew_attn', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2']
+             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'cn_overlap', 'gemm_pp',
+             'gemm_panel', 'row_affine', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2']
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
     for n in names:
         assert n in src, n
@@ -232,63 +232,106 @@ def test_source_hash_tracks_kernel_sources():
     assert len(h) == 16 and h == source_hash()
 
 
-def test_rotating_phase_schedule_is_hazard_free_model():
-    """Executable restatement of the ROT schedule of k_gemm (csrc/gemm.hip): G wave groups one barrier interval apart, group g in interval
-    t G + g reads the fragments of K tile t and issues its LDS-DMA pieces of tile t + NS - 1, in interval t G + g + 1 it issues the MFMAs, and
-    at the end of its sub-phase G - 1 - g of tile t it waits for its own pieces of tile t + 1.  The model replays the per-group programs
-    against one global barrier counter and checks, for every (G, NS, nt): all groups execute the same number of barriers; a tile is read
-    only after EVERY group has waited for its pieces of that tile before an earlier barrier; a ring slot is refilled only after the last
-    reader of its previous tile has passed a barrier behind its reads."""
-    for G in (2, 3):
-        for NS in (3, 4):
-            for nt in range(1, 12):
-                ntG = nt * G
-                # per group: list of (barrier_index_after_which_the_event_happens, kind, tile); events between barrier k-1 and barrier k have time k
-                events = []          # (time, group, kind, tile)
-                n_barriers = []
-                for g in range(G):
-                    SW = G - 1 - g
-                    k = 0            # barriers executed so far by this group
-                    issued = list(range(min(nt, NS - 1)))           # prologue tiles (all groups)
-                    for t in issued:
-                        events.append((0, g, 'issue', t))
-                    events.append((0, g, 'wait', 0))                # wait_landed(0)
-                    k += 1                                          # the "tile 0 visible" barrier
-                    k += g                                          # idle intervals
-                    for t in range(nt):
-                        gi = t * G + g
-                        events.append((k, g, 'read', t))
-                        if t + NS - 1 < nt:
-                            events.append((k, g, 'issue', t + NS - 1))
-                        if SW == 0 and t + 1 < nt:
-                            events.append((k, g, 'wait', t + 1))
-                        k += 1                                      # barrier gi (always < ntG)
-                        events.append((k, g, 'mfma', t))
-                        if SW == 1 and t + 1 < nt:
-                            events.append((k, g, 'wait', t + 1))
-                        if gi + 1 < ntG:
-                            k += 1
-                        if G == 3:
-                            if SW == 2 and t + 1 < nt:
-                                events.append((k, g, 'wait', t + 1))
-                            if gi + 2 < ntG:
-                                k += 1
-                    n_barriers.append(k)
-                assert len(set(n_barriers)) == 1, (G, NS, nt, n_barriers)          # nobody waits for a wave that never arrives
-                assert n_barriers[0] == ntG + 1
-                wait_time = {(g, t): tm for tm, g, kind, t in events if kind == 'wait'}
-                issue_time = {(g, t): tm for tm, g, kind, t in events if kind == 'issue'}
-                read_time = {(g, t): tm for tm, g, kind, t in events if kind == 'read'}
+def test_ping_pong_schedules_are_hazard_free_model():
+    """Executable restatement of the two schedules of k_gemm_pp (csrc/gemm_pp.h): two wave groups one barrier interval apart.  The model
+    replays the per-group programs against one barrier counter (an event's time = barriers the group has executed before it) and
+    checks, for every ring depth and K-tile count: both groups execute the same number of barriers; a tile is read only after every wave
+    that issued pieces of it has waited for them BEFORE an earlier barrier (RAW); the counted wait allows exactly the pieces of the
+    group's younger tiles to stay in flight; a ring slot is refilled only behind a barrier that follows its last read (WAR)."""
+    for NS in (3, 4, 5):
+        PD = NS - 1
+        for nt in range(1, 14):
+            # ---------------- SCHED 1: both groups issue a share of every tile and read every tile
+            ev, nb = [], []
+            for G in (0, 1):
+                k = 0
+                for t in range(min(PD, nt)):
+                    ev.append((k, G, 'issue', t, None))
+                ev.append((k, G, 'wait', 0, min(nt, PD) - 1))
+                k += 1
+                if G == 1:
+                    k += 1
                 for t in range(nt):
-                    first_read = min(read_time[(g, t)] for g in range(G))
-                    for g in range(G):
-                        assert issue_time[(g, t)] <= wait_time[(g, t)]                  # a wave waits for pieces it has issued
-                        assert wait_time[(g, t)] < first_read, (G, NS, nt, t, g)        # RAW: landed + a barrier before anyone reads
-                    if t >= NS:                                                          # tile t reuses the slot of tile t - NS
-                        last_read_prev = max(read_time[(g, t - NS)] for g in range(G))
-                        first_issue = min(issue_time[(g, t)] for g in range(G))
-                        assert last_read_prev < first_issue, (G, NS, nt, t)             # WAR: a barrier between last read and refill
-                    # the counted wait: when group g waits for tile t it has issued exactly the tiles up to min(nt - 1, t + NS - 2)
-                    for g in range(G):
-                        issued_by_then = [tt for (gg, tt), tm in issue_time.items() if gg == g and tm <= wait_time[(g, t)]]
-                        assert max(issued_by_then) == min(nt - 1, t + NS - 2), (G, NS, nt, t, g)
+                    rf = t + PD < nt
+                    ev.append((k, G, 'read', t, None))
+                    if rf:
+                        ev.append((k, G, 'issue', t + PD, None))
+                    wait = (t + 1, PD - 1) if rf else ((t + 1, nt - 2 - t) if t + 1 < nt else None)
+                    if G == 1 and wait:
+                        ev.append((k, G, 'wait') + wait)
+                    k += 1
+                    if G == 0:
+                        if wait:
+                            ev.append((k, G, 'wait') + wait)
+                        k += 1
+                    elif rf or t + 1 < nt:
+                        k += 1
+                nb.append(k)
+            assert nb[0] == nb[1] == 2 * nt + 1, (NS, nt, nb)
+            for t in range(nt):
+                first_read = min(tm for tm, g, kind, tt, _ in ev if kind == 'read' and tt == t)
+                for G in (0, 1):
+                    w = [(tm, y) for tm, g, kind, tt, y in ev if kind == 'wait' and tt == t and g == G]
+                    assert len(w) == 1, (NS, nt, t, G)
+                    tm_w, younger = w[0]
+                    assert tm_w < first_read, ('RAW', NS, nt, t, G)
+                    issued = [tt for tm, g, kind, tt, _ in ev if kind == 'issue' and g == G and tm <= tm_w]
+                    assert t in issued and younger == len([u for u in issued if u > t]), ('count', NS, nt, t, G)
+                if t >= NS:
+                    last_read = max(tm for tm, g, kind, tt, _ in ev if kind == 'read' and tt == t - NS)
+                    first_issue = min(tm for tm, g, kind, tt, _ in ev if kind == 'issue' and tt == t)
+                    assert last_read < first_issue, ('WAR', NS, nt, t)
+            # ---------------- SCHED 2: tile u is issued by group (u + PD) & 1 and read by group u & 1
+            def own_younger(u):
+                last = min(u - 1 + PD, nt - 1)
+                return (last - u) // 2 if last >= u + 2 else 0
+            ev, nb = [], []
+            for G in (0, 1):
+                k = 0
+                for u in range(PD):
+                    if ((u + PD) & 1) == G and u < nt:
+                        ev.append((k, G, 'issue', u, None))
+                if (PD & 1) == G:
+                    last = min(PD - 1, nt - 1)
+                    ev.append((k, G, 'wait', 0, last // 2 if last >= 2 else 0))
+                k += 1
+
+                def end_wait(i, rf, k):
+                    if rf:
+                        ev.append((k, G, 'wait', i + 1, (PD - 1) // 2))
+                    elif i + 1 < nt:
+                        ev.append((k, G, 'wait', i + 1, own_younger(i + 1)))
+                if G == 1:
+                    if PD % 2 == 0:
+                        end_wait(0, False, k)
+                    k += 1
+                t = G
+                while t < nt:
+                    rf = t + 1 + PD < nt
+                    ev.append((k, G, 'read', t, None))
+                    if rf or t + PD < nt:
+                        ev.append((k, G, 'issue', t + PD, None))
+                    if PD % 2 == 1:
+                        end_wait(t, rf, k)
+                    k += 1
+                    if rf or t + 1 < nt:
+                        if PD % 2 == 0:
+                            end_wait(t + 1, rf, k)
+                        k += 1
+                    t += 2
+                nb.append(k)
+            assert nb[0] == nb[1] == nt + 1, (NS, nt, nb)
+            for t in range(nt):
+                reads = [(tm, g) for tm, g, kind, tt, _ in ev if kind == 'read' and tt == t]
+                assert len(reads) == 1 and reads[0][1] == (t & 1), (NS, nt, t)
+                issues = [(tm, g) for tm, g, kind, tt, _ in ev if kind == 'issue' and tt == t]
+                assert len(issues) == 1, (NS, nt, t)
+                waits = [(tm, g, y) for tm, g, kind, tt, y in ev if kind == 'wait' and tt == t]
+                assert len(waits) == 1 and waits[0][1] == issues[0][1], ('owner waits', NS, nt, t)
+                tm_w, G, younger = waits[0]
+                assert issues[0][0] <= tm_w < reads[0][0], ('RAW', NS, nt, t)
+                issued = [tt for tm, g, kind, tt, _ in ev if kind == 'issue' and g == G and tm <= tm_w]
+                assert younger == len([u for u in issued if u > t]), ('count', NS, nt, t, younger, issued)
+                if t >= NS:
+                    last_read = [tm for tm, g, kind, tt, _ in ev if kind == 'read' and tt == t - NS][0]
+                    assert last_read < issues[0][0], ('WAR', NS, nt, t)

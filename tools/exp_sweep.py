@@ -18,7 +18,7 @@ from ezaudio_amd.config import configs, load_yaml_with_includes      # noqa: E40
 from ezaudio_amd.sampler import LatentSampler                         # noqa: E402
 from ezaudio_amd.weights import random_state_dict                     # noqa: E402
 
-DEFAULTS = dict(fuse_mask=7, fuse_q2=1, tile_partial=9, geglu_tile=-1, split18=3, split36=3, split72=3, row_variant=1, xcd_map=1,
+DEFAULTS = dict(gemm_pp=3, fuse_q2=1, tile_partial=9, geglu_tile=-1, split18=3, split36=3, split72=3, row_variant=1, xcd_map=1,
                 attn_xcd=1, tile_f32=25, qkv_waves9=1, geglu_big=40, tile_partial_big=40, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1)
 
 argv = [a for a in sys.argv[1:] if a != '--cn']
