@@ -55,6 +55,7 @@ struct WsPtrs {  // workspace regions used on the per-step path, resolved once a
     bf16_t* ape; float *h, *skips; bf16_t *u, *ucat; float* qkv; bf16_t *q, *k, *vt, *ao, *act; float *part, *y, *pred;
     uint8_t* kmask; bf16_t *kc, *vct; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
+    float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
 };
 
 struct ezdit_handle {
@@ -75,6 +76,7 @@ struct ezdit_handle {
     int B = 0, L = 0, Lc = 0, n_slots = 0, M = 0, Mp = 0, Lp = 0, Lcp = 0, Mc = 0;
     std::map<std::string, Buf> bufs;
     bool ctx_ready = false, ts_ready = false, cond_ready = false;
+    bool z_tables_ready = false;   // the LayerNorm-algebra tables of the prepared timesteps exist (opt_zfuse was on at ezdit_prepare_timesteps)
     int n_ts = 0, per_row = 0;
 
     // sampler
@@ -105,10 +107,20 @@ struct ezdit_handle {
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     // M > 2048 rows (batched prompts): the large-tile kernel (k_gemm2, 256x256) for the residual and GEGLU GEMMs; split_big 0 = as
     // many K splits as keep the grid within one round of the 256 CUs (measured on MI355X at M = 4000: -2.6 % per step vs round 1's tiles)
-    int opt_tile_partial_big = 40, opt_tile_f32_big = 10, opt_geglu_big = 40, opt_split_big = 0;
+    int opt_tile_partial_big = 40, opt_tile_f32_big = 25, opt_geglu_big = 40, opt_split_big = 0;
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
     int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
     int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp) at M <= 2048: bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); the residual GEMMs select it through tile_partial = 62
+    // LayerNorm algebra (common.h, GemmArgs.z*): the attention-out, cross-attention-out and (in front of an in / mid block) MLP-out
+    // projections run UN-SPLIT on the ping-pong kernel with the gated residual, partial LayerNorm statistics and the next GEMM's operand
+    // in their epilogue; the consumer (fused QKV GEMM, cross-attention q projection, GEGLU GEMM) finishes the LayerNorm in ITS epilogue:
+    // no split-K slabs and 72 of the 102 row-kernel launches of an XL step less (253 launches instead of 325), bit-for-bit the same algebra
+    // as the reference (goldens pass at the same gates).  MEASURED SLOWER on MI355X and therefore OFF: XL one prompt 4.56 ms vs 4.25 ms per
+    // step, four prompts 13.6 vs 12.3 ms.  The un-split 64x128 projection runs on 144 of 256 CUs (M = 1000; 3 rounds at M = 4000) and takes
+    // 16-20 us in situ against 9.4 (split-K 3 on 216 CUs) + 7.3 (row kernel) + one launch boundary; every consumer pays 1-3 us for its
+    // statistics / G' / C' loads.  profiles/r03_zfuse_*.txt; DESIGN.md section 4.  Needs gemm_pp bits 0 and 1 and the fused q projection.
+    int opt_zfuse = 0;
+    int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 0;                                                                       // write-through (sc1) output stores
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
@@ -363,6 +375,16 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("lora", ns * nblk * 6 * D * 4);
     add("mod", ns * nblk * 6 * D * 4);
     add("modf", ns * 2 * D * 4);
+    // LayerNorm algebra: partial row statistics (chunks of 64 columns, up to the 2D-wide concat), G' / C' tables per modulation slot
+    {
+        const long I2 = 2L * h->I, N3 = 3L * D, nmax = I2 > N3 ? I2 : N3;
+        add("zstat", (size_t)Mp * ((2 * D + 63) / 64) * 8);
+        add("zt_qkv", (size_t)ns * nblk * 2 * N3 * 4);
+        add("zt_geglu", (size_t)ns * nblk * 2 * I2 * 4);
+        add("zt_q2", (size_t)nblk * 2 * D * 4);
+        add("zA", (size_t)rup(4 * ns, 128) * h->ldD * 2);
+        add("ztmp", (size_t)rup(4 * ns, 128) * nmax * 4);
+    }
     return off;
 }
 
@@ -378,6 +400,7 @@ struct Ctx {
     const FuseResid* fuse = nullptr;
     const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
     bool panel = false;                 // one-shot: panel placement of a split-K GEMM (GemmArgs.xcd_panel)
+    const float* zG = nullptr; const float* zC = nullptr; long zt_stride = 0;   // one-shot: LayerNorm algebra in the consumer's epilogue
     // first launch failure of this call (hipGetLastError after EVERY launch: a rejected launch -- LDS limit, bad grid,
     // unsupported fused configuration -- must surface as an error code, never as stale numbers)
     hipError_t err = hipSuccess;
@@ -425,6 +448,11 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; g.xcd_qkv = h->opt_qkv_affine && h->opt_attn_xcd; }
     if (c.panel) { g.xcd_panel = 1; c.panel = false; }
+    if (c.zG) {
+        g.zstat_in = h->p.zstat; g.zparts = (h->D + 63) / 64; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
+        g.cur_step = h->p.ints; g.row_slot = h->per_row ? h->p.ints + 16 : nullptr; g.rows_per_b = h->L;
+        c.zG = nullptr;
+    }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
         g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
         g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
@@ -511,6 +539,7 @@ void resolve_workspace(ezdit_handle* h) {
     p.ao = h->buf<bf16_t>("ao"); p.act = h->buf<bf16_t>("act"); p.part = h->buf<float>("part"); p.y = h->buf<float>("y");
     p.pred = h->buf<float>("pred"); p.kmask = h->buf<uint8_t>("kmask"); p.kc = h->buf<bf16_t>("kc"); p.vct = h->buf<bf16_t>("vct");
     p.mod = h->buf<float>("mod"); p.modf = h->buf<float>("modf");
+    p.zstat = h->buf<float2>("zstat"); p.zt_qkv = h->buf<float>("zt_qkv"); p.zt_geglu = h->buf<float>("zt_geglu"); p.zt_q2 = h->buf<float>("zt_q2");
     if (h->is_cn) { p.cembed = h->buf<float>("cembed"); p.cnres = h->buf<float>("cnres"); p.skipbf = h->buf<bf16_t>("skipbf"); }
 }
 
@@ -737,8 +766,34 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(EZDIT_E_HIP, "time-path launch failed: %s", hipGetErrorString(e));
     }
+    if (h->opt_zfuse) {
+        // LayerNorm algebra tables (GemmArgs.z*): G' = g W^T, C' = c W^T (+ bias) of the LayerNorm in front of the fused QKV GEMM (norm1,
+        // modulated: per slot), of the GEGLU GEMM (norm3, modulated; C' carries mlp.net.0.proj.bias) and of cross-attention's to_q (norm2,
+        // static).  Small bf16 GEMMs on exact hi + lo splits of the fp32 vectors; once per call.
+        Ctx c{h, st};
+        const long mod_slot = (long)nblk * 6 * D;
+        bf16_t* zA = h->buf<bf16_t>("zA");
+        float* ztmp = h->buf<float>("ztmp");
+        const int I2 = 2 * h->I, N3 = 3 * D;
+        for (int b = 0; b < nblk; ++b) {
+            const BlkW& w = h->blk[b];
+            const float* modb = h->p.mod + (long)b * 6 * D;
+            launch_z_hilo(modb + 0 * D, modb + 1 * D, mod_slot, zA, h->ldD, n, D, st);
+            gemm(c, zA, h->ldD, w.wqkv, nullptr, ztmp, N3, 4 * n, N3, EPI_F32, 25);
+            launch_z_combine(ztmp, N3, nullptr, h->p.zt_qkv + (long)b * 2 * N3, h->p.zt_qkv + (long)b * 2 * N3 + N3, (long)nblk * 2 * N3, n, N3, st);
+            launch_z_hilo(modb + 3 * D, modb + 4 * D, mod_slot, zA, h->ldD, n, D, st);
+            gemm(c, zA, h->ldD, w.w1, nullptr, ztmp, I2, 4 * n, I2, EPI_F32, 25);
+            launch_z_combine(ztmp, I2, w.b1, h->p.zt_geglu + (long)b * 2 * I2, h->p.zt_geglu + (long)b * 2 * I2 + I2, (long)nblk * 2 * I2, n, I2, st);
+            launch_z_hilo(w.n2w, w.n2b, 0, zA, h->ldD, 1, D, st);
+            gemm(c, zA, h->ldD, w.wq2, nullptr, ztmp, D, 4, D, EPI_F32, 25);
+            launch_z_combine(ztmp, D, nullptr, h->p.zt_q2 + (long)b * 2 * D, h->p.zt_q2 + (long)b * 2 * D + D, 0, 1, D, st);
+        }
+        const hipError_t e = hipGetLastError();
+        if (c.bad() || e != hipSuccess) return fail(EZDIT_E_HIP, "LayerNorm-algebra table launch failed: %s", hipGetErrorString(e));
+    }
     h->steps_done = 0;
     h->ts_ready = true;
+    h->z_tables_ready = h->opt_zfuse != 0;
     h->n_ts = n;
     h->per_row = per_row;
     return EZDIT_OK;
@@ -793,6 +848,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, tile_for(h, M, false));
 
     const float* part_src = part;
+    bool u_is_z = false;   // `u` holds A' = bf16(h g) + partial statistics (LayerNorm algebra) instead of a finished LayerNorm
+    bool* u_is_z_ptr = &u_is_z;
     auto make_row = [&](int mode, const float* h_in, float* h_out, int nsplit, const float* bias, const float* gate,
                         long gate_stride, const float* lg, const float* lc, long ln_stride, const float* skip, const float* cnp,
                         int ld_u) {
@@ -818,6 +875,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         const RowArgs r = make_row(mode, h_in, h_out, nsplit, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
         launch_row(r, st);
         c.launched("k_row");
+        if (lg && !skip) u_is_z_ptr[0] = false;   // `u` now holds a finished LayerNorm
     };
     // residual GEMM + its row operator: out = rowop(A . W^T as split-K slabs): two launches (the one-launch form with an in-launch
     // hand-off measured slower in round 2 and was removed)
@@ -828,6 +886,26 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         row(mode, h_in, h_out, s2, bias, gate, gate_stride, lg, lc, ln_stride, skip, cnp, ld_u);
     };
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
+    // LayerNorm algebra (opt_zfuse): un-split residual projection whose epilogue produces h_new, its partial LayerNorm statistics and
+    // A' = bf16(h_new * zg) for the next GEMM; the consumer finishes the LayerNorm.  u_is_z tells the next consumer what `u` holds.
+    // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
+    const int qkv_mode = !(h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64)) ? 0
+                         : ((h->opt_gemm_pp & 2) && M <= h->opt_pp_max_m && D % (2 * h->dh) == 0) ? 2 : (D % (4 * h->dh) == 0 ? 1 : 0);
+    const bool zf = h->opt_zfuse && h->z_tables_ready && M <= h->opt_pp_max_m && (h->opt_gemm_pp & 1) && h->geglu_tile < 0 && qkv_mode == 2 &&
+                    h->opt_fuse_q2 && ((long)h->B * h->H * ((h->L + 63) / 64) <= 512 || h->opt_fuse_q2 == 2) && h->Lcp % 128 == 0;
+    auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
+                       const float* zg, long zg_stride) {
+        GemmArgs g;
+        memset(&g, 0, sizeof g);
+        g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
+        g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = 63;
+        g.xcd_map = h->opt_xcd_map; g.wt = h->opt_wt; g.debug = h->opt_gemm_debug;
+        g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
+        g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
+        g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat;
+        c.launched("k_gemm_pp (residual)", launch_gemm(g, st));
+        u_is_z = true;
+    };
 
     // LN1 of block 0 on the patch embedding (ControlNet: x = patch_embed(x) + controlnet_pre(condition) first, :263-266)
     STOPCHK();
@@ -880,10 +958,11 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hn.rope_cos = p.rope_cos; hn.rope_sin = p.rope_sin;
         hn.q = p.q; hn.k = p.k; hn.vt = p.vt;
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
-        if (h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64) && D % (4 * h->dh) == 0) {
+        if (qkv_mode) {
             // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
             c.hn = &hn;
-            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, ((h->opt_gemm_pp & 2) && M <= 2048) ? 61 : h->opt_qkv_waves9);
+            if (u_is_z) { c.zG = p.zt_qkv + (long)b * 2 * 3 * D; c.zC = c.zG + 3 * D; c.zt_stride = (long)nblk * 2 * 3 * D; }
+            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, qkv_mode == 2 ? 61 : h->opt_qkv_waves9);
         } else {
             gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32,
                  (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
@@ -908,6 +987,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             gemm(c, at.out, h->ldD, w.wo, w.bo, hA, D, M, D, EPI_F32, tile_for(h, M, false));
             STOPCHK();
             row(0, hA, nullptr, 0, nullptr, nullptr, 0, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
+        } else if (zf) {
+            resid_z(at.out, h->ldD, w.wo, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, 0);
         } else {
             resid(at.out, h->ldD, w.wo, 1, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         }
@@ -927,6 +1008,10 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
             at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
+            if (u_is_z) {
+                at.zstat_in = p.zstat; at.zparts = (D + 63) / 64; at.zD = D; at.zeps = 1e-5f;
+                at.zG = p.zt_q2 + (long)b * 2 * D; at.zC = at.zG + D;
+            }
         } else {
             gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
@@ -951,13 +1036,17 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             gemm(c, at.out, h->ldD, w.wo2, w.bo2, hA, D, M, D, EPI_F32, tile_for(h, M, false));
             STOPCHK();
             row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+        } else if (zf) {
+            at.zstat_in = nullptr;
+            resid_z(at.out, h->ldD, w.wo2, hA, hA, w.bo2, nullptr, 0, modv(b, 3), mod_slot);
         } else {
             resid(at.out, h->ldD, w.wo2, 1, hA, hA, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
         }
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
+        if (u_is_z) { c.zG = p.zt_geglu + (long)b * 2 * 2 * h->I; c.zC = c.zG + 2 * h->I; c.zt_stride = (long)nblk * 2 * 2 * h->I; }
         gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU,
-             h->geglu_tile >= 0 ? h->geglu_tile : (M <= 2048 ? ((h->opt_gemm_pp & 1) ? 60 : 13) : h->opt_geglu_big));
+             h->geglu_tile >= 0 ? h->geglu_tile : ((M <= h->opt_pp_max_m && (h->opt_gemm_pp & 1)) ? 60 : M <= 2048 ? 13 : h->opt_geglu_big));
         STOPCHK();
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
         const float* b2 = w.b2;
@@ -974,7 +1063,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
-            resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
+            if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot);
+            else resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
     }
@@ -1237,12 +1327,43 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     if (g.debug & 16) g.part_bf16 = 1;   // 16000 + v: bf16 split-K slabs
     g.ts = g_gemm_ts;
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
+    if (g.debug & 64) {
+        // 64000 + v: run the consumer side of the LayerNorm algebra on neutral tables (statistics of a zero-mean, unit-variance row, G' = 0,
+        // C' = bias): same results as the plain epilogue up to the factor rsqrt(1 + 1e-5), same code path and memory traffic as the real thing
+        static float2* zs = nullptr; static float* zg0 = nullptr; static float* zc = nullptr; static size_t cap_rows = 0, cap_n = 0;
+        const size_t rows = (size_t)rup(M, 128), nn = (size_t)rup(N, 128);
+        if (rows > cap_rows) { if (zs) (void)hipFree(zs); HIPCHK(hipMalloc(&zs, rows * 18 * sizeof(float2))); cap_rows = rows;
+            std::vector<float2> hst(rows * 18, make_float2(0.f, 64.f)); HIPCHK(hipMemcpy(zs, hst.data(), hst.size() * sizeof(float2), hipMemcpyHostToDevice)); }
+        if (nn > cap_n) { if (zg0) (void)hipFree(zg0); if (zc) (void)hipFree(zc); HIPCHK(hipMalloc(&zg0, nn * 4)); HIPCHK(hipMalloc(&zc, nn * 4)); cap_n = nn; HIPCHK(hipMemset(zg0, 0, nn * 4)); }
+        if (bias) HIPCHK(hipMemcpyAsync(zc, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream)); else HIPCHK(hipMemsetAsync(zc, 0, nn * 4, (hipStream_t)stream));
+        g.zstat_in = zs; g.zparts = 18; g.zD = 1152; g.zG = zg0; g.zC = zc; g.zt_slot_stride = 0; g.zeps = 1e-5f;
+        g.debug &= ~64;
+    }
     if (g.epi > EPI_GEGLU || g.tile > 127) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
     if (g.epi != EPI_PARTIAL) g.splitk = 1;
     (void)hipGetLastError();
     if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "gemm variant %d not supported", variant);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of k_gemm failed: %s", hipGetErrorString(e));
+    return EZDIT_OK;
+}
+
+// EPI_RESID of the ping-pong kernel (un-split residual projection + partial LayerNorm statistics + next operand), stand-alone:
+// h_out = h_in + gate * (A . W^T + bias); zu = bf16(h_out * zg); zstat[row][N / 64 chunks] = (sum, M2 about the chunk mean)
+int ezdit_test_resid(const void* A, int lda, const void* W, int ldw, const float* bias, const float* h_in, const float* gate, const float* zg,
+                     float* h_out, void* zu, int ld_zu, void* zstat, int M, int N, int K, ezdit_stream stream) {
+    if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias;
+    g.out = h_out; g.ldo = N; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_RESID; g.tile = 63; g.xcd_map = 1;
+    g.resid = h_in; g.ldr = N; g.gate = gate; g.rows_per_b = 1;
+    g.zu = (bf16_t*)zu; g.ld_zu = ld_zu; g.zg = zg; g.zstat_out = (float2*)zstat;
+    g.ts = g_gemm_ts;
+    (void)hipGetLastError();
+    if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "residual GEMM configuration not supported");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of k_gemm_pp failed: %s", hipGetErrorString(e));
     return EZDIT_OK;
 }
 
@@ -1311,6 +1432,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "gemm_pp")) h->opt_gemm_pp = value;
+    else if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
+    else if (!strcmp(name, "pp_max_m")) h->opt_pp_max_m = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
     else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;

@@ -93,6 +93,36 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             constexpr int FN = DN / 32;
             const int mh = wave & 1, kq = wave >> 1;
             const int rowb = b * a.Lq;
+            // LayerNorm algebra: (mu, r) of the operand row that query row (tid >> 3) of this tile is projected from, requested NOW (every
+            // chunk up front) so that the loads land under the projection's K loop; used in phase 1b
+            float zmu = 0.f, zr = 1.f;
+            if (a.zstat_in) {   // 8 threads per row (the phase-1b thread layout): thread q takes the chunks q, q + 8, ...; all 8 end up with (mu, r)
+                constexpr int NK = 5;   // up to 40 chunks
+                const int q = tid & 7;
+                int qr = qt * 64 + (tid >> 3);
+                qr = qr < a.Lq ? qr : a.Lq - 1;
+                const float2* st = a.zstat_in + (long)(rowb + qr) * a.zparts;
+                float2 sv[NK];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) sv[k] = st[q + 8 * k < a.zparts ? q + 8 * k : 0];
+                const int nlast = a.zD - 64 * (a.zparts - 1);
+                const float inv_last = 1.f / (float)nlast, inv_d = 1.f / (float)a.zD;
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) s += q + 8 * k < a.zparts ? sv[k].x : 0.f;
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+                zmu = s * inv_d;
+                float m2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int p = q + 8 * k;
+                    const bool last = p == a.zparts - 1;
+                    const float d = sv[k].x * (last ? inv_last : 1.f / 64.f) - zmu;
+                    m2 += p < a.zparts ? fmaf(last ? (float)nlast : 64.f, d * d, sv[k].y) : 0.f;
+                }
+                m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+                zr = rsqrtf(m2 * inv_d + a.zeps);
+            }
             uint32_t aoff[1], boff[(DN * 8 + NT - 1) / NT];
             stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
             stage_offsets<DN, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
@@ -195,6 +225,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     const int col = part * CP + e;
                     v[e] = red[(0 * 64 + row) * DS + col] + red[(1 * 64 + row) * DS + col] + red[(2 * 64 + row) * DS + col] +
                            red[(3 * 64 + row) * DS + col];
+                    if (a.zstat_in) v[e] = fmaf(zr, v[e], fmaf(-zr * zmu, a.zG[h * DH + col], a.zC[h * DH + col]));
                     s1 += v[e];
                 }
                 s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);

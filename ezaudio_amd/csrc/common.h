@@ -49,6 +49,10 @@ enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
     EPI_GEGLU = 2,    // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
+    // un-split residual GEMM of the ping-pong kernel: out (fp32) = resid + gate * (acc + bias) as EPI_F32, AND the bf16 operand of the next
+    // GEMM, A' = h_new * zg (the LayerNorm gain only), AND per-(row, 64-column chunk) partial statistics of h_new: the LayerNorm itself
+    // is finished by the CONSUMER (GemmArgs.z*, "LN algebra" in DESIGN.md).  Replaces split-K slabs + the row kernel.
+    EPI_RESID = 4,
     EPI_QKV = 3       // fused q|k|v projection (tile 64 x 4 whole heads: 64x288 for head_dim 72, 64x256 for 64): per-head LayerNorm + RoPE of q / k and
                       // V -> V^T straight into the attention layouts through LDS (GemmArgs.hn); nothing is written to `out`
 };
@@ -146,6 +150,18 @@ struct GemmArgs {
     int xcd_panel;
     // EPI_QKV: place every tile on the XCD whose attention workgroups consume it (single prompt: B * H / 4 == 8; gemm.hip)
     int xcd_qkv;
+    // ---- LayerNorm algebra (k_gemm_pp).  LN(x) g + c followed by a GEMM with W equals  r (x g) W^T - r mu (g W^T) + c W^T  row by row, with
+    // (mu, r) the row's mean and 1 / sqrt(var + eps): the producer of x stores A' = bf16(x g) and partial statistics, the consumer runs the
+    // plain GEMM on A' and applies  acc := r (acc - mu G'[col]) + C'[col]  in its epilogue, G' = g W^T and C' = c W^T (+ bias) precomputed
+    // per modulation slot (ezdit_prepare_timesteps).  Exact up to where the bf16 rounding of the operand falls (on x g instead of LN(x) g + c).
+    // producer (EPI_RESID):
+    bf16_t* zu; int ld_zu;                      // A' [M][ld_zu]
+    const float* zg; long zg_slot_stride;       // LayerNorm gain of the consumer (per slot when the stride is non-zero)
+    float2* zstat_out;                          // [M][N / 64]: (sum, M2 about the chunk mean) of h_new over each 64-column chunk
+    // consumer (EPI_QKV, EPI_GEGLU; null zstat_in = plain GEMM):
+    const float2* zstat_in; int zparts; int zD; // [M][zparts] partial statistics of the operand's rows: zparts = ceil(zD / 64) chunks of 64 columns (the last one ragged)
+    const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]
+    float zeps;
     unsigned long long* ts;   // test hook (k_gemm_pp): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
     int epi_lds;   // k_gemm bf16 epilogues (GEGLU output, bf16 slabs): park the tile in the dead ring and write whole rows, 16 bytes per lane
 };
@@ -171,6 +187,9 @@ struct AttnArgs {
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
+    // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)
+    // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)
+    const float2* zstat_in; int zparts; int zD; const float* zG; const float* zC; float zeps;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 
@@ -241,3 +260,7 @@ struct Conv1dArgs {  // out[b][co][lo] = act(bias[co] + sum_{ci,k} w[co][ci][k] 
 };
 void launch_conv1d(const Conv1dArgs& a, hipStream_t st);
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu
+// LayerNorm algebra tables (rowops.hip): (g, c) [n_slots][D] (stride slot_stride) -> bf16 rows (g hi, g lo, c hi, c lo) per slot, zero padded to ldo;
+// and back: zG[s][n] = tmp[4s][n] + tmp[4s+1][n], zC[s][n] = tmp[4s+2][n] + tmp[4s+3][n] (+ bias[n])
+void launch_z_hilo(const float* g, const float* c, long slot_stride, bf16_t* out, int ldo, int n_slots, int D, hipStream_t st);
+void launch_z_combine(const float* tmp, int ld_tmp, const float* bias, float* zG, float* zC, long slot_stride, int n_slots, int N, hipStream_t st);

@@ -712,7 +712,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
     if (EPI == EPI_PARTIAL && a.xcd_panel && BM == 128) grid.x = 8 * ((a.N + BN - 1) / BN) * a.splitk * (((a.M + BM - 1) / BM + 7) / 8);   // M tile tm -> XCD tm % 8 (gemm_pp.h)
     else a.xcd_panel = 0;
-    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096;
+    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096 + BM * 8;   // ring + (mu, r) of the tile's rows (LayerNorm algebra)
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     static std::atomic<bool> attr_set[32];   // per (kernel, device); two host threads may race here on first use (harmless double set)
     int dev = 0;
@@ -835,14 +835,24 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.K <= 0 || a.K % BK) return 1;
     if (a.epi == EPI_QKV && a.tile >= 60) {   // ping-pong kernel, k-split schedule: 128 x (2 whole heads), ring 4
-        if (a.hn.dh == 72) return launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2>(a, st);
-        if (a.hn.dh == 64) return launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2>(a, st);
+        if (a.zstat_in && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= 40)) return 1;
+        if (a.hn.dh == 72) return a.zstat_in ? launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2, 64>(a, st) : launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2>(a, st);
+        if (a.hn.dh == 64) return a.zstat_in ? launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2, 64>(a, st) : launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2>(a, st);
         return 1;
     }
     if (a.epi == EPI_QKV) {   // lockstep kernel, tiles that hold four whole heads: 64x288 (head_dim 72, 9 or 6 waves) or 64x256 (head_dim 64, 8 waves)
         if (a.hn.dh == 72) return a.tile == 1 ? launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st) : launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
         return 1;
+    }
+    if (a.epi == EPI_RESID) {   // un-split residual projection of the ping-pong kernel (k-split schedule, 64 x 128 tiles, ring 4)
+        if (!a.zu || !a.zg || !a.zstat_out || !a.out || !a.bias || !a.resid || a.splitk != 1) return 1;
+        if (a.debug & 1) return a.gate ? launch_pp<64, 128, 2, 2, 4, EPI_RESID, 2, 64>(a, st) : launch_pp<64, 128, 2, 2, 4, EPI_RESID, 2>(a, st);   // A/B: ring 4
+        return a.gate ? launch_pp<64, 128, 2, 2, 6, EPI_RESID, 2, 64>(a, st) : launch_pp<64, 128, 2, 2, 6, EPI_RESID, 2>(a, st);
+    }
+    if (a.epi == EPI_GEGLU && a.zstat_in) {   // GEGLU GEMM that finishes the LayerNorm of its operand (LayerNorm algebra): ping-pong kernel only
+        if (a.tile != 60 || !(a.zG && a.zC && a.zparts > 0 && a.zparts <= 40)) return 1;
+        return launch_pp<128, 288, 4, 2, 3, EPI_GEGLU, 1, 64>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);
     if (a.epi == EPI_PARTIAL) return launch_e<EPI_PARTIAL>(a, st);

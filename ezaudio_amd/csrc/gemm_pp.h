@@ -41,13 +41,13 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// wait until at most `younger` x PER loads are in flight (younger in [0, MAXY])
-template <int PER, int MAXY>
+// wait until at most `younger` x PER (+ EXTRA) loads are in flight (younger in [0, MAXY])
+template <int PER, int MAXY, int EXTRA = 0>
 __device__ __forceinline__ void wait_younger(int younger) {
-    if constexpr (MAXY >= 3) { if (younger >= 3) { wait_vmcnt<3 * PER>(); return; } }
-    if constexpr (MAXY >= 2) { if (younger >= 2) { wait_vmcnt<2 * PER>(); return; } }
-    if constexpr (MAXY >= 1) { if (younger >= 1) { wait_vmcnt<PER>(); return; } }
-    wait_vmcnt<0>();
+    if constexpr (MAXY >= 3) { if (younger >= 3) { wait_vmcnt<3 * PER + EXTRA>(); return; } }
+    if constexpr (MAXY >= 2) { if (younger >= 2) { wait_vmcnt<2 * PER + EXTRA>(); return; } }
+    if constexpr (MAXY >= 1) { if (younger >= 1) { wait_vmcnt<PER + EXTRA>(); return; } }
+    wait_vmcnt<EXTRA>();
 }
 
 // exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
@@ -97,6 +97,44 @@ __device__ __forceinline__ void copy_out_bf16(const bf16_t* tile, int pitch, int
             }
         }
     }
+}
+
+// ---- LayerNorm algebra (GemmArgs.z*): (mu, r) of one row from its per-chunk partial statistics (sum, M2 about the chunk mean), merged
+// with Chan's parallel-variance formula; chunk p holds min(64, D - 64 p) columns.  Same accuracy class as a two-pass LayerNorm.
+constexpr int Z_MAXP = 40;   // chunks of 64 columns a row's statistics may have (2D = 2304 -> 36)
+// TPR threads per row (consecutive lanes), thread q of a row takes the chunks q, q + TPR, ...: every chunk is requested before the first use
+// and a row's chunks are read by neighbouring lanes (32 contiguous bytes per 4 lanes) -- the first build let every lane walk its own
+// row chunk by chunk (one L2 round trip per chunk, 16 lines per load instruction) and paid +11 us on the GEGLU GEMM for it.
+// All TPR lanes of the row return (mu, r).
+template <int TPR>
+__device__ __forceinline__ void z_row_stats_coop(const float2* __restrict__ st, int parts, int D, float eps, int q, float& mu, float& r) {
+    constexpr int NK = (Z_MAXP + TPR - 1) / TPR;
+    float2 v[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) v[k] = st[q + TPR * k < parts ? q + TPR * k : 0];
+    const int nlast = D - 64 * (parts - 1);            // columns of the last (possibly ragged) chunk
+    const float inv_last = 1.f / (float)nlast, inv_d = 1.f / (float)D;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) s += q + TPR * k < parts ? v[k].x : 0.f;
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
+    mu = s * inv_d;
+    float m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int p = q + TPR * k;
+        const bool last = p == parts - 1;
+        const float d = v[k].x * (last ? inv_last : 1.f / 64.f) - mu;
+        m2 += p < parts ? fmaf(last ? (float)nlast : 64.f, d * d, v[k].y) : 0.f;
+    }
+#pragma unroll
+    for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
+    r = rsqrtf(m2 * inv_d + eps);
+}
+// modulation slot of a row: the device step counter (slot0, read once per kernel) + the row's batch element offset (per-row timesteps only)
+__device__ __forceinline__ int z_slot(const GemmArgs& a, int slot0, int rowc) {
+    return slot0 + (a.row_slot ? a.row_slot[rowc / a.rows_per_b] : 0);
 }
 
 // ---- epilogues for the 16x16 C layout.  The MFMAs compute the TRANSPOSED tile (W fragment as the A operand), so a lane owns ONE
@@ -168,40 +206,73 @@ __device__ __forceinline__ void pp_store_direct(const GemmArgs& a, f32x4 (&acc)[
 // GEGLU: W rows are interleaved 8 value / 8 gate, so a 16-column fragment holds inner indices 8 j' .. 8 j' + 7: values in the lanes
 // with cg = lane >> 4 in {0, 1}, their gates in the lanes cg + 2 (= lane ^ 32).  Each lane of a pair finishes two of the four outputs
 // (branch-free: both lanes evaluate  mul * gelu(arg)  with their own selection of mul / arg).
-template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, int EPI>
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, int EPI, bool ZC>
 __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid, int z,
-                                             unsigned long long* ts = nullptr) {
+                                             const float2* zrow, int slot0, unsigned long long* ts = nullptr) {
     static_assert(EPI == EPI_GEGLU || EPI == EPI_PARTIAL, "bf16 outputs only");
     constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;   // output columns of the tile
     static_assert(OC % 8 == 0, "16-byte row chunks");
     constexpr int PITCH = OC + 8;
     bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
     const int m_in = lane & 15, cg = lane >> 4;
-    float4 b4[FN];
-    if constexpr (EPI == EPI_GEGLU) {   // bias of this lane's packed columns: requested up front, unconditionally (clamped)
-        const int ncl = a.N - 4;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            int cp = col0 + wn * TN + j * 16 + 4 * cg;
-            cp = cp < ncl ? cp : ncl;
-            b4[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cp) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
     uint32_t pk[FM][FN];
     if constexpr (EPI == EPI_GEGLU) {
         // the math runs out of registers BEFORE the barrier that frees the ring: the group that finished its MFMAs one interval earlier
         // overlaps its GELUs with the other group's last MFMA phase.  Exchange: v_permlane32_swap swaps the upper 32 lanes of its first
         // operand with the lower 32 lanes of its second; with (x0, x2) [and (x1, x3)] as operands the value lane ends up with
         // (v0, g0), the gate lane with (v2, g2): BOTH evaluate  first * gelu(second), no selects, no LDS.
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
+        // Every global operand is requested up front, unconditionally (clamped addresses): a load inside a bounds check makes hipcc wait
+        // vmcnt(0) once per fragment (18 dependent L2 round trips in the first build of this kernel).
+        const int ncl = a.N - 4;
+        // per-column vectors of the epilogue, requested once, up front: the bias (plain), or G' and C' of the modulation slot (LayerNorm algebra;
+        // C' includes the bias).  With per-row timesteps (row_slot) the slot differs between rows: they are re-read per row fragment then.
+        float4 c4[FN], g4[FN];
+        const bool shared_slot = !ZC || !a.row_slot;
+        if (shared_slot) {
+            const long so = ZC ? (long)slot0 * a.zt_slot_stride : 0;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const float x0 = acc[i][j][0] + b4[j].x, x1 = acc[i][j][1] + b4[j].y, x2 = acc[i][j][2] + b4[j].z, x3 = acc[i][j][3] + b4[j].w;
+                int cp = col0 + wn * TN + j * 16 + 4 * cg;
+                cp = cp < ncl ? cp : ncl;
+                if constexpr (ZC) {
+                    g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
+                    c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
+                } else {
+                    g4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    c4[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float mu = 0.f, r = 1.f;
+            if constexpr (ZC) {   // LayerNorm algebra: x = r (acc - mu G') + C'
+                const int rl = wm * TM + i * 16 + m_in;
+                if (!shared_slot) {
+                    int row = row0 + rl;
+                    row = row < a.M ? row : a.M - 1;
+                    const long so = (long)z_slot(a, slot0, row) * a.zt_slot_stride;
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        int cp = col0 + wn * TN + j * 16 + 4 * cg;
+                        cp = cp < ncl ? cp : ncl;
+                        g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
+                        c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
+                    }
+                }
+                const float2 mr = zrow[rl];
+                mu = mr.x; r = mr.y;
+            }
+            const float rm = r * mu;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const float x0 = fmaf(r, acc[i][j][0], fmaf(-rm, g4[j].x, c4[j].x)), x1 = fmaf(r, acc[i][j][1], fmaf(-rm, g4[j].y, c4[j].y));
+                const float x2 = fmaf(r, acc[i][j][2], fmaf(-rm, g4[j].z, c4[j].z)), x3 = fmaf(r, acc[i][j][3], fmaf(-rm, g4[j].w, c4[j].w));
                 const auto e0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x2), false, false);
                 const auto e1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
                 pk[i][j] = pack_bf2(__uint_as_float(e0[0]) * gelu_erf(__uint_as_float(e0[1])), __uint_as_float(e1[0]) * gelu_erf(__uint_as_float(e1[1])));
             }
+        }
     }
     __syncthreads();   // every wave is done with the last K tile: the ring is dead
     if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
@@ -231,17 +302,144 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
     copy_out_bf16<NT>(tile, PITCH, BM, OC, out, a.ldo, row0, EPI == EPI_GEGLU ? col0 / 2 : col0, a.M, EPI == EPI_GEGLU ? a.N / 2 : a.N, a.wt, tid);
 }
 
+// EPI_RESID: the un-split residual projection.  h_new = resid + gate * (acc + bias) (fp32, stored), its per-(row, 64-column chunk) partial
+// LayerNorm statistics, and A' = bf16(h_new * zg) -- the operand of the NEXT GEMM, whose epilogue finishes the LayerNorm (GemmArgs.z*).
+// One wave holds 16 rows x 64 columns here (TN == 64): a row's chunk statistics are an in-lane sum over 4 fragments plus two xor-shuffles.
+// The epilogue's operands (bias, residual rows, gate, LayerNorm gain) are requested at KERNEL START (pp_resid_operands) and ride through the K
+// loop in registers: after the loop nothing waits on global memory any more.
+template <int FM, int FN, int TM, int TN, bool GATE>
+__device__ __forceinline__ void pp_resid_operands(const GemmArgs& a, int row0, int col0, int wm, int wn, int lane, int slot0,
+                                                  float4 (&b4)[FM][FN], float4 (&r4)[FM][FN], float4 (&g4)[FM][FN], float4 (&z4)[FM][FN]) {
+    const int m_in = lane & 15, cg = lane >> 4;
+    const int ncl = a.N - 4;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = row0 + wm * TM + i * 16 + m_in;
+        const int rowc = row < a.M ? row : a.M - 1;
+        const int slot = z_slot(a, slot0, rowc);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {   // unconditional, clamped; bias and resid are mandatory, the gate is a template switch: a null-pointer test
+            int col = col0 + wn * TN + j * 16 + 4 * cg;   // per operand made hipcc serialise the loads behind vmcnt(0) waits
+            col = col < ncl ? col : ncl;
+            b4[i][j] = *reinterpret_cast<const float4*>(a.bias + col);
+            r4[i][j] = *reinterpret_cast<const float4*>(a.resid + (long)rowc * a.ldr + col);
+            if constexpr (GATE) g4[i][j] = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
+            else g4[i][j] = make_float4(1.f, 1.f, 1.f, 1.f);
+            z4[i][j] = *reinterpret_cast<const float4*>(a.zg + (long)slot * a.zg_slot_stride + col);
+        }
+    }
+}
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT>
+__device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid,
+                                               const float4 (&b4a)[FM][FN], const float4 (&r4a)[FM][FN], const float4 (&g4a)[FM][FN], const float4 (&z4a)[FM][FN]) {
+    static_assert(TN == 64 && FN == 4, "one 64-column statistics chunk per wave");
+    constexpr int PITCH = BN + 8;
+    static_assert(BN % 8 == 0, "16-byte row chunks");
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+    const int m_in = lane & 15, cg = lane >> 4;
+    float* out = reinterpret_cast<float*>(a.out);
+    uint2 pk[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = row0 + wm * TM + i * 16 + m_in;
+        const float4 (&b4)[FN] = b4a[i];
+        const float4 (&r4)[FN] = r4a[i];
+        const float4 (&g4)[FN] = g4a[i];
+        const float4 (&z4)[FN] = z4a[i];
+        float4 hn[FN];
+        float s1 = 0.f;
+        int nval = 0;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int col = col0 + wn * TN + j * 16 + 4 * cg;
+            const bool ok = col < a.N;
+            // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
+            hn[j].x = ok ? r4[j].x + g4[j].x * (acc[i][j][0] + b4[j].x) : 0.f;
+            hn[j].y = ok ? r4[j].y + g4[j].y * (acc[i][j][1] + b4[j].y) : 0.f;
+            hn[j].z = ok ? r4[j].z + g4[j].z * (acc[i][j][2] + b4[j].z) : 0.f;
+            hn[j].w = ok ? r4[j].w + g4[j].w * (acc[i][j][3] + b4[j].w) : 0.f;
+            nval += ok ? 4 : 0;
+            s1 += (hn[j].x + hn[j].y) + (hn[j].z + hn[j].w);
+            if (ok && row < a.M) {
+                float* dst = out + (long)row * a.ldo + col;
+                if (a.wt) st16_wt(dst, hn[j]); else *reinterpret_cast<float4*>(dst) = hn[j];
+            }
+        }
+        // chunk statistics over the valid columns of this wave's 64: the 4 lanes (cg) of a row sit 16 lanes apart
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        nval += __shfl_xor(nval, 16, 64);
+        nval += __shfl_xor(nval, 32, 64);
+        const float mean = nval > 0 ? s1 * __builtin_amdgcn_rcpf((float)nval) : 0.f;   // any value near the mean serves Chan's merge (the consumer recomputes the mean from the sums)
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const bool ok = col0 + wn * TN + j * 16 + 4 * cg < a.N;
+            float d;
+            d = hn[j].x - mean; q += ok ? d * d : 0.f;
+            d = hn[j].y - mean; q += ok ? d * d : 0.f;
+            d = hn[j].z - mean; q += ok ? d * d : 0.f;
+            d = hn[j].w - mean; q += ok ? d * d : 0.f;
+        }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        const int chunk = (col0 + wn * TN) >> 6;
+        if (cg == 0 && row < a.M && chunk * 64 < a.N) a.zstat_out[(long)row * ((a.N + 63) >> 6) + chunk] = make_float2(s1, q);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            pk[i][j].x = pack_bf2(hn[j].x * z4[j].x, hn[j].y * z4[j].y);
+            pk[i][j].y = pack_bf2(hn[j].z * z4[j].z, hn[j].w * z4[j].w);
+        }
+    }
+    __syncthreads();   // the exchange area of the k-split schedule is dead: park A'
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<uint2*>(tile + (wm * TM + i * 16 + m_in) * PITCH + wn * TN + j * 16 + 4 * cg) = pk[i][j];
+    __syncthreads();
+    copy_out_bf16<NT>(tile, PITCH, BM, BN, a.zu, a.ld_zu, row0, col0, a.M, a.N, a.wt, tid);
+}
+
 // fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile
 // holds NH = BN / head_dim WHOLE heads of q, of k or of v (D is a multiple of BN), parked in LDS as fp32 so that head boundaries need not
 // coincide with MFMA fragments; per-head LayerNorm + RoPE of q / k -> [B][H][Lp][DQK], V -> V^T [B][H][DV][Lp].
-template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT>
-__device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid) {
+template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT, bool ZC>
+__device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid,
+                                             const float2* zrow, int slot0) {
     constexpr int NH = BN / DH, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
     static_assert(NH * DH == BN && DH % 4 == 0 && (DH * 2) % 16 == 0, "whole heads");
     float* tile = reinterpret_cast<float*>(smem);                        // [BM][PITCH] fp32, reuses the ring
     bf16_t* qk_st = reinterpret_cast<bf16_t*>(smem + BM * PITCH * 4);    // [BM][NH][DH] bf16: normalised q / k heads on their way out
     static_assert((BM * PITCH * 4) % 16 == 0, "staging alignment");
     const int m_in = lane & 15, cg = lane >> 4;
+    if constexpr (ZC) {   // LayerNorm algebra: the projection of LN(x) g + c is  r (acc - mu G') + C'
+        const int ncl = a.N - 4;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int rl = wm * TM + i * 16 + m_in;
+            int row = row0 + rl;
+            row = row < a.M ? row : a.M - 1;
+            const long so = (long)z_slot(a, slot0, row) * a.zt_slot_stride;
+            float4 c4[FN], g4[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                int cp = col0 + wn * TN + j * 16 + 4 * cg;
+                cp = cp < ncl ? cp : ncl;
+                g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
+                c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
+            }
+            const float2 mr = zrow[rl];
+            const float r = mr.y, rm = mr.y * mr.x;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                acc[i][j][0] = fmaf(r, acc[i][j][0], fmaf(-rm, g4[j].x, c4[j].x));
+                acc[i][j][1] = fmaf(r, acc[i][j][1], fmaf(-rm, g4[j].y, c4[j].y));
+                acc[i][j][2] = fmaf(r, acc[i][j][2], fmaf(-rm, g4[j].z, c4[j].z));
+                acc[i][j][3] = fmaf(r, acc[i][j][3], fmaf(-rm, g4[j].w, c4[j].w));
+            }
+        }
+    }
     __syncthreads();                                                      // every wave is done with the ring
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -338,8 +536,9 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
     }
 }
 
-// VAR bits: timing ablations only (results are garbage; EZ_ABLATE builds): 8 = no MFMAs, 16 = no fragment reads, 32 = no LDS-DMA refill
-// inside the loop.  Measured and dropped (MI355X, 128x288 tile, cycles per K tile): s_setprio(1) over the MFMA phase 1809 vs 1793,
+// VAR bits: 64 = LayerNorm algebra in the epilogue (EPI_GEGLU / EPI_QKV consumers; EPI_RESID: the residual has a gate) -- a template
+// switch, not a run-time test, so that the epilogue's loads are straight-line;
+// timing ablations (results are garbage; EZ_ABLATE builds): 8 = no MFMAs, 16 = no fragment reads, 32 = no LDS-DMA refill inside the loop.  Measured and dropped (MI355X, 128x288 tile, cycles per K tile): s_setprio(1) over the MFMA phase 1809 vs 1793,
 // over the LOAD phase 1806, static priority for group 1 1819 -- priorities do not move this loop.
 // GemmArgs.ts (test hook, nullable): wave 0 of every workgroup records s_memtime at kernel start, loop start, loop end, kernel end
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR>
@@ -354,8 +553,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr int PA = BM / 32;                // pieces [0, PA) come from A, [PA, NP) from W
     constexpr int STAGE = NP * 4096;
     constexpr int PD = NS - 1;                 // prefetch distance in K tiles
-    static_assert(NS >= 3 && NS <= 5, "ring depth");
-    static_assert(NS * STAGE <= 160 * 1024, "LDS budget of a CU");
+    static_assert(NS >= 3 && NS <= 6, "ring depth");
+    static_assert(NS * STAGE + BM * 8 <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics)");
     constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -385,6 +584,28 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     const int ke = nk * (z + 1) / a.splitk;
     const int nt = ke - kb;
 
+    // VAR & 64 ("ZM"): EPI_GEGLU / EPI_QKV finish a LayerNorm in their epilogue (GemmArgs.z*, consumer side); EPI_RESID has a gate
+    constexpr bool ZM = (VAR & 64) != 0;
+    const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed in the epilogue only
+    float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
+    if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
+        // the tile's rows' partial statistics are one contiguous block: 4 threads per row, coalesced; lands under the prologue's first-tile wait;
+        // read back in the epilogue, many barriers later
+        static_assert(BM * 4 == NT, "4 threads per row");
+        int row = row0 + (tid >> 2);
+        row = row < a.M ? row : a.M - 1;
+        float mu, r;
+        z_row_stats_coop<4>(a.zstat_in + (long)row * a.zparts, a.zparts, a.zD, a.zeps, tid & 3, mu, r);
+        if ((tid & 3) == 0) zrow[tid >> 2] = make_float2(mu, r);
+    }
+    // EPI_RESID: the epilogue's operands (bias, residual rows, gate, LayerNorm gain) are requested NOW, in front of the prologue's LDS-DMA, and
+    // ride through the K loop in registers: after the loop nothing waits on global memory.  (Vector-memory loads complete in issue order, so
+    // the first tile's wait covers them: prologue 1842 -> 3799 cycles, epilogue 10120 -> 5668 on the D x D shape.  Requesting them BEHIND the
+    // LDS-DMA with a counted wait does not work from HIP source: beside in-flight LDS-DMA hipcc waits vmcnt(0) wherever it touches a register
+    // loaded from memory, and loads hidden in inline asm get copied by the register allocator before they land.)
+    constexpr int RFM = EPI == EPI_RESID ? FM / 2 : 1, RFN = EPI == EPI_RESID ? FN : 1;
+    float4 rb4[RFM][RFN], rr4[RFM][RFN], rg4[RFM][RFN], rz4[RFM][RFN];
+    if constexpr (EPI == EPI_RESID) pp_resid_operands<RFM, RFN, TM / 2, TN, ZM>(a, row0, col0, wm * 2 + grp, wn, lane, slot0, rb4, rr4, rg4, rz4);
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
     if (ts && lane == 0) ts[0] = __builtin_readcyclecounter();
     f32x4 acc[FM][FN];
@@ -661,16 +882,20 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         // from here on: 2 WM x WN waves, wave tile TM/2 x TN
         const int ewm = wm * 2 + grp;
+        if constexpr (EPI == EPI_RESID) {
+            static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "A' tile must fit the ring");
+            pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT>(a, half, smem, row0, col0, ewm, wn, lane, tid, rb4, rr4, rg4, rz4);
+        }
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
             static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");
-            pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT>(a, half, smem, row0, col0, ewm, wn, lane, tid);
+            pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zrow, slot0);
         }
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
-                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, ts);
+                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, zrow, slot0, ts);
                     if (ts && lane == 0) ts[3] = __builtin_readcyclecounter();
                     return;
                 }
@@ -682,7 +907,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
-                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, ts);
+                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, zrow, slot0, ts);
                     if (ts && lane == 0) ts[3] = __builtin_readcyclecounter();
                     return;
                 }

@@ -593,6 +593,39 @@ void launch_cfg_ddim(const CfgDdimArgs& a, float* partial, hipStream_t st) {
     hipLaunchKernelGGL(k_cfg_apply, dim3(CFG_NB, a.P), dim3(256), 0, st, a, partial);
 }
 
+// ---- LayerNorm algebra tables (common.h, GemmArgs.z*): G' = g W^T and C' = c W^T (+ bias) for every modulation slot.  The gain / shift
+// vectors enter the bf16 MFMA GEMM as EXACT hi + lo bf16 pairs (g = hi + lo up to 2^-17 relative), four operand rows per slot:
+// (g hi, g lo, c hi, c lo); k_z_combine adds the pairs back.  Runs once per call (ezdit_prepare_timesteps), not per step.
+__global__ void k_z_hilo(const float* g, const float* c, long slot_stride, bf16_t* out, int ldo, int n_slots, int D) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_slots * ldo) return;
+    const int s = (int)(i / ldo), k = (int)(i % ldo);
+    float gv = 0.f, cv = 0.f;
+    if (k < D) { gv = g[(long)s * slot_stride + k]; cv = c[(long)s * slot_stride + k]; }
+    const uint16_t gh = f2bf(gv), ch = f2bf(cv);
+    bf16_t* o = out + (long)(4 * s) * ldo + k;
+    o[0] = gh;
+    o[ldo] = f2bf(gv - bf2f(gh));
+    o[2 * (long)ldo] = ch;
+    o[3 * (long)ldo] = f2bf(cv - bf2f(ch));
+}
+__global__ void k_z_combine(const float* tmp, int ld_tmp, const float* bias, float* zG, float* zC, long slot_stride, int n_slots, int N) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_slots * N) return;
+    const int s = (int)(i / N), n = (int)(i % N);
+    const float* t = tmp + (long)(4 * s) * ld_tmp + n;
+    zG[(long)s * slot_stride + n] = t[0] + t[ld_tmp];
+    zC[(long)s * slot_stride + n] = t[2 * (long)ld_tmp] + t[3 * (long)ld_tmp] + (bias ? bias[n] : 0.f);
+}
+void launch_z_hilo(const float* g, const float* c, long slot_stride, bf16_t* out, int ldo, int n_slots, int D, hipStream_t st) {
+    const long total = (long)n_slots * ldo;
+    hipLaunchKernelGGL(k_z_hilo, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, g, c, slot_stride, out, ldo, n_slots, D);
+}
+void launch_z_combine(const float* tmp, int ld_tmp, const float* bias, float* zG, float* zC, long slot_stride, int n_slots, int N, hipStream_t st) {
+    const long total = (long)n_slots * N;
+    hipLaunchKernelGGL(k_z_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, ld_tmp, bias, zG, zC, slot_stride, n_slots, N);
+}
+
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st) {
     const long total = (long)M * ldo;
     hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, out, ldo, M, N, act);

@@ -194,6 +194,11 @@ int ezvae_sample(const float* dev_enc, const float* dev_noise, float* dev_z, int
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw,
                     const float* dev_bias, void* dev_out, int ldo, int M, int N, int K, int splitk,
                     ezdit_stream stream);
+/* unit-test hook of the un-split residual projection (LayerNorm algebra, producer side): h_out = h_in + gate * (A . W^T + bias) (fp32 [M][N]),
+ * zu = bf16(h_out * zg) ([M][ld_zu]) and zstat ([M][ceil(N / 64)] float pairs: sum and M2 about the chunk mean of each 64-column chunk). */
+int ezdit_test_resid(const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw, const float* dev_bias, const float* dev_h_in,
+                     const float* dev_gate, const float* dev_zg, float* dev_h_out, void* dev_zu_bf16, int ld_zu, void* dev_zstat,
+                     int M, int N, int K, ezdit_stream stream);
 /* test hook: ezdit_test_gemm launches of the ping-pong kernel record, per workgroup, eight 64-bit shader-clock stamps (kernel start, K-loop
  * start, K-loop end, kernel end, then epilogue internals) into dev_buf ([workgroups][8] uint64; NULL switches it off). */
 int ezdit_debug_gemm_timestamps(void* dev_buf);
@@ -221,6 +226,10 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   cn_overlap 0/1 (fused sampler: ControlNet branch on a side stream next to the backbone's in-blocks)
  *   gemm_pp (ping-pong kernel k_gemm_pp at M <= 2048: bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; the residual GEMMs select it with
  *     tile_partial = 62)
+ *   zfuse 0/1 (LayerNorm algebra: attention-out / cross-attention-out / MLP-out projections un-split with the residual, partial LayerNorm
+ *     statistics and the next GEMM's operand in their epilogue; the consumer GEMM finishes the LayerNorm in its epilogue -- no split-K slabs,
+ *     no row kernel on those edges; needs gemm_pp = 3 and fuse_q2), pp_max_m (largest number of token rows the ping-pong kernels and the
+ *     LayerNorm algebra are used at; above it the large-tile k_gemm2 path)
  *   gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
  *     row_affine 0/1 (the row kernel processes row panel p on XCD p % 8): a panel's slabs / residual stream / LayerNorm output stay in
  *     one XCD's L2 across the kernel boundary.  Placement only.

@@ -221,6 +221,79 @@ def mint_sampler(name, size, L, Lc, steps, seed_w, seed_in, guidance_scale, guid
     print('wrote', path, out.shape, float(out.std()))
 
 
+def mint_cn_sampler(name, size, L, Lc, steps, seed_w, seed_in, guidance_scale, guidance_rescale, eta, scale, out_dir='tests/golden'):
+    """Run the reference's UNMODIFIED ControlNet sampler, src/inference_controlnet.py:27-129 `inference`, on the reference's own MaskDiT +
+    DiTControlNet (synthetic checkpoints), with the duck-typed tokenizer / T5 / scheduler fakes of mint_sampler."""
+    import importlib
+    import torch
+    from .controlnet import CN_DEFAULT, make_controlnet_state_dict
+    from .weights import model_config, make_inputs, uniform_pm1
+    _import_reference()
+    for stub in ('pandas',):
+        try:
+            importlib.import_module(stub)
+        except Exception:
+            sys.modules.setdefault(stub, types.ModuleType(stub))
+    with contextlib.redirect_stdout(io.StringIO()):
+        from src.models.controlnet import DiTControlNet
+        from src.inference_controlnet import inference as cn_inference
+    cfg = model_config(size)
+    m, _ = build_reference(cfg, seed_w)
+    ccfg = dict(cfg)
+    ccfg.update({k: (list(v) if isinstance(v, list) else v) for k, v in CN_DEFAULT.items()})
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = DiTControlNet(**ccfg).eval()
+    sd = make_controlnet_state_dict(cfg, CN_DEFAULT, seed_w)
+    cn.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=False)
+    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, seed=seed_in)
+    C = cfg['out_chans']
+    s3 = np.float32(np.sqrt(3.0))
+    init = (uniform_pm1('smp.init', C * L, seed_in) * s3).reshape(1, C, L)
+    noises = [(uniform_pm1(f'smp.z{i}', C * L, seed_in) * s3).reshape(1, C, L) for i in range(steps)]
+    cond = (0.5 + 0.5 * uniform_pm1('smp.cond', 2 * L, seed_in)).reshape(1, 1, 2 * L).astype(np.float32)
+    tok = _FakeTok({'prompt': (np.array([[0]]), inp['ctx_mask'][0:1].astype(np.int64)),
+                    '': (np.array([[1]]), inp['ctx_mask'][1:2].astype(np.int64))})
+    t5 = _FakeT5({0: inp['ctx'][0:1], 1: inp['ctx'][1:2]})
+    sched = _OracleScheduler(DIFF, noises)
+    params = dict(text_encoder=dict(max_length=Lc), model=cfg, autoencoder=dict(scale=1.0, shift=0.0))
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: torch.from_numpy(init.copy())
+    try:
+        torch.set_num_threads(os.cpu_count())
+        out = cn_inference(lambda embedding: embedding, m, cn, None, None, torch.from_numpy(cond), tok, t5, params, sched,
+                           ['prompt'], None, L, guidance_scale, guidance_rescale, steps, eta, 2024, scale, 'cpu')
+    finally:
+        torch.randn = real_randn
+    meta = dict(size=size, L=L, Lc=Lc, steps=steps, seed_w=seed_w, seed_in=seed_in, guidance_scale=guidance_scale,
+                guidance_rescale=guidance_rescale, eta=eta, scale=scale)
+    path = os.path.join(out_dir, f'sampler_{name}.npz')
+    np.savez(path, meta=np.array(repr(meta)), latent=out.numpy().astype(np.float32))
+    print('wrote', path, out.shape, float(out.std()))
+
+
+def mint_energy(name, out_dir='tests/golden'):
+    """The reference's EnergyExtractor, loaded BY FILE PATH from src/models/conditions/energy.py:7-56 (the package __init__ pulls in unrelated
+    modules), with the conditioner section of ckpts/controlnet/energy_l.yml:46-52, on deterministic waveforms."""
+    import importlib.util
+    import torch
+    from .weights import uniform_pm1
+    spec = importlib.util.spec_from_file_location('ref_energy', os.path.join(REF, 'src/models/conditions/energy.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ex = mod.EnergyExtractor(hop_size=240, window_size=1920, padding='reflect', min_db=-60, norm=True)
+    arrs = {}
+    for i, (n, amp) in enumerate(((24000, 0.1), (240000, 0.5), (7201, 0.02))):
+        t = np.arange(n, dtype=np.float32)
+        wav = (amp * uniform_pm1(f'energy.wav{i}', n, 7) * (0.55 + 0.45 * np.sin(2 * np.pi * t / 5000.0))).astype(np.float32).reshape(1, n)
+        wav[:, n // 3:n // 3 + 2000] = 0.0   # a silent stretch: exercises the -60 dB floor
+        with torch.no_grad():
+            e = ex(torch.from_numpy(wav.copy())).numpy()
+        arrs[f'n{i}'] = np.array([n, amp], dtype=np.float64)
+        arrs[f'energy{i}'] = e.astype(np.float32)
+        print('minted energy', i, e.shape, float(e.mean()))
+    np.savez(os.path.join(out_dir, f'{name}.npz'), **arrs)
+
+
 def _import_reference_vae():
     """OobleckDecoder / OobleckEncoder from the reference; third-party modules its file imports at the top but the
     Oobleck path never touches (torchaudio, alias_free_torch, vector_quantize_pytorch; autoencoders.py:7-8, bottleneck.py:6)
@@ -327,6 +400,14 @@ JOBS = {
     'xl_b8':     (mint_forward, dict(size='xl', L=500, Lc=100, timesteps=[499], seed_w=1234, seed_in=14, n_valid=(12, 1, 30, 1, 5, 1, 100, 1), B=8)),
     # config #5: XL width + the energy_l.yml controlnet section, 10 s latent; residual rows sampled every 25 tokens
     'cn_xl':     (mint_controlnet, dict(size='xl', L=500, Lc=100, t=[979, 499], seed_w=1234, seed_in=33, scale=1.0, row_stride=25)),
+    # the ONE ControlNet configuration the reference ships: EzAudio-L + ckpts/controlnet/energy_l.yml, 10 s latent
+    'cn_l':      (mint_controlnet, dict(size='l', L=500, Lc=100, t=[979, 499], seed_w=1234, seed_in=34, scale=1.0, row_stride=25)),
+    # ... and its sampler: the reference's unmodified src/inference_controlnet.py::inference, 50 steps, guidance 3.5, no rescale, eta 1
+    'smp_cn_l':  (mint_cn_sampler, dict(size='l', L=500, Lc=100, steps=50, seed_w=1234, seed_in=23, guidance_scale=3.5, guidance_rescale=0.0, eta=1.0, scale=1.0)),
+    # editing above toy size (conditioners.py:151-176, inference.py:79-86,103-104): forward with gt + mask and the full loop, L = 300
+    'l_edit':    (mint_forward, dict(size='l', L=300, Lc=100, timesteps=[499], seed_w=1234, seed_in=12, with_gt=True)),
+    'smp_l_edit': (mint_sampler, dict(size='l', L=300, Lc=100, steps=50, seed_w=1234, seed_in=24, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0, with_gt=True)),
+    'energy':    (mint_energy, dict()),
 }
 
 

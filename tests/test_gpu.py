@@ -139,6 +139,41 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 1152, 1152), (1000, 1152, 4608), (192, 144, 192), (192, 128, 128), (77, 576, 64), (500, 1024, 320)])
+def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K):
+    """Producer side of the LayerNorm algebra (EPI_RESID of k_gemm_pp): h_new = h + gate * (A W^T + b) in fp32, its per-64-column-chunk
+    (sum, M2) statistics -- merged here with Chan's formula and compared with the row's true mean / variance -- and A' = bf16(h_new * g)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    Np = (N + 127) // 128 * 128
+    W = torch.zeros(Np, K, dtype=torch.bfloat16)
+    W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias, gate, zg = torch.randn(N, generator=g), torch.rand(N, generator=g), 1 + 0.3 * torch.randn(N, generator=g)
+    h_in = torch.randn(M, N, generator=g) + 0.7          # a row mean that is not small against the spread
+    ref = h_in.double() + gate.double() * (A.float().double() @ W[:N].float().double().T + bias.double())
+    ld = (N + 63) // 64 * 64
+    parts = (N + 63) // 64
+    Ad, Wd, bd, gd, zd, hd = A.to(dev), W.to(dev), bias.to(dev), gate.to(dev), zg.to(dev), h_in.to(dev)
+    h_out = torch.full((M, N), float('nan'), device=dev)
+    zu = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    zs = torch.zeros(M, parts, 2, device=dev)
+    rc = lib.ezdit_test_resid(Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), hd.data_ptr(), gd.data_ptr(), zd.data_ptr(), h_out.data_ptr(),
+                              zu.data_ptr(), ld, zs.data_ptr(), M, N, K, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = h_out.cpu().double()
+    assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
+    st = zs.cpu().double()
+    n = torch.tensor([min(64, N - 64 * p) for p in range(parts)], dtype=torch.float64)
+    mean = st[:, :, 0].sum(1) / N
+    m2 = (st[:, :, 1] + n * (st[:, :, 0] / n - mean[:, None]) ** 2).sum(1)
+    np.testing.assert_allclose(mean.numpy(), ref.mean(1).numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose((m2 / N).numpy(), ref.var(1, unbiased=False).numpy(), rtol=2e-5)
+    want = (got * zg.double()).float()
+    assert rel_l2(zu.float().cpu().numpy()[:, :N], want.numpy()) < 3e-3     # one bf16 rounding
+    assert (zu.float().cpu()[:, N:] == 0).all()
+
+
 @pytest.mark.parametrize('tile', [6, 13, 40, 41, 42, 2013, 2040, 2041, 2042, 2060, 2061, 2062, 2063, 2064, 2065])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
@@ -235,6 +270,30 @@ def test_forward_matches_reference_golden(lib, dev, name):
         r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
         print(f'{name} t={t}: rel-L2 {r:.3e} max-abs {a:.3e}')
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, t, r, a)
+
+
+@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'xl'])
+def test_layernorm_algebra_path_matches_reference_golden(lib, dev, name):
+    """Option zfuse (off by default: measured slower): un-split residual projections whose epilogue emits h, partial LayerNorm
+    statistics and the next GEMM's operand h * g, the consumer GEMM finishing the LayerNorm as r (acc - mu G') + C' in its epilogue.  Same
+    gates against the reference's own outputs as the default path; fewer launches (no split-K slabs, no row kernel on those edges)."""
+    cfg, sd, inp, kw, g, meta = golden_case(name)
+    m = get_model(meta['size'], meta['seed_w'])
+    t = meta['timesteps'][0]
+    ref = g[f'pred_t{t}']
+    base = _forward(m, inp, t, kw).cpu().numpy()
+    n_base = m.last_launch_count
+    assert lib.ezdit_set_option(m._h, b'zfuse', 1) == 0
+    try:
+        pred = _forward(m, inp, t, kw).cpu().numpy()
+        n_z = m.last_launch_count
+    finally:
+        assert lib.ezdit_set_option(m._h, b'zfuse', 0) == 0
+    nblk = cfg['depth'] + 1
+    assert n_z == n_base - (2 * nblk + cfg['depth'] // 2)      # attention-out and cross-out of every block, MLP-out in front of in / mid blocks
+    r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
+    print(f'{name} t={t} zfuse: rel-L2 {r:.3e} max-abs {a:.3e} (default path {rel_l2(base, ref):.3e}); launches {n_base} -> {n_z}')
+    assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
 @pytest.mark.parametrize('size,L', [('s', 77), ('s64', 131), ('s', 1), ('s', 1500)])
@@ -431,11 +490,11 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=0)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
-                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62))])
+                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -448,7 +507,7 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
         assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
         outs.append(_forward(m, inp, 499, kw).cpu().numpy())
     assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0   # shipped defaults
-    if opt not in ('row_variant', 'gemm_pp', 'tile_partial'):   # placement / issue order / launch structure only: bitwise identical
+    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse'):   # placement / issue order / launch structure only: bitwise identical
         for o in outs[1:]:
             np.testing.assert_array_equal(outs[0], o)
     else:   # row_variant: same math, different rounding points; gemm_pp / tile_partial: another kernel (other MFMA shape, other fp32 summation order over K)

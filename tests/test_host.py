@@ -180,7 +180,7 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
     _, h = _handle(lib, 'xs')
     names = ['tile_partial', 'tile_f32', 'tile_qkv', 'tile_p18', 'tile_p36', 'tile_p72', 'geglu_tile', 'tile_partial_big', 'tile_f32_big',
              'geglu_big', 'split18', 'split36', 'split72', 'split_big', 'xcd_map', 'slab_bf16', 'wt', 'fuse_qkv', 'qkv_waves9', 'fuse_q2',
-             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'cn_overlap', 'gemm_pp',
+             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'cn_overlap', 'gemm_pp', 'zfuse', 'pp_max_m',
              'gemm_panel', 'row_affine', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2']
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
     for n in names:
@@ -238,7 +238,7 @@ def test_ping_pong_schedules_are_hazard_free_model():
     checks, for every ring depth and K-tile count: both groups execute the same number of barriers; a tile is read only after every wave
     that issued pieces of it has waited for them BEFORE an earlier barrier (RAW); the counted wait allows exactly the pieces of the
     group's younger tiles to stay in flight; a ring slot is refilled only behind a barrier that follows its last read (WAR)."""
-    for NS in (3, 4, 5):
+    for NS in (3, 4, 5, 6):
         PD = NS - 1
         for nt in range(1, 14):
             # ---------------- SCHED 1: both groups issue a share of every tile and read every tile

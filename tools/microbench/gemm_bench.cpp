@@ -51,9 +51,7 @@ int main(int argc, char** argv) {
     };
     // which configurations run on which shape
     std::vector<Cfg> wide = {   // N >= 3456
-        {"old 128x288 12w r3 (13)", 13, 2, 1, 0, 1}, {"pp 128x288 s1 r3 (60)", 60, 2, 1, 0, 1}, {"pp60 var1 setprio", 60, 2, 1, 1, 1},
-        {"pp60 var2 dma-first", 60, 2, 1, 2, 1}, {"pp60 var64 interleave", 60, 2, 1, 64, 1}, {"pp60 var128 load prio", 60, 2, 1, 128, 1}, {"pp60 var192", 60, 2, 1, 192, 1}, {"pp60 var65", 60, 2, 1, 65, 1},
-        {"pp61 var64", 61, 2, 1, 64, 1}, {"pp61 var192", 61, 2, 1, 192, 1}, {"pp60 var5 static prio", 60, 2, 1, 5, 1},
+        {"old 128x288 12w r3 (13)", 13, 2, 1, 0, 1}, {"pp 128x288 s1 r3 (60)", 60, 2, 1, 0, 1}, {"pp60 LN-algebra epilogue", 60, 2, 1, 0, 9}, 
         {"pp 128x144 s2 r4 (61) geglu", 61, 2, 1, 0, 1}, {"pp 128x144 s2 r3 (64) geglu", 64, 2, 1, 0, 1},
         {"pp 128x128 s1 r3 (62) geglu", 62, 2, 1, 0, 1}, {"pp 128x128 s2 r4 (65) geglu", 65, 2, 1, 0, 1},
         {"pp60 abl8 noMFMA", 60, 2, 1, 8, 1}, {"pp60 abl16 noReads", 60, 2, 1, 16, 1}, {"pp60 abl32 noDMA", 60, 2, 1, 32, 1},
@@ -188,6 +186,35 @@ int main(int argc, char** argv) {
             if (bad) printf("      %ld elements out of tolerance\n", bad);
             fflush(stdout);
             CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+        }
+        if (N == 1152 && (!cfilter[0] || strstr("resid", cfilter))) {   // un-split residual projection with LayerNorm statistics (EPI_RESID)
+            float *dh, *dg, *dz; uint16_t* dzu; float* dzs;
+            CHECK(hipMalloc(&dh, (size_t)Mp * N * 4)); CHECK(hipMalloc(&dg, N * 4)); CHECK(hipMalloc(&dz, N * 4));
+            CHECK(hipMalloc(&dzu, (size_t)Mp * N * 2)); CHECK(hipMalloc(&dzs, (size_t)Mp * (N / 64) * 8));
+            CHECK(hipMemset(dh, 0, (size_t)Mp * N * 4)); CHECK(hipMemcpy(dg, hb.data(), N * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dz, hb.data(), N * 4, hipMemcpyHostToDevice));
+            auto run = [&]() { return ezdit_test_resid(dA, K, dW, K, db, dh, dg, dz, dout, dzu, N, dzs, M, N, K, st); };
+            if (run()) { printf("   resid unsupported (%s)\n", ezdit_last_error()); }
+            else {
+                CHECK(hipStreamSynchronize(st));
+                hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+                for (int i = 0; i < 5; ++i) run();
+                CHECK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; ++i) run();
+                CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+                float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+                printf("   %-34s %8.2f us  %7.1f TF\n", "pp 64x128 s2 EPI_RESID (un-split)", ms * 1e3 / iters, 2.0 * M * N * K / (ms * 1e3 / iters) * 1e-6);
+                const int NWG = 8192;
+                unsigned long long* dts; CHECK(hipMalloc(&dts, NWG * 8 * 8)); CHECK(hipMemsetAsync(dts, 0, NWG * 8 * 8, st));
+                ezdit_debug_gemm_timestamps(dts); run(); ezdit_debug_gemm_timestamps(nullptr);
+                CHECK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> hts(NWG * 8);
+                CHECK(hipMemcpy(hts.data(), dts, NWG * 8 * 8, hipMemcpyDeviceToHost));
+                double pro = 0, loop = 0, epi = 0; int n = 0;
+                for (int w = 0; w < NWG; ++w) { const unsigned long long* t = &hts[8 * w]; if (!t[0] || !t[3]) continue; ++n; pro += t[1] - t[0]; loop += t[2] - t[1]; epi += t[3] - t[2]; }
+                if (n) printf("      stamps (%d WGs): prologue %.0f | loop %.0f (%.1f per K tile) | epilogue %.0f\n", n, pro / n, loop / n, loop / n / (K / 64), epi / n);
+                CHECK(hipFree(dts));
+            }
+            CHECK(hipFree(dh)); CHECK(hipFree(dg)); CHECK(hipFree(dz)); CHECK(hipFree(dzu)); CHECK(hipFree(dzs));
         }
         CHECK(hipFree(dA)); CHECK(hipFree(dW)); CHECK(hipFree(db)); CHECK(hipFree(dC)); CHECK(hipFree(dout));
     }
