@@ -1376,6 +1376,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
+    a.ts = g_gemm_ts;
     (void)hipGetLastError();
     if (launch_attention(a, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "attention configuration not supported");
     const hipError_t e = hipGetLastError();

@@ -80,6 +80,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     }
     const int q0 = qt * 64 + qs * 32;
     const long bh = (long)b * a.H + h;
+    unsigned long long* ts = (a.ts && tid < 64) ? a.ts + 8 * (long)blockIdx.x : nullptr;
+    if (ts && lane == 0) ts[0] = __builtin_readcyclecounter();
 
     const bf16_t* Q = a.q + (bh * a.Lqp + q0 + r32) * DQK + 8 * hi;
     const char* Kg = reinterpret_cast<const char*>(a.k + bh * a.Lkp * DQK);
@@ -358,6 +360,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     LOAD_TILE(0);
     WRITE_TILE(0);
     __syncthreads();
+    if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) LOAD_TILE(t + 1);
         const char* kb = smem + (t & 1) * BUF;
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
         __syncthreads();
     }
 
+    if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
     // ---- merge the key sub-blocks: (m, l, O) of the waves kh >= 1 -> LDS -> kh = 0 (log-sum-exp merge) ----
 #pragma unroll
     for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[tt]));
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             for (int r = 0; r < 16; ++r) o[tt][r] = o[tt][r] * a1 + xo_r[((qs * NDT + tt) * 16 + r) * 64 + lane] * a2;
     }
     const float inv = 1.f / lsum;
+    if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
 
     // lane holds O^T[d = 32t + (r&3) + 8*(r>>2) + 4*hi][q = q0 + r32]
     const int qrow = q0 + r32;
@@ -493,6 +498,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 *reinterpret_cast<uint2*>(orow + d) = v;
             }
         }
+    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
 }
 
 #undef LOAD_TILE

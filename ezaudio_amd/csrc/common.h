@@ -190,6 +190,7 @@ struct AttnArgs {
     // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)
     // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)
     const float2* zstat_in; int zparts; int zD; const float* zG; const float* zC; float zeps;
+    unsigned long long* ts;     // test hook: [workgroup][8] shader-clock stamps (start, operands staged, tile loop end, merge end, end), nullable
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 

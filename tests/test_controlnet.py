@@ -7,7 +7,7 @@ import pytest
 
 from oracle.controlnet import CN_DEFAULT, ControlNetOracle, conv1d, energy_curve, make_controlnet_state_dict
 from oracle.dit import DiTOracle
-from oracle.weights import make_inputs, make_state_dict, model_config, uniform_pm1
+from oracle.weights import make_inputs, make_state_dict, model_config, uniform_pm1  # noqa: F401
 from tests.util import GOLDEN, rel_l2
 
 
@@ -29,9 +29,10 @@ def _cn_keys(meta):
     return pairs, meta.get('row_stride', 1)
 
 
-@pytest.mark.parametrize('name,only_t', [('cn_xs', None), ('cn_s', None), ('cn_xl', 499)])
+@pytest.mark.parametrize('name,only_t', [('cn_xs', None), ('cn_s', None), ('cn_xl', 499), ('cn_l', 499)])
 def test_controlnet_oracle_matches_reference_golden(name, only_t):
-    """cn_xl = BASELINE config #5's shape (XL width, energy_l.yml controlnet section, 10 s latent); one of its two timesteps on CPU."""
+    """cn_xl = BASELINE config #5's shape (XL width, energy_l.yml controlnet section, 10 s latent); cn_l = the one ControlNet configuration
+    the reference ships (EzAudio-L + ckpts/controlnet/energy_l.yml); one of their two timesteps on CPU."""
     cfg, sd, csd, inp, cond, g, meta = cn_case(name)
     o = DiTOracle(cfg, sd)
     co = ControlNetOracle(cfg, csd)
@@ -72,6 +73,62 @@ def test_conv1d_and_energy_curve_against_torch():
     np.testing.assert_allclose(c[:, 0].numpy(), gdb.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_energy_extractor_matches_the_reference_file_golden():
+    """tests/golden/energy.npz was minted by loading /root/reference/src/models/conditions/energy.py BY FILE PATH (oracle/mint_golden.py::
+    mint_energy; conditioner section of ckpts/controlnet/energy_l.yml): the product's Conditioner and the oracle's energy_curve against the
+    reference's own outputs, incl. a silent stretch (the -60 dB floor) and a length that is not a multiple of the hop."""
+    import torch
+    from ezaudio_amd.conditions import Conditioner
+    g = np.load(os.path.join(GOLDEN, 'energy.npz'))
+    cond = Conditioner('energy', hop_size=240, window_size=1920, padding='reflect', min_db=-60, norm=True)
+    for i in range(3):
+        n, amp = int(g[f'n{i}'][0]), float(g[f'n{i}'][1])
+        t = np.arange(n, dtype=np.float32)
+        wav = (amp * uniform_pm1(f'energy.wav{i}', n, 7) * (0.55 + 0.45 * np.sin(2 * np.pi * t / 5000.0))).astype(np.float32).reshape(1, n)
+        wav[:, n // 3:n // 3 + 2000] = 0.0
+        ref = g[f'energy{i}']                                    # [1, frames, 1]
+        frames = ref.shape[1]
+        np.testing.assert_allclose(energy_curve(wav)[:, :frames], ref, rtol=2e-4, atol=2e-5)
+        c = cond(torch.from_numpy(wav), (1, 128, frames // 2))     # [1, 1, 2 * latent frames]
+        m = min(c.shape[-1], frames)
+        np.testing.assert_allclose(c[0, 0, :m].numpy(), ref[0, :m, 0], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_controlnet_sampler_matches_the_reference_controlnet_loop_golden(lib):
+    """sampler_smp_cn_l: the reference's UNMODIFIED src/inference_controlnet.py::inference (50 steps, guidance 3.5, no rescale, eta 1) on the
+    configuration it ships -- EzAudio-L + the energy ControlNet of ckpts/controlnet/energy_l.yml -- against the fused HIP sampler with the
+    ControlNet attached (one captured graph per step: ControlNet on a side stream + backbone + CFG / DDIM)."""
+    import ast
+    import torch
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    from tests.util import DIFF
+    g = np.load(os.path.join(GOLDEN, 'sampler_smp_cn_l.npz'))
+    meta = ast.literal_eval(str(g['meta']))
+    cfg = model_config(meta['size'])
+    sd = make_state_dict(cfg, meta['seed_w'])
+    csd = make_controlnet_state_dict(cfg, CN_DEFAULT, meta['seed_w'])
+    m, cn = _models(cfg, sd, csd)
+    L, Lc, steps = meta['L'], meta['Lc'], meta['steps']
+    inp = make_inputs(cfg, B=2, L=L, Lc=Lc, seed=meta['seed_in'])
+    C = cfg['out_chans']
+    s3 = np.float32(np.sqrt(3.0))
+    init = (uniform_pm1('smp.init', C * L, meta['seed_in']) * s3).reshape(1, C, L)
+    noises = [(uniform_pm1(f'smp.z{i}', C * L, meta['seed_in']) * s3).reshape(1, C, L) for i in range(steps)]
+    cond = (0.5 + 0.5 * uniform_pm1('smp.cond', 2 * L, meta['seed_in'])).reshape(1, 1, 2 * L).astype(np.float32)
+    smp = LatentSampler(m, DDIMScheduler(**DIFF))
+    smp.prepare(_t(inp['ctx'][0:1]), _t(inp['ctx_mask'][0:1]), _t(inp['ctx'][1:2]), _t(inp['ctx_mask'][1:2]), _t(init),
+                torch.stack([_t(z) for z in noises], 0), meta['guidance_scale'], meta['guidance_rescale'], steps, meta['eta'],
+                controlnet=cn, condition=_t(cond), conditioning_scale=meta['scale'])
+    smp.run(steps)
+    lat = smp.finish()
+    torch.cuda.synchronize()
+    r = rel_l2(lat.cpu().numpy(), g['latent'])
+    print(f'smp_cn_l: final-latent rel-L2 {r:.3e}')
+    assert torch.isfinite(lat).all() and r < 2e-2
+
+
 # ---------------------------------------------------------------------------------------------------
 def _t(a):
     import torch
@@ -90,7 +147,7 @@ def _models(cfg, sd, csd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', ['cn_xs', 'cn_s', 'cn_xl'])
+@pytest.mark.parametrize('name', ['cn_xs', 'cn_s', 'cn_xl', 'cn_l'])
 def test_controlnet_hip_matches_reference_golden(lib, name):
     """cn_xl: BASELINE config #5 (XL width + the energy ControlNet, L = 500) at t in {979, 499} against the reference's own
     DiTControlNet residuals and the backbone prediction that consumes them."""

@@ -1,0 +1,45 @@
+// Kernel-level timing of the attention kernel through the C ABI test hook, with in-kernel cycle stamps (no Python):
+//   hipcc --offload-arch=gfx950 -O2 -x hip tools/microbench/attn_bench.cpp -o tools/_run/attn_bench -Iinclude -Lezaudio_amd -lezaudio_hip -Wl,-rpath,'$ORIGIN/../../ezaudio_amd'
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "ezdit.h"
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+static uint32_t rs = 777u;
+static uint16_t rbf() { rs = rs * 1664525u + 1013904223u; float f = ((rs >> 8) & 0xffff) / 32768.0f - 1.0f; uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
+int main() {
+    ezdit_config c; memset(&c, 0, sizeof c);
+    c.embed_dim = 1152; c.num_heads = 16; c.depth = 28; c.in_chans = 257; c.out_chans = 128; c.context_dim = 2048; c.ada_sola_rank = 36; c.ada_sola_alpha = 36; c.mlp_ratio = 4.0f; c.max_len = 2048;
+    ezdit_handle* h = nullptr;
+    if (ezdit_create(&c, &h)) { printf("create failed: %s\n", ezdit_last_error()); return 1; }
+    hipStream_t st; CHECK(hipStreamCreate(&st));
+    const int B = 2, H = 16, DQK = 80, DV = 96, D = 1152;
+    struct Case { int Lq, Lk; } cases[] = {{500, 500}, {500, 100}};
+    for (auto cs : cases) {
+        const int Lqp = (cs.Lq + 127) / 128 * 128, Lkp = (cs.Lk + 127) / 128 * 128;
+        std::vector<uint16_t> q((size_t)B * H * Lqp * DQK), k((size_t)B * H * Lkp * DQK), v((size_t)B * H * DV * Lkp);
+        for (auto& x : q) x = rbf(); for (auto& x : k) x = rbf(); for (auto& x : v) x = rbf();
+        uint16_t *dq, *dk, *dv, *dout; 
+        CHECK(hipMalloc(&dq, q.size() * 2)); CHECK(hipMalloc(&dk, k.size() * 2)); CHECK(hipMalloc(&dv, v.size() * 2)); CHECK(hipMalloc(&dout, (size_t)B * cs.Lq * D * 2));
+        CHECK(hipMemcpy(dq, q.data(), q.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dk, k.data(), k.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dv, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+        auto run = [&]() { return ezdit_test_attention(h, dq, dk, dv, nullptr, dout, B, cs.Lq, cs.Lk, Lqp, Lkp, st); };
+        if (run()) { printf("attention failed: %s\n", ezdit_last_error()); return 1; }
+        CHECK(hipStreamSynchronize(st));
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        for (int i = 0; i < 5; ++i) run();
+        CHECK(hipEventRecord(e0, st)); for (int i = 0; i < 50; ++i) run(); CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const int NWG = 4096; unsigned long long* dts; CHECK(hipMalloc(&dts, NWG * 64)); CHECK(hipMemsetAsync(dts, 0, NWG * 64, st));
+        ezdit_debug_gemm_timestamps(dts); run(); ezdit_debug_gemm_timestamps(nullptr); CHECK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> t(NWG * 8); CHECK(hipMemcpy(t.data(), dts, NWG * 64, hipMemcpyDeviceToHost));
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int n = 0;
+        for (int w = 0; w < NWG; ++w) { const unsigned long long* s = &t[8 * w]; if (!s[0] || !s[3] || !s[4]) continue; ++n; a0 += s[1] - s[0]; a1 += s[2] - s[1]; a2 += s[4] - s[2]; a3 += s[3] - s[4]; }
+        printf("attention B=%d H=%d Lq=%d Lk=%d: %.2f us | stamps (%d WGs, cycles): operands staged %.0f | tile loop %.0f | merge %.0f | store %.0f\n", B, H, cs.Lq, cs.Lk, ms * 1e3 / 50, n, a0 / (n ? n : 1), a1 / (n ? n : 1), a2 / (n ? n : 1), a3 / (n ? n : 1));
+        CHECK(hipFree(dq)); CHECK(hipFree(dk)); CHECK(hipFree(dv)); CHECK(hipFree(dout)); CHECK(hipFree(dts));
+    }
+    ezdit_destroy(h);
+    return 0;
+}
