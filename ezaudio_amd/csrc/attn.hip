@@ -303,15 +303,26 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     // staging registers: NAMED scalars, not an array (hipcc demotes a register array that is live across the tile loop
     // to scratch); every thread issues all its loads unconditionally (chunk index clamped), only LDS writes are predicated
     uint4 k0 = {}, k1 = {}, k2 = {}, v0 = {}, v1 = {}, v2 = {};
+    // per-thread byte offsets of the staged chunks, computed ONCE; the tile base pointers below are wave-uniform, so the loads take the
+    // SGPR-base + 32-bit VGPR-offset form and the loop spends no VALU work on 64-bit addresses
+    uint32_t koff[3], voff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int ck = tid + NT * i, cv = tid + NT * i;
+        ck = ck < KCH ? ck : KCH - 1;
+        cv = cv < VCH ? cv : VCH - 1;
+        koff[i] = (uint32_t)ck * 16u;
+        voff[i] = ((uint32_t)(cv / VCPR) * (uint32_t)a.Lkp + (uint32_t)(cv % VCPR) * 8u) * 2u;
+    }
+    // buffer loads: descriptor (SGPRs, wave-uniform) + the per-thread 32-bit offset above + the tile offset as the scalar soffset -> no
+    // per-tile address arithmetic at all
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kg), 0, a.Lkp * DQK * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VTg), 0, DV * a.Lkp * 2, 0x00020000);
     auto kchunk = [&](int i, int key0) -> uint4 {
-        int c = tid + NT * i;
-        c = c < KCH ? c : KCH - 1;
-        return *reinterpret_cast<const uint4*>(Kg + (long)key0 * DQK * 2 + c * 16);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(krs, (int)koff[i], key0 * DQK * 2, 0));
     };
     auto vchunk = [&](int i, int key0) -> uint4 {
-        int c = tid + NT * i;
-        c = c < VCH ? c : VCH - 1;
-        return *reinterpret_cast<const uint4*>(VTg + (long)(c / VCPR) * a.Lkp + key0 + (c % VCPR) * 8);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(vrs, (int)voff[i], key0 * 2, 0));
     };
     auto kstore = [&](int i, char* kb, const uint4& val) {
         const int c = tid + NT * i;
@@ -371,26 +382,40 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             const int kidx = key0 + r32;
             bool kv = kidx < a.Lk;
             if (km) kv = kv && (km[kidx < a.Lk ? kidx : 0] != 0);
-            const uint32_t tmask = (uint32_t)__ballot(kv) >> (4 * hi);  // lanes 0..31 fill bits 0..31
+            const uint32_t ball = (uint32_t)__ballot(kv);               // lanes 0..31 fill bits 0..31
+            const uint32_t tmask = ball >> (4 * hi);
+            // wave-uniform: no key of this sub-tile is masked or beyond Lk (every self-attention tile but the last).  The loop is bound
+            // by VALU issue (~300 instructions per wave and tile against 11 MFMAs, tools/microbench/attn_bench.cpp), so the common case
+            // drops the per-element mask selects and folds scale and reference max into one FMA feeding exp2.
+            const bool full = ball == 0xffffffffu;
+            // S^T in VGPRs (the softmax reads every element once: through AGPRs that is 16 v_accvgpr_read per tile), written by inline-asm
+            // MFMAs so that the register class is ours to choose.  The wait states hipcc would insert are inside the strings: 2 in front
+            // (an operand may have just been written by a VALU or DS instruction the compiler scheduled right before the statement) and
+            // 20 behind the last one (its final pass writes s[12..15]; any reader but a chained MFMA must stay that far behind).
             f32x16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kh * 32 + r32) * KSTR + (2 * ks + hi) * 16);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            {
+                const bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kb + (kh * 32 + r32) * KSTR + hi * 16);
+                asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(kf0), "v"(qf[0]));
             }
-            // The last MFMA writes a12..a15 in its final pass.  hipcc 7.2 was observed to place the accumulator
-            // reads only ~4 wait states behind it when a uniform branch separated them (stale s[14], s[15]): pin an
-            // explicit 20-state gap that depends on the accumulator.
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(s));
+#pragma unroll
+            for (int ks = 1; ks < NKS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (kh * 32 + r32) * KSTR + (2 * ks + hi) * 16);
+                if (ks + 1 < NKS) asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(kf), "v"(qf[ks]));
+                else asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s) : "v"(kf), "v"(qf[ks]));
+            }
             // lane holds S^T[key0 + (r&3) + 8*(r>>2) + 4*hi][q0 + r32]
             float tmax = -1e30f;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool v = (tmask >> ((r & 3) + 8 * (r >> 2))) & 1u;
-                s[r] = v ? s[r] * c : -1e30f;
-                tmax = fmaxf(tmax, s[r]);
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax *= c;   // c > 0: max(c s) == c max(s), rounding included
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool v = (tmask >> ((r & 3) + 8 * (r >> 2))) & 1u;
+                    s[r] = v ? s[r] * c : -1e30f;
+                    tmax = fmaxf(tmax, s[r]);
+                }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             // deferred rescale: keep the old reference max while the tile max exceeds it by < 2^-? ... THR (log2 units);
@@ -408,11 +433,26 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             }
             float psum = 0.f;
             float p[16];
+            if (full) {
+                const f32x2 c2 = {c, c}, nm2 = {-m, -m};
+                f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool v = (tmask >> ((r & 3) + 8 * (r >> 2))) & 1u;
-                p[r] = v ? __builtin_amdgcn_exp2f(s[r] - m) : 0.f;
-                psum += p[r];
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 x = {s[r], s[r + 1]};
+                    x = __builtin_elementwise_fma(x, c2, nm2);
+                    p[r] = __builtin_amdgcn_exp2f(x[0]);
+                    p[r + 1] = __builtin_amdgcn_exp2f(x[1]);
+                    const f32x2 pp = {p[r], p[r + 1]};
+                    ps2 += pp;
+                }
+                psum = ps2[0] + ps2[1];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool v = (tmask >> ((r & 3) + 8 * (r >> 2))) & 1u;
+                    p[r] = v ? __builtin_amdgcn_exp2f(s[r] - m) : 0.f;
+                    psum += p[r];
+                }
             }
             psum += __shfl_xor(psum, 32, 64);
             lsum += psum;
@@ -428,14 +468,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     union { bf16x8 v; uint2 h2[2]; } vf;
                     vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
                     vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
-                    o[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[tt], 0, 0, 0);
+                    // register classes by constraint: O^T (and S^T above) in VGPRs -- the rescale and the softmax are VALU code, which cannot
+                    // address AGPRs; with the builtin hipcc parked O^T in AGPRs and copied all 16 NDT values out and back every tile -- while
+                    // the loop-invariant Q fragments ("a") and the staging registers take the AGPR half
+                    asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(o[tt]) : "v"(vf.v), "v"(pf.v));
                 }
             }
         }
-        // keep the O^T accumulators resident in AGPRs across iterations (otherwise hipcc round-trips all 16*NDT of them
-        // through VGPRs every tile because the conditional rescale is VALU work)
-#pragma unroll
-        for (int tt = 0; tt < NDT; ++tt) asm volatile("" : "+a"(o[tt]));
         if (t + 1 < ntiles) WRITE_TILE((t + 1) & 1);
         __syncthreads();
     }
@@ -443,7 +482,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
     // ---- merge the key sub-blocks: (m, l, O) of the waves kh >= 1 -> LDS -> kh = 0 (log-sum-exp merge) ----
 #pragma unroll
-    for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(o[tt]));
+    for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(o[tt]));
     constexpr int XO = 2 * NDT * 16 * 64;                              // floats per partner: [qs][NDT][16][64]
     float* xo = reinterpret_cast<float*>(smem);                        // [NKH-1][qs][NDT][16][64]
     float* xml = reinterpret_cast<float*>(smem) + (NKH - 1) * XO;      // [NKH-1][qs][2][32]
