@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
-GEGLU_VARIANT = 8000 + 13 * 4 + 2  # ezdit_test_gemm: tile config 13 (128x288, 12 waves, ring 3: what the step uses at M <= 2048), GEGLU epilogue staged through LDS (8000: the shipped epi_lds form)
+GEGLU_VARIANT = 60 * 4 + 2  # ezdit_test_gemm: tile config 60 (ping-pong kernel k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1>: what the step launches for mlp.net.0.proj), GEGLU epilogue
 
 
 def load_yaml(path):
@@ -77,9 +77,58 @@ def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     fl = 2.0 * M * D * 2 * inner
-    return dict(name='k_gemm<128,288,4x3 waves,GEGLU> (mlp.net.0.proj + GEGLU epilogue)', launches_per_step=cfg['depth'] + 1,
+    return dict(name='k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1> (mlp.net.0.proj + GEGLU epilogue)', launches_per_step=cfg['depth'] + 1,
                 flops_per_launch=fl, avg_us=us, tflops=fl / us / 1e6, frac=fl / us / 1e6 / PEAK_BF16_TFLOPS,
                 note='back-to-back launches, includes launch gaps')
+
+
+def shard4_measure(unet, params, cfg, dev, n_ddim, use_graph, steps=100, warmup=50):
+    """BASELINE.json config #4 (32 prompts over 8 GPUs) seen from ONE GPU: 4 prompts = 8 denoiser rows per launch, same sampler, same
+    kernels, same clock discipline as the headline loop.  Reported as an extra key of the default line; never the headline `value`."""
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    P, L, Lc = 4, 10 * params['autoencoder']['latent_sr'], params['text_encoder']['max_length']
+    g = torch.Generator().manual_seed(4711)
+    text = torch.randn(P, Lc, cfg['context_dim'], generator=g)
+    uncond = torch.randn(1, Lc, cfg['context_dim'], generator=g).repeat(P, 1, 1)
+    text_mask = torch.zeros(P, Lc, dtype=torch.bool)
+    for i in range(P):
+        text_mask[i, :4 + (9 * i) % 37] = True
+    uncond_mask = torch.zeros(P, Lc, dtype=torch.bool)
+    uncond_mask[:, :1] = True
+    init = torch.randn(P, cfg['out_chans'], L, generator=g)
+    noise = torch.randn(n_ddim, P, cfg['out_chans'], L, generator=g)
+    smp = LatentSampler(unet, DDIMScheduler(**params['diff']))
+    smp.prepare(text, text_mask, uncond, uncond_mask, init, noise, 5.0, 0.75, n_ddim, 1.0)
+    init_dev = init.to(dev)
+
+    def run_steps(k):
+        done = 0
+        while done < k:
+            n = min(n_ddim, k - done)
+            with torch.cuda.stream(smp.stream):
+                smp.latents.copy_(init_dev, non_blocking=True)
+                unet.lib.ezdit_set_step(unet._h, 0, C.c_void_p(smp.stream.cuda_stream))
+            smp.run(n, use_graph=use_graph)
+            done += n
+
+    run_steps(warmup)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(smp.stream)
+    run_steps(steps)
+    e1.record(smp.stream)
+    lat = smp.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(lat).all(), 'non-finite latents'
+    fl = flops_per_step(cfg, 2 * P, L, Lc)
+    ach = fl * (steps / (e0.elapsed_time(e1) * 1e-3)) / 1e12
+    return {'workload': 'same sampler, 4 prompts/GPU = 8 denoiser rows (the per-GPU shard of BASELINE config #4: 32 prompts over 8 GPUs)',
+            'prompts_per_gpu': P, 'steps': steps, 'warmup': warmup, 'ms_per_step': dt * 1e3 / steps, 'sample_steps_per_s': steps / dt * P,
+            'flops_per_step': fl, 'achieved_tflops': ach, 'roofline_frac': ach / PEAK_BF16_TFLOPS,
+            'kernel_launches_per_step': unet.last_launch_count}
 
 
 def relaunch_command(n_gpus, argv, port=None):
@@ -189,7 +238,7 @@ def cpu_baseline(size, budget_s=20.0, timeout_s=240):
 
 
 def measured_traffic():
-    """HBM-side bytes per step from profiles/*_pmc_step.json (scripts/pmc_step.sh), only if it was measured on THIS tree's kernels."""
+    """L2<->fabric bytes per step from profiles/*_pmc_step.json (scripts/pmc_step.sh), only if it was measured on THIS tree's kernels."""
     from ezaudio_amd.build import source_hash
     best = None
     pdir = os.path.join(ROOT, 'profiles')
@@ -222,6 +271,9 @@ def main():
                                                            '(test mode: latents are gathered through host memory)')
     ap.add_argument('--shared-device', action='store_true',
                     help='test mode for 1-GPU boxes: every rank uses cuda:0 (needs --dist-backend gloo; RCCL refuses duplicate devices)')
+    ap.add_argument('--no-shard4', action='store_true', help="skip the extra 4-prompts/GPU measurement (BASELINE config #4's per-GPU shard) of the default line")
+    ap.add_argument('--dump-latents', default='', help='rank 0 saves the gathered final latents [prompts x world, C, L] here (torch.save): placement tests')
+    ap.add_argument('--as-rank', type=int, default=-1, help='single process: seed the synthetic inputs as rank R of a multi-rank job would (placement tests)')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--budget', type=float, default=20.0, help=argparse.SUPPRESS)
@@ -276,12 +328,13 @@ def main():
         assert unet.lib.ezdit_set_option(unet._h, k.encode(), int(v)) == 0, kv
 
     # synthetic inputs, generated on CPU with seeded generators (identical on every box)
-    g = torch.Generator().manual_seed(11 + rank)
+    irank = a.as_rank if (a.as_rank >= 0 and world == 1) else rank
+    g = torch.Generator().manual_seed(11 + irank)
     text = torch.randn(P, Lc, cfg['context_dim'], generator=g)
     uncond = torch.randn(1, Lc, cfg['context_dim'], generator=g).repeat(P, 1, 1)
     text_mask = torch.zeros(P, Lc, dtype=torch.bool)
     for i in range(P):
-        text_mask[i, :4 + (9 * (rank * P + i)) % 37] = True      # 4..40 valid tokens
+        text_mask[i, :4 + (9 * (irank * P + i)) % 37] = True      # 4..40 valid tokens
     uncond_mask = torch.zeros(P, Lc, dtype=torch.bool)
     uncond_mask[:, :1] = True                                      # "" -> EOS only
     n_ddim = a.ddim_steps
@@ -334,6 +387,10 @@ def main():
         from ezaudio_amd.dist import gather_samples
         all_lat = gather_samples(lat if a.dist_backend == 'nccl' else lat.cpu(), P * world)
         assert all_lat.shape[0] == P * world
+    else:
+        all_lat = lat
+    if a.dump_latents and rank == 0:
+        torch.save(all_lat.detach().float().cpu(), a.dump_latents)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -378,7 +435,7 @@ def main():
             mt = measured_traffic()
             if mt is not None:   # separate rocprofv3 --pmc passes of this same command, on THIS tree's kernels (else: null)
                 res['roofline']['traffic'] = mt[1]['traffic_bytes_per_step']
-                res['roofline']['traffic_unit'] = 'HBM-side bytes per step'
+                res['roofline']['traffic_unit'] = 'L2<->fabric bytes per step (FETCH_SIZE x2 + WRITE_SIZE; largely served by the Infinity Cache, not all of it reaches HBM)'
                 res['roofline']['traffic_source'] = f'profiles/{mt[0]} (src_hash {mt[1]["src_hash"]}; FETCH_SIZE x2 + WRITE_SIZE)'
                 res['roofline']['traffic_over_weights'] = mt[1]['traffic_bytes_per_step'] / float(unet._blob.numel())
                 res['roofline']['mfma_busy_frac_pmc'] = mt[1].get('mfma_busy_frac')
@@ -387,6 +444,11 @@ def main():
                 res['roofline']['dominant_kernel'] = dominant_kernel_probe(unet, cfg, B * L, smp.stream)
             except Exception as e:  # the probe must never cost the headline number
                 res['roofline']['dominant_kernel'] = {'error': repr(e)}
+        if world == 1 and P == 1 and a.size == 'xl' and not a.controlnet and not a.no_shard4 and a.as_rank < 0:
+            try:   # after the headline loop: it re-binds the workspace for 8 rows
+                res['config4_shard'] = shard4_measure(unet, params, cfg, dev, n_ddim, use_graph)
+            except Exception as e:
+                res['config4_shard'] = {'error': repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.size)
         print(json.dumps(res))

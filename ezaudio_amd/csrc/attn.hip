@@ -469,8 +469,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
                     vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
                     // register classes by constraint: O^T (and S^T above) in VGPRs -- the rescale and the softmax are VALU code, which cannot
-                    // address AGPRs; with the builtin hipcc parked O^T in AGPRs and copied all 16 NDT values out and back every tile -- while
-                    // the loop-invariant Q fragments ("a") and the staging registers take the AGPR half
+                    // address AGPRs; with the builtin hipcc parked O^T in AGPRs and copied all 16 NDT values out and back every tile.  The staging
+                    // registers and part of the Q fragments end up in the AGPR half (hipcc's choice under the 128-VGPR cap)
                     asm("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(o[tt]) : "v"(vf.v), "v"(pf.v));
                 }
             }
@@ -480,63 +480,60 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     }
 
     if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
-    // ---- merge the key sub-blocks: (m, l, O) of the waves kh >= 1 -> LDS -> kh = 0 (log-sum-exp merge) ----
+    // ---- merge the key sub-blocks (log-sum-exp) and store, spread over ALL waves ----
+    // Every wave parks its partial (m, l, O^T) in LDS; after one barrier the (query sub-block, 8-column group) items of the tile are dealt
+    // round-robin to the waves, so each wave sums NKH partials for 2-3 items and issues 2-3 eight-byte stores per lane.  (Before: the
+    // waves kh >= 1 parked, the two kh = 0 waves merged NKH - 1 partners one after the other -- 3 x 48 LDS reads + FMAs per lane -- and
+    // issued 12 stores per lane while six waves had already left; merge + store were 4.7K of the 19.4K cycles of a launch.)
 #pragma unroll
     for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(o[tt]));
-    constexpr int XO = 2 * NDT * 16 * 64;                              // floats per partner: [qs][NDT][16][64]
-    float* xo = reinterpret_cast<float*>(smem);                        // [NKH-1][qs][NDT][16][64]
-    float* xml = reinterpret_cast<float*>(smem) + (NKH - 1) * XO;      // [NKH-1][qs][2][32]
-    static_assert(2 * BUF >= (NKH - 1) * (XO + 2 * 2 * 32) * 4, "exchange area must fit the staging buffers");
-    if (kh >= 1) {
-        float* xo_w = xo + (kh - 1) * XO;
-        float* xml_w = xml + (kh - 1) * (2 * 2 * 32);
+    constexpr int NG = DH / 8;                                        // column groups: G <-> d = 8 G + 4 hi + {0..3} = (tt = G / 4, g = G % 4)
+    constexpr int NW = 2 * NKH;
+    float4* xo = reinterpret_cast<float4*>(smem);                      // [NKH][qs][NG][64 lanes]
+    float* xml = reinterpret_cast<float*>(smem + NKH * 2 * NG * 64 * 16);   // [NKH][qs][2][32]
+    static_assert(SMEM >= NKH * 2 * NG * 64 * 16 + NKH * 2 * 2 * 32 * 4, "exchange area must fit the staging buffers");
 #pragma unroll
-        for (int tt = 0; tt < NDT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xo_w[((qs * NDT + tt) * 16 + r) * 64 + lane] = o[tt][r];
-        if (hi == 0) {
-            xml_w[(qs * 2 + 0) * 32 + r32] = m;
-            xml_w[(qs * 2 + 1) * 32 + r32] = lsum;
-        }
+    for (int G = 0; G < NG; ++G)
+        xo[((kh * 2 + qs) * NG + G) * 64 + lane] = make_float4(o[G / 4][4 * (G % 4)], o[G / 4][4 * (G % 4) + 1], o[G / 4][4 * (G % 4) + 2], o[G / 4][4 * (G % 4) + 3]);
+    if (hi == 0) {
+        xml[((kh * 2 + qs) * 2 + 0) * 32 + r32] = m;
+        xml[((kh * 2 + qs) * 2 + 1) * 32 + r32] = lsum;
     }
     __syncthreads();
-    if (kh >= 1) return;
-#pragma unroll
-    for (int j = 0; j < NKH - 1; ++j) {
-        const float* xo_r = xo + j * XO;
-        const float* xml_r = xml + j * (2 * 2 * 32);
-        const float m2 = xml_r[(qs * 2 + 0) * 32 + r32], l2 = xml_r[(qs * 2 + 1) * 32 + r32];
-        const float mm = fmaxf(m, m2);
-        const float a1 = __builtin_amdgcn_exp2f(m - mm), a2 = __builtin_amdgcn_exp2f(m2 - mm);
-        lsum = lsum * a1 + l2 * a2;
-        m = mm;
-#pragma unroll
-        for (int tt = 0; tt < NDT; ++tt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[tt][r] = o[tt][r] * a1 + xo_r[((qs * NDT + tt) * 16 + r) * 64 + lane] * a2;
-    }
-    const float inv = 1.f / lsum;
     if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
-
-    // lane holds O^T[d = 32t + (r&3) + 8*(r>>2) + 4*hi][q = q0 + r32]
+    // weights of the NKH partials for query row q0 + r32 (the items of a wave all belong to its own query sub-block: NW is even)
+    float wgt[NKH];
+    {
+        float mk[NKH], mm = -1e30f;
+#pragma unroll
+        for (int k = 0; k < NKH; ++k) { mk[k] = xml[((k * 2 + qs) * 2 + 0) * 32 + r32]; mm = fmaxf(mm, mk[k]); }
+        float l = 0.f;
+#pragma unroll
+        for (int k = 0; k < NKH; ++k) { wgt[k] = __builtin_amdgcn_exp2f(mk[k] - mm); l = fmaf(xml[((k * 2 + qs) * 2 + 1) * 32 + r32], wgt[k], l); }
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int k = 0; k < NKH; ++k) wgt[k] *= inv;
+    }
     const int qrow = q0 + r32;
-    if (qrow >= a.Lq) return;
-    bf16_t* orow = a.out + ((long)b * a.Lq + qrow) * a.ldo + h * DH;
+    bf16_t* orow = a.out + ((long)b * a.Lq + (qrow < a.Lq ? qrow : a.Lq - 1)) * a.ldo + h * DH + 4 * hi;
 #pragma unroll
-    for (int tt = 0; tt < NDT; ++tt)
+    for (int i = 0; i < (2 * NG + NW - 1) / NW; ++i) {
+        const int G = (wave + i * NW) >> 1;   // item = wave + i NW = 2 G + qs
+        if (G < NG) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 32 * tt + 8 * g + 4 * hi;
-            if (d < DH) {
-                float v4[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = o[tt][4 * g + e] * inv;
+            for (int k = 0; k < NKH; ++k) {
+                const float4 v = xo[((k * 2 + qs) * NG + G) * 64 + lane];
+                acc.x = fmaf(v.x, wgt[k], acc.x); acc.y = fmaf(v.y, wgt[k], acc.y); acc.z = fmaf(v.z, wgt[k], acc.z); acc.w = fmaf(v.w, wgt[k], acc.w);
+            }
+            if (qrow < a.Lq) {
                 uint2 v;
-                v.x = pack_bf2(v4[0], v4[1]);
-                v.y = pack_bf2(v4[2], v4[3]);
-                *reinterpret_cast<uint2*>(orow + d) = v;
+                v.x = pack_bf2(acc.x, acc.y);
+                v.y = pack_bf2(acc.z, acc.w);
+                *reinterpret_cast<uint2*>(orow + 8 * G) = v;
             }
         }
+    }
     if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
 }
 

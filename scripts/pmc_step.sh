@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM-traffic and MFMA-utilisation counters of ONE denoising step, per kernel (runs on the MI355X box from the repo root):
 #     bash scripts/pmc_step.sh [tag] [extra bench.py args]
-# Three separate rocprofv3 --pmc passes of the SAME bench command (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md
+# Six separate rocprofv3 --pmc passes of the SAME bench command (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md
 # "rocprofv3 PMC slots"), eager launches so that every dispatch is attributed to its kernel, then tools/pmc_step_summary.py folds
 # the CSVs into gpurun_out/<tag>_pmc_step.json (copy it to profiles/).  The JSON records the hash of the kernel sources it was
 # measured on; bench.py quotes `roofline.traffic` from it only while that hash still matches the tree.
@@ -13,7 +13,7 @@ STEPS=20
 WARM=5
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-probe --no-graph $*"
+BENCH="python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-probe --no-shard4 --no-graph $*"
 pass() {
   name=$1; shift
   timeout 900 rocprofv3 --kernel-trace --pmc "$@" -d "$OUT" -o "$name" --output-format csv -- $BENCH > "$OUT/$name.log" 2>&1
@@ -22,6 +22,11 @@ pass() {
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE
+# LDS pipe and L2: is the K loop waiting on LDS (bank conflicts, instruction issue) or on memory?  
+pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_VALU
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
+# how much of the L2<->fabric traffic reaches DRAM (the rest is served by the Infinity Cache)
+pass dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_BUBBLE_sum
 python "$ROOT/tools/pmc_step_summary.py" "$OUT" $((STEPS + WARM)) --tag "$TAG" --args "$*" > "$ROOT/gpurun_out/${TAG}_pmc_step.json"
 python - <<PY
 import json

@@ -173,43 +173,50 @@ def test_inference_shards_prompts_and_gathers_audio_gloo_world2(n):
         assert torch.equal(singles[0], ref[0]) and not torch.equal(singles[1], ref[1])
 
 
-@pytest.mark.gpu
-def test_bench_spawns_two_rccl_ranks_when_two_gpus_are_present():
-    """`python bench.py --gpus 2` -- the form the driver uses -- must start its own ranks (torch.distributed.run on 127.0.0.1),
-    shard the prompts, all-gather over RCCL and print ONE JSON line.  Needs >= 2 GPUs (skipped on the 1-GPU test boxes)."""
+def _bench_dump(root, env, extra, path):
+    """Run bench.py with `extra` arguments, saving the gathered final latents to `path`; returns (json line, latents)."""
     import json
     import subprocess
     import sys
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '20', '--warmup', '10', '--no-cpu-baseline', '--no-probe',
+                        '--dump-latents', path] + extra, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), torch.load(path)
+
+
+def _assert_placement_independent(root, env, multi, size_args, tmp_path):
+    """Sample r of the 2-rank job (rank r's prompt, gathered by the collective) == the same prompt run alone in one process."""
+    assert multi.shape[0] == 2
+    for r in range(2):
+        _, single = _bench_dump(root, env, ['--gpus', '1', '--as-rank', str(r)] + size_args, str(tmp_path / f'single{r}.pt'))
+        assert single.shape[0] == 1 and torch.equal(single[0], multi[r]), f'rank {r}: gathered latents differ from the single-process run'
+
+
+@pytest.mark.gpu
+def test_bench_spawns_two_rccl_ranks_when_two_gpus_are_present(tmp_path):
+    """`python bench.py --gpus 2` -- the form the driver uses -- must start its own ranks (torch.distributed.run on 127.0.0.1),
+    shard the prompts, all-gather over RCCL and print ONE JSON line.  Needs >= 2 GPUs (skipped on the 1-GPU test boxes)."""
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 GPUs')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '10',
-                        '--no-cpu-baseline', '--no-probe'], capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1
-    res = json.loads(lines[0])
+    res, multi = _bench_dump(root, env, ['--gpus', '2'], str(tmp_path / 'multi.pt'))
     assert res['n_gpus'] == 2 and res['distributed']['world_size'] == 2 and res['distributed']['backend'] == 'nccl'
     assert res['scaling'] == 'weak' and res['value'] > 0
+    # placement independence over RCCL: what rank r computed on its own GPU and the all-gather delivered is bitwise what one process computes
+    _assert_placement_independent(root, env, multi, [], tmp_path)
 
 
 @pytest.mark.gpu
-def test_bench_multi_rank_path_on_one_gpu_over_gloo():
+def test_bench_multi_rank_path_on_one_gpu_over_gloo(tmp_path):
     """The whole N > 1 path of bench.py -- self re-launch under torch.distributed.run on 127.0.0.1, prompt sharding, the timed loop on
     every rank, the final gather, max-over-ranks timing, ONE JSON line from rank 0 -- exercised on a 1-GPU box: both ranks share
     cuda:0 and the collectives go through gloo (RCCL refuses two ranks on one device; the nccl form is the test above)."""
-    import json
-    import subprocess
-    import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--size', 'l', '--steps', '20', '--warmup', '10',
-                        '--no-cpu-baseline', '--no-probe', '--dist-backend', 'gloo', '--shared-device'],
-                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-    assert len(lines) == 1, r.stdout[-2000:]
-    res = json.loads(lines[0])
+    res, multi = _bench_dump(root, env, ['--gpus', '2', '--size', 'l', '--dist-backend', 'gloo', '--shared-device'], str(tmp_path / 'multi.pt'))
     assert res['n_gpus'] == 2 and res['distributed']['world_size'] == 2 and res['distributed']['backend'] == 'gloo'
     assert res['scaling'] == 'weak' and res['value'] > 0 and res['config']['prompts_per_gpu'] == 1
+    _assert_placement_independent(root, env, multi, ['--size', 'l'], tmp_path)

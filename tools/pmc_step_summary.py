@@ -63,6 +63,9 @@ def main():
     fetch, fcalls, ff = read_pass(a.dir, 'fetch')
     write, _, wf = read_pass(a.dir, 'write')
     sq, scalls, sf = read_pass(a.dir, 'sq')
+    lds, _, lf = read_pass(a.dir, 'lds')     # optional passes: absent in summaries made before round 3
+    tcc, _, tf = read_pass(a.dir, 'tcc')
+    dram, _, df = read_pass(a.dir, 'dram')
     kernels = sorted(set(fetch) | set(write) | set(sq))
     rows, tot_f, tot_w, tot_busy, tot_gui = [], 0.0, 0.0, 0.0, 0.0
     for k in kernels:
@@ -81,6 +84,25 @@ def main():
                'wave_cycles': s.get('SQ_WAVE_CYCLES', 0.0), 'wait_any': s.get('SQ_WAIT_ANY', 0.0),
                'wait_inst_any': s.get('SQ_WAIT_INST_ANY', 0.0), 'active_inst_any': s.get('SQ_ACTIVE_INST_ANY', 0.0),
                'gui_active_cycles': gui}
+        if k in lds:   # LDS pipe: conflict cycles per active LDS cycle, LDS instructions, and the share of wave time spent waiting on LDS
+            q = lds[k]
+            row.update({'lds_bank_conflict_cycles': q.get('SQ_LDS_BANK_CONFLICT', 0.0), 'lds_idx_active_cycles': q.get('SQ_LDS_IDX_ACTIVE', 0.0),
+                        'lds_bank_conflict_frac': q.get('SQ_LDS_BANK_CONFLICT', 0.0) / q['SQ_LDS_IDX_ACTIVE'] if q.get('SQ_LDS_IDX_ACTIVE') else 0.0,
+                        'lds_addr_conflict_cycles': q.get('SQ_LDS_ADDR_CONFLICT', 0.0), 'lds_insts': q.get('SQ_INSTS_LDS', 0.0),
+                        'valu_insts': q.get('SQ_INSTS_VALU', 0.0),
+                        'wait_inst_lds_frac_of_wave_cycles': q.get('SQ_WAIT_INST_LDS', 0.0) / q['SQ_WAVE_CYCLES'] if q.get('SQ_WAVE_CYCLES') else 0.0,
+                        'active_inst_lds_frac_of_wave_cycles': q.get('SQ_ACTIVE_INST_LDS', 0.0) / q['SQ_WAVE_CYCLES'] if q.get('SQ_WAVE_CYCLES') else 0.0})
+        if k in tcc:   # L2 (TCC, summed over the 8 XCDs x 16 channels): hit rate of the requests the CUs sent, and reads forwarded to the fabric
+            q = tcc[k]
+            hm = q.get('TCC_HIT_sum', 0.0) + q.get('TCC_MISS_sum', 0.0)
+            row.update({'tcc_hit': q.get('TCC_HIT_sum', 0.0), 'tcc_miss': q.get('TCC_MISS_sum', 0.0), 'tcc_req': q.get('TCC_REQ_sum', 0.0),
+                        'tcc_hit_rate': q.get('TCC_HIT_sum', 0.0) / hm if hm else 0.0, 'tcc_ea_rdreq': q.get('TCC_EA0_RDREQ_sum', 0.0)})
+        if k in dram:  # requests the L2s sent to the fabric that were routed to DRAM (the others hit the Infinity Cache); request counts, not bytes
+            q = dram[k]
+            row.update({'ea_rdreq_dram': q.get('TCC_EA0_RDREQ_DRAM_sum', 0.0), 'ea_wrreq_dram': q.get('TCC_EA0_WRREQ_DRAM_sum', 0.0),
+                        'ea_wrreq': q.get('TCC_EA0_WRREQ_sum', 0.0), 'tcc_bubble': q.get('TCC_BUBBLE_sum', 0.0)})
+            if k in tcc and tcc[k].get('TCC_EA0_RDREQ_sum'):
+                row['ea_rdreq_dram_frac'] = q.get('TCC_EA0_RDREQ_DRAM_sum', 0.0) / tcc[k]['TCC_EA0_RDREQ_sum']
         rows.append(row)
         if not prep:
             tot_f += fb; tot_w += wb; tot_busy += busy; tot_gui += dur
@@ -91,7 +113,7 @@ def main():
            'mfma_busy_frac': tot_busy / (N_SIMD * tot_gui * PEAK_GHZ) if tot_gui else 0.0,
            'note': 'FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section), WRITE_SIZE as reported; prepare-only kernels excluded; '
                    'eager launches (--no-graph) so each dispatch is attributed; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel ns x 2.4 GHz)',
-           'files': [os.path.basename(f) for f in ff + wf + sf], 'kernels': rows}
+           'files': [os.path.basename(f) for f in ff + wf + sf + lf + tf + df], 'kernels': rows}
     json.dump(out, sys.stdout, indent=1)
 
 
