@@ -58,6 +58,8 @@ struct WsPtrs {  // workspace regions used on the per-step path, resolved once a
     float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
 };
 
+static unsigned long long* g_gemm_ts = nullptr;   // ezdit_debug_gemm_timestamps: device buffer for in-kernel cycle stamps (gemm_pp.h, attn.hip)
+
 struct ezdit_handle {
     ezdit_config cfg;
     int D, H, dh, nblk, nhalf, I, C, Cin, Cctx, r6;
@@ -149,6 +151,8 @@ struct ezdit_handle {
     int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
     int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
+    int opt_stamp_launch = -1;   // in-situ cycle stamps: the launch with this index of a forward writes them (ezdit_debug_gemm_timestamps buffer; eager launches only)
+    int opt_trace_launches = 0;  // print 'index name' of every launch of a forward to stderr
     int steps_done = 0;  // host mirror of the device step counter (ezdit_sampler_run bounds check)
     int device = -1;     // device that was current at ezdit_create
     std::vector<BlkW> blk;
@@ -406,7 +410,10 @@ struct Ctx {
     hipError_t err = hipSuccess;
     int rc = EZDIT_OK;
     const char* where = nullptr;
+    // cycle-stamp buffer for the launch about to be issued (nullptr unless the 'stamp_launch' option selects it)
+    unsigned long long* stamps() const { return (g_gemm_ts && h->launches == h->opt_stamp_launch) ? g_gemm_ts : nullptr; }
     void launched(const char* what, int launch_rc = 0) {
+        if (h->opt_trace_launches) fprintf(stderr, "launch %d %s\n", h->launches, what);
         h->launches++;
         if (launch_rc != 0 && rc == EZDIT_OK) { rc = launch_rc; where = what; }
         const hipError_t e = hipGetLastError();
@@ -458,7 +465,8 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
         g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
         c.fuse = nullptr;
     }
-    c.launched("k_gemm", launch_gemm(g, c.st));
+    g.ts = c.stamps();
+    c.launched(epi == EPI_GEGLU ? "k_gemm (GEGLU)" : epi == EPI_QKV ? "k_gemm (QKV)" : epi == EPI_PARTIAL ? "k_gemm (split-K slabs)" : "k_gemm", launch_gemm(g, c.st));
 }
 
 // Tile / split-K heuristics: measured in situ on MI355X with tools/ab_sweep.py (one knob flipped on the live sampler) and
@@ -903,6 +911,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
         g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat;
+        g.ts = c.stamps();
         c.launched("k_gemm_pp (residual)", launch_gemm(g, st));
         u_is_z = true;
     };
@@ -977,6 +986,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
+        at.ts = c.stamps();
         c.launched("k_attn (self)", launch_attention(at, st));
         STOPCHK();
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
@@ -1028,6 +1038,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         at.kmask = p.kmask;
         at.Lk = h->Lc; at.Lkp = h->Lcp;
         STOPCHK();
+        at.ts = c.stamps();
         c.launched("k_attn (cross)", launch_attention(at, st));
         STOPCHK();
         if (fuse_res) {
@@ -1309,7 +1320,6 @@ int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream
 }
 
 // ------------------------------------------------------------------------------------------------------
-static unsigned long long* g_gemm_ts = nullptr;
 int ezdit_debug_gemm_timestamps(void* dev_buf) { g_gemm_ts = static_cast<unsigned long long*>(dev_buf); return EZDIT_OK; }
 
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
@@ -1445,6 +1455,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "tile_p36")) h->opt_tile_p36 = value;
     else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;
     else if (!strcmp(name, "tile_qkv")) h->opt_tile_qkv = value;
+    else if (!strcmp(name, "stamp_launch")) h->opt_stamp_launch = value;
+    else if (!strcmp(name, "trace_launches")) h->opt_trace_launches = value;
     else return fail(EZDIT_E_INVALID, "unknown option %s", name);
     drop_graph(h);
     for (ezdit_handle* u : h->cn_users) drop_graph(u);   // a backbone's captured step embeds the attached ControlNet's kernels and arguments

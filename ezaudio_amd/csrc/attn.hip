@@ -25,6 +25,19 @@
 
 namespace {
 
+// reductions over the lane pair (lane, lane ^ 32) by one VALU v_permlane32_swap (hipcc lowers __shfl_xor(x, 32) to ds_bpermute_b32: an
+// LDS-pipe round trip of ~100+ cycles in the middle of the softmax dependency chain, twice per tile).  After swapping x with itself,
+// r[0] keeps x in lanes 0..31 and holds x[lane - 32] in lanes 32..63; r[1] holds x[lane + 32] in lanes 0..31 and keeps x in lanes 32..63:
+// in every lane {r[0], r[1]} = {own value, partner's value}.
+__device__ __forceinline__ float pair_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int DH>
 struct HeadGeom;
 template <>
@@ -367,6 +380,10 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr float RESCALE_THR = 4.0f;  // log2 units: P <= 16
     const float c = 1.4426950408889634f * rsqrtf((float)DH);  // log2(e) / sqrt(dh)
 
+    // two waves per SIMD: the later-dispatched half loses VALU arbitration to the older half (priority, then age); one static priority
+    // step for it evens the pair out (MI355X_MICROARCH.md "Two waves per SIMD").  The guard must be provably wave-uniform: s_setprio
+    // ignores EXEC.
+    if (NKH == 4 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     const int ntiles = (a.Lk + TK - 1) / TK;
     LOAD_TILE(0);
     WRITE_TILE(0);
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     tmax = fmaxf(tmax, s[r]);
                 }
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = pair_max(tmax);
             // deferred rescale: keep the old reference max while the tile max exceeds it by < 2^-? ... THR (log2 units);
             // P is then bounded by 2^THR instead of 1, which fp32 sums / bf16 P absorb; the accumulators are touched
             // only when some row really needs a new reference (wave-uniform branch).
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     psum += p[r];
                 }
             }
-            psum += __shfl_xor(psum, 32, 64);
+            psum = pair_sum(psum);
             lsum += psum;
 #pragma unroll
             for (int step = 0; step < 2; ++step) {
