@@ -124,7 +124,9 @@ struct ezdit_handle {
     int opt_zfuse = 0;
     int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
-    int opt_wt = 0;                                                                       // write-through (sc1) output stores
+    int opt_wt = 2;   // write-through (sc1) output stores: 0 off, 1 on, 2 = on while B L <= 2048.  The end-of-kernel write-back then has nothing left to flush: -3.5 % step time
+                      // for one prompt (4.19 -> 4.04 ms), +1.4 % for four (the step is throughput-bound there and the stores compete with the loads)
+    int wt() const { return opt_wt == 2 ? (B * L <= 2048) : opt_wt; }
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
@@ -449,7 +451,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.tile = tile;
     g.xcd_map = h->opt_xcd_map;
     g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
-    g.wt = h->opt_wt;
+    g.wt = h->wt();
     g.debug = h->opt_gemm_debug;
     g.epi_lds = h->opt_epi_lds;
     g.rows_per_b = 1;
@@ -872,7 +874,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         r.skip = skip; r.cn = cnp;
         r.u = lg ? (skip ? p.ucat : u) : nullptr; r.ld_u = ld_u;
         r.M = M; r.D = D; r.L = h->L;
-        r.cur_step = cur; r.row_slot = row_slot; r.wt = h->opt_wt;
+        r.cur_step = cur; r.row_slot = row_slot; r.wt = h->wt();
         r.variant = h->opt_row_variant;
         r.affine = h->opt_row_affine && M <= 1024;
         return r;
@@ -907,7 +909,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         memset(&g, 0, sizeof g);
         g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
         g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = 63;
-        g.xcd_map = h->opt_xcd_map; g.wt = h->opt_wt; g.debug = h->opt_gemm_debug;
+        g.xcd_map = h->opt_xcd_map; g.wt = h->wt(); g.debug = h->opt_gemm_debug;
         g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
         g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat;
@@ -982,7 +984,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         AttnArgs at;
         memset(&at, 0, sizeof at);
         at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
-        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd;
+        at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd; at.wt = h->wt();
         at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
@@ -1330,7 +1332,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->opt_wt : 0; memset(&g.hn, 0, sizeof g.hn);
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->wt() : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
     g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: bits 0-1 k_gemm2 experiment bits (GemmArgs.debug), bit 3 LDS-staged bf16 epilogue, bit 4 bf16 slabs, bits 8.. k_gemm_pp ablation variant
     if (g.debug & 8) g.epi_lds = 1;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     const int q0 = qt * 64 + qs * 32;
     const long bh = (long)b * a.H + h;
     unsigned long long* ts = (a.ts && tid < 64) ? a.ts + 8 * (long)blockIdx.x : nullptr;
-    if (ts && lane == 0) ts[0] = __builtin_readcyclecounter();
+    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }   // [6], [7]: 100 MHz device-wide clock
 
     const bf16_t* Q = a.q + (bh * a.Lqp + q0 + r32) * DQK + 8 * hi;
     const char* Kg = reinterpret_cast<const char*>(a.k + bh * a.Lkp * DQK);
@@ -547,11 +547,11 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 uint2 v;
                 v.x = pack_bf2(acc.x, acc.y);
                 v.y = pack_bf2(acc.z, acc.w);
-                *reinterpret_cast<uint2*>(orow + 8 * G) = v;
+                if (a.wt) st8_wt(orow + 8 * G, v); else *reinterpret_cast<uint2*>(orow + 8 * G) = v;
             }
         }
     }
-    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
+    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 #undef LOAD_TILE

@@ -25,14 +25,19 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 
 // write-through stores (sc1): the line does not stay dirty in this XCD's L2, so the end-of-kernel write-back that the next
 // kernel's launch waits for has nothing left to flush (every kernel here is consumed by all XCDs of the next one)
+// (inline asm: hipcc pads nothing behind the statement, so the wait state a store of more than 8 bytes needs before a following instruction
+// may overwrite its data registers is inside the string)
 __device__ __forceinline__ void st16_wt(void* p, float4 v) {
     f32x4 x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 __device__ __forceinline__ void st8_wt(void* p, uint2 v) {
     u32x2_t x = {v.x, v.y};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void st4_wt(void* p, uint32_t v) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -187,6 +192,7 @@ struct AttnArgs {
     // run on ONE XCD (hardware deals workgroup i to XCD i % 8), so each pair's K / V^T is fetched into exactly one L2.
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
+    int wt;                     // output stores are write-through (sc1)
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
     // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)
     // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)

@@ -297,7 +297,6 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
     }
     if (ts && lane == 0) ts[5] = __builtin_readcyclecounter();
     __syncthreads();
-    if (ts && lane == 0) ts[6] = __builtin_readcyclecounter();
     bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (EPI == EPI_PARTIAL ? (long)z * a.slab_stride : 0);
     copy_out_bf16<NT>(tile, PITCH, BM, OC, out, a.ldo, row0, EPI == EPI_GEGLU ? col0 / 2 : col0, a.M, EPI == EPI_GEGLU ? a.N / 2 : a.N, a.wt, tid);
 }
@@ -504,8 +503,10 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
             const int m = row0 + r;
             if (m < a.M) {
                 const int b = m / hn.L, l = m % hn.L;
-                *reinterpret_cast<uint4*>(dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + c8 * 8) =
-                    *reinterpret_cast<const uint4*>(qk_st + (r * NH + hh) * DH + c8 * 8);
+                bf16_t* dst = dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + c8 * 8;
+                const uint4 v = *reinterpret_cast<const uint4*>(qk_st + (r * NH + hh) * DH + c8 * 8);
+                if (a.wt) st16_wt(dst, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+                else *reinterpret_cast<uint4*>(dst) = v;
             }
         }
     } else {
@@ -518,8 +519,9 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
                 if (m < a.M) {
                     const int b = m / hn.L, l = m % hn.L;
                     const int hh = cc / DH, d = cc % DH;
-                    *reinterpret_cast<uint32_t*>(hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l) =
-                        pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
+                    bf16_t* dst = hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l;
+                    const uint32_t v = pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
+                    if (a.wt) st4_wt(dst, v); else *reinterpret_cast<uint32_t*>(dst) = v;
                 }
             }
         } else {
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     float4 rb4[RFM][RFN], rr4[RFM][RFN], rg4[RFM][RFN], rz4[RFM][RFN];
     if constexpr (EPI == EPI_RESID) pp_resid_operands<RFM, RFN, TM / 2, TN, ZM>(a, row0, col0, wm * 2 + grp, wn, lane, slot0, rb4, rr4, rg4, rz4);
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
-    if (ts && lane == 0) ts[0] = __builtin_readcyclecounter();
+    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }   // [6], [7]: the 100 MHz device-wide clock (cycle counters are not comparable between workgroups)
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -896,7 +898,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
                     pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, zrow, slot0, ts);
-                    if (ts && lane == 0) ts[3] = __builtin_readcyclecounter();
+                    if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
                     return;
                 }
             }
@@ -908,14 +910,14 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
                     pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, zrow, slot0, ts);
-                    if (ts && lane == 0) ts[3] = __builtin_readcyclecounter();
+                    if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
                     return;
                 }
             }
         }
         if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) pp_store_direct<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
     }
-    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); }
+    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 }  // namespace

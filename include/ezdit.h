@@ -218,7 +218,7 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  * are the measured best on MI355X; none changes results beyond fp rounding.  Unknown names return EZDIT_E_INVALID.
  *   GEMM tile ids (csrc/gemm.hip table): tile_partial, tile_f32, tile_qkv, tile_p18 / tile_p36 / tile_p72 (per K depth),
  *     geglu_tile, and for > 2048 rows tile_partial_big, tile_f32_big, geglu_big; split-K: split18 / split36 / split72, split_big
- *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1 (write-through stores)
+ *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1/2 (write-through (sc1) output stores; 2 = default: on while B L <= 2048)
  *   fuse_qkv 0/1 (head-norm + RoPE + V^T in the QKV GEMM epilogue), qkv_waves9 0/1, fuse_q2 0/1/2 (cross-attention computes its
  *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
  *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
@@ -236,6 +236,8 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks), qkv_affine 0/1 (fused QKV GEMM: every tile
  *     on the XCD whose attention workgroups read it), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
  *   gemm_debug (k_gemm2 experiment bits)
+ *   stamp_launch i / trace_launches 0/1 (diagnostics, eager launches only: launch i of a forward writes its in-kernel cycle stamps to the buffer
+ *     registered with ezdit_debug_gemm_timestamps; every launch of a forward is named on stderr -- tools/diag_stamps.py)
  *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 

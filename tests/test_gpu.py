@@ -490,11 +490,11 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=0)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=0, wt=2)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
-                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (0, 1))])
+                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (0, 1)), ('wt', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands

@@ -87,14 +87,15 @@ def main(size='xl'):
             torch.cuda.synchronize()
             m.lib.ezdit_debug_gemm_timestamps(None)
             raw = ts.cpu().numpy().reshape(NWG, 8)
-            base = raw[raw[:, 0] > 0, 0].min() if (raw[:, 0] > 0).any() else 0
-            a = np.where(raw > 0, raw - base + 1, 0).astype(np.float64)
-            ok = (a[:, 0] > 0) & (a[:, 3] > 0)
-            a = a[ok]
-            if not len(a):
+            okr = (raw[:, 0] > 0) & (raw[:, 3] > 0)
+            if not okr.any():
                 break
-            span = a[:, 3].max() - a[:, 0].min()
-            skew = a[:, 0].max() - a[:, 0].min()
+            # cycle counters are per workgroup-local clock domain; [6] / [7] hold the 100 MHz device-wide clock at the start and the end
+            rt0, rt1 = raw[okr, 6], raw[okr, 7]
+            span = float(rt1.max() - rt0.min()) * 10.0      # ns: first workgroup start -> last workgroup end
+            skew = float(rt0.max() - rt0.min()) * 10.0      # ns: first -> last workgroup start
+            mine = float((rt1 - rt0).mean()) * 10.0         # ns: mean lifetime of a workgroup
+            a = raw[okr].astype(np.float64) - float(raw[okr, 0].min())
             if names[i].startswith('k_attn'):
                 row = [a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 4] - a[:, 2], a[:, 3] - a[:, 4]]
                 lab = ['first tile staged', 'tile loop', 'partials parked', 'merge + stores']
@@ -108,7 +109,7 @@ def main(size='xl'):
                 e = np.sort(row[2])
                 print(f'    epilogue over workgroups: min {e[0]:.0f} p25 {e[len(e) // 4]:.0f} median {e[len(e) // 2]:.0f} p75 {e[3 * len(e) // 4]:.0f} max {e[-1]:.0f}; '
                       f'prologue min {row[0].min():.0f} max {row[0].max():.0f}; loop min {row[1].min():.0f} max {row[1].max():.0f}')
-            v = np.array([r.mean() for r in row] + [span, skew, len(a)])
+            v = np.array([r.mean() for r in row] + [mine, span, skew, len(a)])
             nlab = len(lab)
             acc = v if acc is None else acc + v
         assert m.lib.ezdit_set_option(m._h, b'stamp_launch', -1) == 0
@@ -117,7 +118,7 @@ def main(size='xl'):
             continue
         acc /= reps
         parts = ' | '.join(f'{l} {x:.0f}' for l, x in zip(lab, acc[:nlab]))
-        print(f'launch {i:3d} {names[i]:24s}: {parts} | first start -> last end {acc[-3]:.0f} | start skew {acc[-2]:.0f}  ({acc[-1]:.0f} WGs)', flush=True)
+        print(f'launch {i:3d} {names[i]:24s}: {parts} | 100 MHz clock: workgroup lifetime {acc[-4] / 1e3:.2f} us, first start -> last end {acc[-3] / 1e3:.2f} us, start skew {acc[-2] / 1e3:.2f} us  ({acc[-1]:.0f} WGs)', flush=True)
     print('note: stamps are s_memtime ticks (the shader clock counter): compare with the warm numbers of gemm_bench / attn_bench, same unit')
 
 

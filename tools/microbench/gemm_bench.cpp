@@ -176,12 +176,12 @@ int main(int argc, char** argv) {
                     ++n;
                     const double p_ = (double)(t[1] - t[0]), l_ = (double)(t[2] - t[1]), e_ = (double)(t[3] - t[2]), s_ = (double)(t[0] - t_first);
                     pro += p_; loop += l_; epi += e_;
-                    if (t[4]) { e1s += (double)(t[4] - t[2]); e2s += (double)(t[5] - t[4]); e3s += (double)(t[6] - t[5]); e4s += (double)(t[3] - t[6]); }
+                    if (t[4]) { e1s += (double)(t[4] - t[2]); e2s += (double)(t[5] - t[4]); e4s += (double)(t[3] - t[5]); }
                     if (p_ > pro_max) pro_max = p_; if (l_ > loop_max) loop_max = l_; if (e_ > epi_max) epi_max = e_; if (s_ > start_max) start_max = s_;
                 }
                 if (n) printf("      stamps (ticks; %d WGs): span %llu | prologue avg %.0f max %.0f | loop avg %.0f max %.0f (%.1f per K tile) | epilogue avg %.0f max %.0f | last start +%.0f\n",
                               n, t_last - t_first, pro / n, pro_max, loop / n, loop_max, loop / n / ((K / 64) / c.splitk), epi / n, epi_max, start_max);
-                if (n && e2s > 0) printf("      epilogue parts: wait+barrier %.0f | math+park %.0f | barrier %.0f | copy-out %.0f\n", e1s / n, e2s / n, e3s / n, e4s / n);
+                if (n && e2s > 0) printf("      epilogue parts: math + wait + barrier %.0f | park %.0f | barrier + copy-out %.0f\n", e1s / n, e2s / n, e4s / n);
             }
             if (bad) printf("      %ld elements out of tolerance\n", bad);
             fflush(stdout);
