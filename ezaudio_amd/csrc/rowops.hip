@@ -299,6 +299,8 @@ __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
     float acc0 = a.b[co], acc1 = acc0;
     const float* wr = a.w + (long)co * C * 3;
     const float* s0 = sy + ll * C;
+    // 4 steps of the weight row in flight at once (same accumulation order: the loop was one L2 round trip per 4 input channels, 32 in a row)
+#pragma unroll 4
     for (int ci = 0; ci < C; ci += 4) {
         const float4 w0 = ld4(wr + ci * 3), w1 = ld4(wr + ci * 3 + 4), w2 = ld4(wr + ci * 3 + 8);
         const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
@@ -431,11 +433,17 @@ __global__ __launch_bounds__(256) void k_cfg_apply(CfgDdimArgs a, const float* p
     const bool cfg = a.guidance_scale > 0.f;
     const bool rescale = cfg && a.guidance_rescale > 0.f;
     float ratio = 1.f;
-    if (rescale) {
+    if (rescale) {   // wave-uniform
+        // the CFG_NB partial sums of this sample: one 16-byte load per thread into LDS, then every thread adds them up in the SAME order as before
+        // (broadcast LDS reads).  The former loop of CFG_NB dependent scalar loads was 10 of the kernel's 12.5 us.
+        __shared__ float4 part_l[CFG_NB];
+        if (threadIdx.x < CFG_NB) part_l[threadIdx.x] = reinterpret_cast<const float4*>(partial)[(long)p * CFG_NB + threadIdx.x];
+        __syncthreads();
         double s1 = 0, q1 = 0, s2 = 0, q2 = 0;
+#pragma unroll 8
         for (int i = 0; i < CFG_NB; ++i) {
-            const float* o = partial + ((long)p * CFG_NB + i) * 4;
-            s1 += o[0]; q1 += o[1]; s2 += o[2]; q2 += o[3];
+            const float4 o = part_l[i];
+            s1 += o.x; q1 += o.y; s2 += o.z; q2 += o.w;
         }
         const double v1 = (q1 - s1 * s1 / n) / (n - 1);  // torch.std default: unbiased
         const double v2 = (q2 - s2 * s2 / n) / (n - 1);
