@@ -66,7 +66,10 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int KPT = (KCH + NT - 1) / NT, VPT = (VCH + NT - 1) / NT;
     static_assert(KPT <= 3 && VPT <= 3, "staging registers");
     // fused projection (NKH == 4): 3-deep ring of [64 rows of x | DN rows of W] K tiles, then 4 partial [64][DS] fp32 tiles
-    constexpr int DN = DV >= 96 ? 96 : 64;    // W rows staged per K tile (32-row MFMA fragments covering dh)
+    constexpr int DN = DV >= 96 ? 96 : 64;    // W rows of a K tile's LDS slot (32-row MFMA fragments covering dh)
+    constexpr int DW = DQK;                   // ... of which only the first DQK are fetched: rows [DQK, DN) produce projection columns that are dropped
+                                              // below, so their LDS rows may hold anything (an MFMA output column depends on its own W row only) --
+                                              // 10 instead of 12 DMA pieces per K tile at head_dim 72
     constexpr int DS = DQK;                   // columns kept of each partial
     constexpr int PSTAGE = (64 + DN) * 128, PRING = 6 * PSTAGE;   // 3 ring slots of TWO K tiles each (a.xk2) or 3 of one
     constexpr int PRED = 4 * 64 * DS * 4, PQS = 64 * DQK * 2;
@@ -138,9 +141,9 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
                 zr = rsqrtf(m2 * inv_d + a.zeps);
             }
-            uint32_t aoff[1], boff[(DN * 8 + NT - 1) / NT];
+            uint32_t aoff[1], boff[(DW * 8 + NT - 1) / NT];
             stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
-            stage_offsets<DN, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
+            stage_offsets<DW, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
             const char* gA = reinterpret_cast<const char*>(a.xu);
             const char* gW = reinterpret_cast<const char*>(a.xw);
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             auto stage = [&](int t) {
                 char* dst = smem + (t % 3) * PSTAGE + wave_u * 1024;
                 stage_tile<64, NT>(gA + (long)t * 128, aoff, dst, tid);
-                stage_tile<DN, NT>(gW + (long)t * 128, boff, dst + 64 * 128, tid);
+                stage_tile<DW, NT>(gW + (long)t * 128, boff, dst + 64 * 128, tid);
             };
-            // loads per tile of this wave: 1 (x) + 1 or 2 (W: the second pass covers chunks [NT, DN * 8))
-            const bool two = (DN * 8 > NT) && (wave_u * 64 + NT < DN * 8);
+            // loads per tile of this wave: 1 (x) + 1 or 2 (W: the second pass covers chunks [NT, DW * 8))
+            const bool two = (DW * 8 > NT) && (wave_u * 64 + NT < DW * 8);
             stage(0);
             if (nt > 1) stage(1);
             f32x16 acc[FN];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) {
                         stage_tile<64, NT>(gA + (long)(2 * sidx + sub) * 128, aoff, dst + sub * PSTAGE, tid);
-                        stage_tile<DN, NT>(gW + (long)(2 * sidx + sub) * 128, boff, dst + sub * PSTAGE + 64 * 128, tid);
+                        stage_tile<DW, NT>(gW + (long)(2 * sidx + sub) * 128, boff, dst + sub * PSTAGE + 64 * 128, tid);
                     }
                 };
                 if (ns > 1) stage2(1);   // the prologue above (tiles 0 and 1 into slots 0 and PSTAGE) IS stage 0 of this layout

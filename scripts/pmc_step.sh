@@ -9,8 +9,8 @@ TAG=${1:-r02}
 shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
-STEPS=20
-WARM=5
+STEPS=${PMC_STEPS:-20}
+WARM=${PMC_WARM:-5}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-probe --no-shard4 --no-graph $*"
