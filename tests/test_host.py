@@ -335,3 +335,54 @@ def test_ping_pong_schedules_are_hazard_free_model():
                 if t >= NS:
                     last_read = [tm for tm, g, kind, tt, _ in ev if kind == 'read' and tt == t - NS][0]
                     assert last_read < issues[0][0], ('WAR', NS, nt, t)
+
+
+def test_pmc_step_summary_folds_the_lds_and_l2_passes(tmp_path):
+    """tools/pmc_step_summary.py on a synthetic set of rocprofv3 counter CSVs: per-kernel bytes with the gfx950 FETCH_SIZE correction, MFMA busy
+    against the 2.4 GHz peak clock, LDS conflict / wait fractions and the L2 hit rate -- the arithmetic DESIGN.md's roofline table rests on."""
+    import json
+    import subprocess
+    import sys
+
+    def write(tag, rows):
+        d = tmp_path / tag
+        d.mkdir()
+        with open(d / f'{tag}_counter_collection.csv', 'w') as f:
+            f.write('Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n')
+            for did, k, c, v in rows:
+                f.write(f'{did},"{k}",{c},{v},1000,11000\n')   # every dispatch lasts 10 us
+    kg, kr = 'void (anonymous namespace)::k_gemm_pp<128, 288>(GemmArgs)', '(anonymous namespace)::k_row_w<false>(RowArgs)'
+    write('fetch', [(1, kg, 'FETCH_SIZE', 1000), (2, kg, 'FETCH_SIZE', 3000), (3, kr, 'FETCH_SIZE', 500)])           # KB
+    write('write', [(1, kg, 'WRITE_SIZE', 100), (2, kg, 'WRITE_SIZE', 300), (3, kr, 'WRITE_SIZE', 50)])
+    write('sq', [(1, kg, 'SQ_VALU_MFMA_BUSY_CYCLES', 1024 * 12000), (2, kg, 'SQ_VALU_MFMA_BUSY_CYCLES', 1024 * 12000),
+                 (1, kg, 'SQ_WAVE_CYCLES', 1000), (2, kg, 'SQ_WAVE_CYCLES', 1000), (3, kr, 'SQ_WAVE_CYCLES', 10)])
+    write('lds', [(1, kg, 'SQ_LDS_BANK_CONFLICT', 30), (1, kg, 'SQ_LDS_IDX_ACTIVE', 1000), (1, kg, 'SQ_WAIT_INST_LDS', 50), (1, kg, 'SQ_WAVE_CYCLES', 1000)])
+    write('tcc', [(1, kg, 'TCC_HIT_sum', 750), (1, kg, 'TCC_MISS_sum', 250), (1, kg, 'TCC_EA0_RDREQ_sum', 200)])
+    write('dram', [(1, kg, 'TCC_EA0_RDREQ_DRAM_sum', 200)])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'pmc_step_summary.py'), str(tmp_path), '2', '--tag', 't'],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    k = {row['kernel']: row for row in d['kernels']}
+    g = k['k_gemm_pp<128, 288>']
+    assert g['dispatches'] == 2 and g['fetch_bytes'] == 2 * 4000 * 1024 and g['write_bytes'] == 400 * 1024
+    assert abs(g['mfma_busy_frac'] - 0.5) < 1e-9          # 12 000 busy cycles of the 24 000 a SIMD has in 10 us at 2.4 GHz
+    assert abs(g['lds_bank_conflict_frac'] - 0.03) < 1e-12 and abs(g['wait_inst_lds_frac_of_wave_cycles'] - 0.05) < 1e-12
+    assert abs(g['tcc_hit_rate'] - 0.75) < 1e-12 and g['ea_rdreq_dram_frac'] == 1.0
+    assert d['fetch_bytes_per_step'] == (2 * 4000 + 2 * 500) * 1024 / 2 and d['write_bytes_per_step'] == 450 * 1024 / 2
+    assert 'lds_bank_conflict_frac' not in k['k_row_w<false>']          # a kernel the optional passes did not see keeps the old columns only
+
+
+def test_bench_line_extras_are_wired():
+    """The keys and flags round 3 added to bench.py: the config-#4 shard measurement, the placement-test dump flags and the traffic label."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    for needle in ("'config4_shard'", '--no-shard4', '--dump-latents', '--as-rank', 'L2<->fabric bytes per step', 'k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1>'):
+        assert needle in src, needle
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.GEGLU_VARIANT == 60 * 4 + 2 and callable(bench.shard4_measure)
+    # the XL step's algorithmic work the roofline fraction is computed from: 1.541 TFLOP for B = 2, L = 500, Lc = 100
+    cfg = bench.model_section('xl')['model']
+    assert abs(bench.flops_per_step(cfg, 2, 500, 100) / 1e12 - 1.541) < 1e-3
