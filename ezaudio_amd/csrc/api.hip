@@ -122,6 +122,10 @@ struct ezdit_handle {
     // 16-20 us in situ against 9.4 (split-K 3 on 216 CUs) + 7.3 (row kernel) + one launch boundary; every consumer pays 1-3 us for its
     // statistics / G' / C' loads.  profiles/r03_zfuse_*.txt; DESIGN.md section 4.  Needs gemm_pp bits 0 and 1 and the fused q projection.
     int opt_zfuse = 0;
+    int opt_ztile = 70;   // producer of the LayerNorm algebra: 70-75 = K-split-inside-the-workgroup kernel (gemm_ks.h; 70 = 48 x 96 tiles), 63 = ping-pong 64 x 128
+    int opt_zmlp = 1;     // MLP-out projection (K = 4 D) in front of an in / mid block on the un-split producer too (0: split-K slabs + row kernel)
+    int opt_zskip = 1;    // skip_linear (K = 2 D) of the out-blocks on the un-split producer
+    int zwidth() const { return opt_ztile == 63 ? 64 : opt_ztile == 70 || opt_ztile == 72 ? 96 : opt_ztile == 75 ? 128 : 64; }   // statistics chunk = the producer's tile width
     int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 2;   // write-through (sc1) output stores: 0 off, 1 on, 2 = on while B L <= 2048.  The end-of-kernel write-back then has nothing left to flush: -3.5 % step time
@@ -407,6 +411,7 @@ struct Ctx {
     const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
     bool panel = false;                 // one-shot: panel placement of a split-K GEMM (GemmArgs.xcd_panel)
     const float* zG = nullptr; const float* zC = nullptr; long zt_stride = 0;   // one-shot: LayerNorm algebra in the consumer's epilogue
+    const int* cur = nullptr; const int* row_slot = nullptr;   // modulation slot of this forward (a ControlNet attached to the fused sampler reads the BACKBONE's step counter)
     // first launch failure of this call (hipGetLastError after EVERY launch: a rejected launch -- LDS limit, bad grid,
     // unsupported fused configuration -- must surface as an error code, never as stale numbers)
     hipError_t err = hipSuccess;
@@ -458,8 +463,8 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; g.xcd_qkv = h->opt_qkv_affine && h->opt_attn_xcd; }
     if (c.panel) { g.xcd_panel = 1; c.panel = false; }
     if (c.zG) {
-        g.zstat_in = h->p.zstat; g.zparts = (h->D + 63) / 64; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
-        g.cur_step = h->p.ints; g.row_slot = h->per_row ? h->p.ints + 16 : nullptr; g.rows_per_b = h->L;
+        g.zw = h->zwidth(); g.zstat_in = h->p.zstat; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
+        g.cur_step = c.cur ? c.cur : h->p.ints; g.row_slot = c.cur ? c.row_slot : (h->per_row ? h->p.ints + 16 : nullptr); g.rows_per_b = h->L;
         c.zG = nullptr;
     }
     if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
@@ -835,6 +840,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     // every step (src/inference_controlnet.py:92-96)
     const int* cur = cur_override ? cur_override : p.ints;
     const int* row_slot = h->per_row ? p.ints + 16 : nullptr;
+    c.cur = cur; c.row_slot = row_slot;
     float* hA = p.h;
     float* skips = p.skips;
     bf16_t* u = p.u;
@@ -908,13 +914,13 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         GemmArgs g;
         memset(&g, 0, sizeof g);
         g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
-        g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = 63;
+        g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->opt_ztile;
         g.xcd_map = h->opt_xcd_map; g.wt = h->wt(); g.debug = h->opt_gemm_debug;
         g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
         g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat;
         g.ts = c.stamps();
-        c.launched("k_gemm_pp (residual)", launch_gemm(g, st));
+        c.launched("k_gemm (un-split residual)", launch_gemm(g, st));
         u_is_z = true;
     };
 
@@ -955,7 +961,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
+            if (zf && h->opt_zskip && h->opt_ztile >= 70) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot);
+            else resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
         // ---- self attention (blocks.py:136-141) ----
@@ -1021,7 +1028,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
             at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
             if (u_is_z) {
-                at.zstat_in = p.zstat; at.zparts = (D + 63) / 64; at.zD = D; at.zeps = 1e-5f;
+                at.zw = h->zwidth(); at.zstat_in = p.zstat; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
                 at.zG = p.zt_q2 + (long)b * 2 * D; at.zC = at.zG + D;
             }
         } else {
@@ -1076,7 +1083,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
-            if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot);
+            if (zf && h->opt_zmlp) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot);
             else resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
@@ -1348,7 +1355,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
             std::vector<float2> hst(rows * 18, make_float2(0.f, 64.f)); HIPCHK(hipMemcpy(zs, hst.data(), hst.size() * sizeof(float2), hipMemcpyHostToDevice)); }
         if (nn > cap_n) { if (zg0) (void)hipFree(zg0); if (zc) (void)hipFree(zc); HIPCHK(hipMalloc(&zg0, nn * 4)); HIPCHK(hipMalloc(&zc, nn * 4)); cap_n = nn; HIPCHK(hipMemset(zg0, 0, nn * 4)); }
         if (bias) HIPCHK(hipMemcpyAsync(zc, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream)); else HIPCHK(hipMemsetAsync(zc, 0, nn * 4, (hipStream_t)stream));
-        g.zstat_in = zs; g.zparts = 18; g.zD = 1152; g.zG = zg0; g.zC = zc; g.zt_slot_stride = 0; g.zeps = 1e-5f;
+        g.zstat_in = zs; g.zparts = 18; g.zD = 1152; g.zw = 64; g.zG = zg0; g.zC = zc; g.zt_slot_stride = 0; g.zeps = 1e-5f;
         g.debug &= ~64;
     }
     if (g.epi > EPI_GEGLU || g.tile > 127) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
@@ -1360,22 +1367,22 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     return EZDIT_OK;
 }
 
-// EPI_RESID of the ping-pong kernel (un-split residual projection + partial LayerNorm statistics + next operand), stand-alone:
-// h_out = h_in + gate * (A . W^T + bias); zu = bf16(h_out * zg); zstat[row][N / 64 chunks] = (sum, M2 about the chunk mean)
-int ezdit_test_resid(const void* A, int lda, const void* W, int ldw, const float* bias, const float* h_in, const float* gate, const float* zg,
+// EPI_RESID (un-split residual projection + partial LayerNorm statistics + next operand), stand-alone:
+// h_out = h_in + gate * (A . W^T + bias); zu = bf16(h_out * zg); zstat[row][N / tile-width chunks] = (sum, M2 about the chunk mean)
+int ezdit_test_resid(int tile, const void* A, int lda, const void* W, int ldw, const float* bias, const float* h_in, const float* gate, const float* zg,
                      float* h_out, void* zu, int ld_zu, void* zstat, int M, int N, int K, ezdit_stream stream) {
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
     GemmArgs g;
     memset(&g, 0, sizeof g);
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias;
-    g.out = h_out; g.ldo = N; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_RESID; g.tile = 63; g.xcd_map = 1;
+    g.out = h_out; g.ldo = N; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_RESID; g.tile = tile; g.xcd_map = 1;
     g.resid = h_in; g.ldr = N; g.gate = gate; g.rows_per_b = 1;
     g.zu = (bf16_t*)zu; g.ld_zu = ld_zu; g.zg = zg; g.zstat_out = (float2*)zstat;
     g.ts = g_gemm_ts;
     (void)hipGetLastError();
     if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "residual GEMM configuration not supported");
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of k_gemm_pp failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of the residual GEMM failed: %s", hipGetErrorString(e));
     return EZDIT_OK;
 }
 
@@ -1446,6 +1453,9 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
     else if (!strcmp(name, "gemm_pp")) h->opt_gemm_pp = value;
     else if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
+    else if (!strcmp(name, "ztile")) h->opt_ztile = value;
+    else if (!strcmp(name, "zmlp")) h->opt_zmlp = value;
+    else if (!strcmp(name, "zskip")) h->opt_zskip = value;
     else if (!strcmp(name, "pp_max_m")) h->opt_pp_max_m = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;
     else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;

@@ -123,8 +123,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 float2 sv[NK];
 #pragma unroll
                 for (int k = 0; k < NK; ++k) sv[k] = st[q + 8 * k < a.zparts ? q + 8 * k : 0];
-                const int nlast = a.zD - 64 * (a.zparts - 1);
-                const float inv_last = 1.f / (float)nlast, inv_d = 1.f / (float)a.zD;
+                const int nlast = a.zD - a.zw * (a.zparts - 1);
+                const float inv_last = 1.f / (float)nlast, inv_cw = 1.f / (float)a.zw, inv_d = 1.f / (float)a.zD;
                 float s = 0.f;
 #pragma unroll
                 for (int k = 0; k < NK; ++k) s += q + 8 * k < a.zparts ? sv[k].x : 0.f;
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 for (int k = 0; k < NK; ++k) {
                     const int p = q + 8 * k;
                     const bool last = p == a.zparts - 1;
-                    const float d = sv[k].x * (last ? inv_last : 1.f / 64.f) - zmu;
-                    m2 += p < a.zparts ? fmaf(last ? (float)nlast : 64.f, d * d, sv[k].y) : 0.f;
+                    const float d = sv[k].x * (last ? inv_last : inv_cw) - zmu;
+                    m2 += p < a.zparts ? fmaf(last ? (float)nlast : (float)a.zw, d * d, sv[k].y) : 0.f;
                 }
                 m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
                 zr = rsqrtf(m2 * inv_d + a.zeps);

@@ -163,9 +163,9 @@ struct GemmArgs {
     // producer (EPI_RESID):
     bf16_t* zu; int ld_zu;                      // A' [M][ld_zu]
     const float* zg; long zg_slot_stride;       // LayerNorm gain of the consumer (per slot when the stride is non-zero)
-    float2* zstat_out;                          // [M][N / 64]: (sum, M2 about the chunk mean) of h_new over each 64-column chunk
+    float2* zstat_out;                          // [M][N tiles]: (sum, M2 about the chunk mean) of h_new over the columns of each N tile (k_gemm_ks: 96; k_gemm_pp: 64-column chunks)
     // consumer (EPI_QKV, EPI_GEGLU; null zstat_in = plain GEMM):
-    const float2* zstat_in; int zparts; int zD; // [M][zparts] partial statistics of the operand's rows: zparts = ceil(zD / 64) chunks of 64 columns (the last one ragged)
+    const float2* zstat_in; int zparts; int zD; int zw; // [M][zparts] partial statistics of the operand's rows: zparts = ceil(zD / zw) chunks of zw columns (the last one ragged; zw = the producer's tile width)
     const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]
     float zeps;
     unsigned long long* ts;   // test hook (k_gemm_pp): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
@@ -196,7 +196,7 @@ struct AttnArgs {
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
     // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)
     // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)
-    const float2* zstat_in; int zparts; int zD; const float* zG; const float* zC; float zeps;
+    const float2* zstat_in; int zparts; int zD; int zw; const float* zG; const float* zC; float zeps;
     unsigned long long* ts;     // test hook: [workgroup][8] shader-clock stamps (start, operands staged, tile loop end, merge end, end), nullable
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported

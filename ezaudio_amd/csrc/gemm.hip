@@ -21,6 +21,7 @@
 //     (launch-boundary reduce, see rowops.hip), so no atomics and bitwise-deterministic results.
 #include "common.h"
 #include "gemm_pp.h"
+#include "gemm_ks.h"
 
 #include <atomic>
 #include <type_traits>
@@ -712,7 +713,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
     if (EPI == EPI_PARTIAL && a.xcd_panel && BM == 128) grid.x = 8 * ((a.N + BN - 1) / BN) * a.splitk * (((a.M + BM - 1) / BM + 7) / 8);   // M tile tm -> XCD tm % 8 (gemm_pp.h)
     else a.xcd_panel = 0;
-    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096 + BM * 8;   // ring + (mu, r) of the tile's rows (LayerNorm algebra)
+    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + 2 * BN * 4;   // ring + (mu, r) of the tile's rows + G' / C' of its columns (LayerNorm algebra)
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     static std::atomic<bool> attr_set[32];   // per (kernel, device); two host threads may race here on first use (harmless double set)
     int dev = 0;
@@ -725,6 +726,40 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     }
     hipLaunchKernelGGL((k_gemm_pp<BM, BN, WM, WN, NS, EPI, SCHED, VAR>), grid, dim3(512), SMEM, st, a);
     return 0;
+}
+
+// K-split-inside-the-workgroup kernel (gemm_ks.h): 8 waves, each with a private LDS slot for its own K chunks, no barrier in the K loop
+template <int FM, int FN, int EPI, bool GATE, bool RES>
+int launch_ks(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    a.xcd_qkv = 0; a.xcd_panel = 0; a.splitk = 1;
+    constexpr int BM = 16 * FM, BN = 16 * FN;
+    dim3 grid(pick_boxes(a, BM, BN), 1, 1);
+    constexpr int SMEM = 8 * (BM + BN) * 128;
+    static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
+    static std::atomic<bool> attr_set[32];   // per (kernel, device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return 1;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES>), grid, dim3(512), SMEM, st, a);
+    return 0;
+}
+// tile ids of the K-split kernel: 70 = 48 x 96 (21 x 12 = 252 workgroups at M = 1000, N = 1152), 71 = 64 x 64, 72 = 32 x 96, 73 = 48 x 64, 75 = 32 x 128
+template <int EPI, bool GATE, bool RES>
+int launch_ks_tile(const GemmArgs& a, hipStream_t st) {
+    switch (a.tile) {
+        case 70: return launch_ks<3, 6, EPI, GATE, RES>(a, st);
+        case 71: return launch_ks<4, 4, EPI, GATE, RES>(a, st);
+        case 72: return launch_ks<2, 6, EPI, GATE, RES>(a, st);
+        case 73: return launch_ks<3, 4, EPI, GATE, RES>(a, st);
+        case 75: return launch_ks<2, 8, EPI, GATE, RES>(a, st);
+        default: return 1;
+    }
 }
 
 // NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
@@ -844,6 +879,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         if (a.hn.dh == 72) return a.tile == 1 ? launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st) : launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
         if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
         return 1;
+    }
+    if (a.epi == EPI_RESID && a.tile >= 70) {   // K-split-inside-the-workgroup kernel: residual (optional) + gate (optional) + statistics + next operand
+        if (!a.zu || !a.zg || !a.zstat_out || !a.out || a.splitk != 1 || (a.gate && !a.resid)) return 1;
+        if (a.gate) return launch_ks_tile<EPI_RESID, true, true>(a, st);
+        if (a.resid) return launch_ks_tile<EPI_RESID, false, true>(a, st);
+        return launch_ks_tile<EPI_RESID, false, false>(a, st);
+    }
+    if (a.epi == EPI_F32 && a.tile >= 70 && a.tile < 80) {
+        if (a.resid || a.conv_cpb) return 1;
+        return launch_ks_tile<EPI_F32, false, false>(a, st);
     }
     if (a.epi == EPI_RESID) {   // un-split residual projection of the ping-pong kernel (k-split schedule, 64 x 128 tiles, ring 4)
         if (!a.zu || !a.zg || !a.zstat_out || !a.out || !a.bias || !a.resid || a.splitk != 1) return 1;

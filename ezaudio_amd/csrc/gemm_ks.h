@@ -1,0 +1,281 @@
+// K-split-inside-the-workgroup bf16 MFMA GEMM for the narrow residual projections (N = D) at small M:
+//      C[M,N] = A[M,K] . W[N,K]^T      (nn.Linear layout, both K-contiguous)
+//
+// Same math as k_gemm / k_gemm_pp (reference: the to_out / proj_out / mlp.net.2 aten::linear calls of src/models/utils/attention.py:148,
+// src/models/utils/modules.py:277 and the gated residual adds of src/models/blocks.py:139,151,156), a different decomposition.
+//
+// Why: at M = 1000 a D x D projection is 2.65 GFLOP -- one microsecond of MFMA time -- and what a launch costs is how long the LAST
+// workgroup waits for its operands.  Split-K over the grid (k_gemm, 216 workgroups, bf16 slabs, a row kernel to reduce them) pays a second
+// launch and 18 MB of slab traffic; 64 x 128 un-split tiles (k_gemm_pp, round 3) fill 144 of 256 CUs and walk 18 dependent barrier intervals.
+// Here the tile is small enough (48 x 96) for 21 x 12 = 252 workgroups -- one round of the chip -- and K is split over the EIGHT WAVES of the
+// workgroup: wave w owns the 64-wide K chunks w, w + 8, ... and a PRIVATE LDS slot for one chunk of [A rows | W rows].  Every wave runs
+//      wait for its own LDS-DMA (vmcnt) -> read the chunk's fragments -> re-issue the slot for its next chunk -> 36 MFMAs
+// with no workgroup barrier anywhere in the K loop: all 144 KB of LDS are in flight from the first cycle, every operand byte crosses the
+// LDS exactly once (each wave multiplies the WHOLE tile for its K slice), and the waves de-phase on their own.  After the loop the eight
+// partial tiles are summed through the (dead) slots in a fixed order (deterministic), 8 lanes per output row, and the epilogue runs on whole
+// row segments: gated residual, LayerNorm partial statistics over the tile's columns, the next GEMM's operand bf16(h g) -- EPI_RESID, the
+// producer side of the LayerNorm algebra (common.h, GemmArgs.z*) -- or plain bias + store (EPI_F32).
+//
+// LDS image of a chunk (as in k_gemm_pp): rows [A tile | W tile], 128 B each, filled by global_load_lds (16 B per lane, one 1-KB piece =
+// 8 rows) with the bank swizzle on the SOURCE address (chunk c of row r lands in 16-byte slot c ^ ((r >> 1) & 7)).
+#pragma once
+#include "common.h"
+
+namespace {
+
+// EPI_RESID operands of one thread (8 threads per output row; SL 16-byte column slots each): requested at kernel start, used after the loop
+template <int SL>
+struct KsOperands {
+    float4 b[SL], r[SL], g[SL], z[SL];
+};
+
+// column of 16-byte (4-float) slot q of lane j of a row: slots come in pairs (8 contiguous columns: one 16-byte bf16 store) while they last,
+// then one single slot per lane (paired with lane ^ 1 for the bf16 store)
+template <int SL>
+__device__ __forceinline__ int ks_slot_of(int q, int j) {
+    constexpr int NP = SL / 2;                       // pairs per lane
+    return q < 2 * NP ? 16 * (q >> 1) + 2 * j + (q & 1) : 16 * NP + j;
+}
+
+template <int FM, int FN, int EPI, bool GATE, bool RES>
+__global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
+    static_assert(EPI == EPI_F32 || EPI == EPI_RESID, "epilogues");
+    static_assert(FN % 2 == 0 && FM >= 1 && FM <= 4, "tile geometry: 8 lanes per output row, FN / 2 column slots each");
+    constexpr int BM = 16 * FM, BN = 16 * FN;
+    constexpr int NPC = (BM + BN) / 8;             // 1-KB LDS-DMA pieces per chunk
+    constexpr int PA = BM / 8;                     // pieces [0, PA) come from A
+    constexpr int SLOT = (BM + BN) * 128;          // bytes of a wave's slot = one K chunk = (after the loop) its partial tile [BM][BN] fp32
+    static_assert(BM * BN * 4 <= SLOT, "partial tile must fit the slot");
+    static_assert(8 * SLOT <= 160 * 1024, "LDS budget of a CU");
+    constexpr int SL = FN / 2;                     // 16-byte column slots per thread in the epilogue
+    constexpr int S4 = BN / 4;                     // 16-byte slots per partial-tile row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int tilesM = (a.M + BM - 1) / BM;
+    const int tilesN = (a.N + BN - 1) / BN;
+    int tm, tn, z;
+    if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
+    const int row0 = tm * BM, col0 = tn * BN;
+    const int nk = a.K / BK;
+    unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
+    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }
+
+    // ---- epilogue operands: thread (row er, lane-in-row ej) of the first 8 BM threads; requested NOW, in front of the first LDS-DMA (vector
+    // memory returns in issue order, so the first chunk's wait covers them) and carried through the K loop in registers
+    const int er = tid >> 3, ej = tid & 7;
+    const bool epi_thread = tid < 8 * BM;
+    int erow = row0 + er;
+    const bool row_ok = epi_thread && erow < a.M;
+    erow = erow < a.M ? erow : a.M - 1;
+    const int ncl = a.N - 4;                       // N is a multiple of 4 for every caller
+    KsOperands<SL> op = {};
+    if (epi_thread) {
+        int slot = 0;
+        if constexpr (EPI == EPI_RESID) slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[erow / a.rows_per_b] : 0);
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            int col = col0 + 4 * ks_slot_of<SL>(q, ej);
+            col = col < ncl ? col : ncl;
+            op.b[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (EPI == EPI_RESID) {
+                if constexpr (RES) op.r[q] = *reinterpret_cast<const float4*>(a.resid + (long)erow * a.ldr + col);
+                if constexpr (GATE) op.g[q] = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
+                op.z[q] = *reinterpret_cast<const float4*>(a.zg + (long)slot * a.zg_slot_stride + col);
+            }
+        }
+    }
+
+    // ---- loop-invariant addressing: byte offset of this lane's 16 bytes of piece p (K offset excluded)
+    uint32_t poff[NPC];
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) {
+        const int row = 8 * p + (lane >> 3), c = lane & 7;
+        if (p < PA) {
+            int grow = row0 + row;
+            grow = grow < a.M ? grow : a.M - 1;
+            poff[p] = (uint32_t)(grow * a.lda + ((c ^ ((row >> 1) & 7)) << 3)) * 2u;
+        } else {
+            const int r2 = row - BM;
+            int gr = col0 + r2;
+            gr = gr < a.wrows ? gr : a.wrows - 1;
+            poff[p] = (uint32_t)(gr * a.ldw + ((c ^ ((r2 >> 1) & 7)) << 3)) * 2u;
+        }
+    }
+    const char* gA = reinterpret_cast<const char*>(a.A);
+    const char* gW = reinterpret_cast<const char*>(a.W);
+    char* slot = smem + wave * SLOT;               // wave-uniform
+    auto issue = [&](int c) {
+        const long koff = (long)c * (BK * 2);
+#pragma unroll
+        for (int p = 0; p < NPC; ++p) {
+            const char* src = (p < PA ? gA : gW) + koff + poff[p];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + p * 1024), 16, 0, 0);
+        }
+    };
+    // fragment read offsets (k_gemm_pp): row (lane & 15) of a 16-row fragment, k-step ks (32 of K) -> 16-byte slot (4 ks + (lane >> 4)) ^ ((row >> 1) & 7)
+    const int r16 = lane & 15, kq = lane >> 4;
+    uint32_t foff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) foff[ks] = r16 * 128 + (((4 * ks + kq) ^ (r16 >> 1)) << 4);
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int c = wave;
+    if (c < nk) issue(c);
+    if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
+    for (; c < nk; c += 8) {
+        // own LDS-DMA landed (nothing else orders a ds_read behind it); no other wave touches this slot: no barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bf16x8 af[FM][2], bfr[FN][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) af[i][ks] = *reinterpret_cast<const bf16x8*>(slot + foff[ks] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bfr[j][ks] = *reinterpret_cast<const bf16x8*>(slot + BM * 128 + foff[ks] + j * 2048);
+        }
+        // the reads must have returned before the refill may overwrite the slot
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 8 < nk) issue(c + 8);
+        __builtin_amdgcn_sched_barrier(0);
+        // transposed product (W fragment as the A operand): a lane owns output row lane & 15 and columns 4 (lane >> 4) + {0..3} of a fragment
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j][ks]), "v"(af[i][ks]));
+    }
+    if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
+    // the last MFMA's result is not interlocked against the reads below (inline asm): 20 wait states tied to the accumulators
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+
+    // ---- park this wave's partial tile in its OWN slot (dead: its last chunk was read above and nothing is in flight): [BM][S4] 16-byte
+    // slots, slot s of row r at s ^ (r & 7) -- the 8 lanes of a store group hold 8 different rows of one column slot
+    {
+        float4* mine = reinterpret_cast<float4*>(slot);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = 16 * i + r16, s = 4 * j + kq;
+                mine[r * S4 + (s ^ (r & 7))] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+    }
+    __syncthreads();
+    if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
+    if (!epi_thread) return;
+
+    // ---- sum the eight partials in wave order (fixed: bit-reproducible) and finish the row segment
+    float4 v[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        const int s = ks_slot_of<SL>(q, ej);
+        const float4* p0 = reinterpret_cast<const float4*>(smem) + er * S4 + (s ^ (er & 7));
+        float4 t = p0[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float4 u = p0[w * (SLOT / 16)];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        v[q] = t;
+    }
+    float* out = reinterpret_cast<float*>(a.out);
+    if constexpr (EPI == EPI_F32) {
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
+            const float4 o = make_float4(v[q].x + op.b[q].x, v[q].y + op.b[q].y, v[q].z + op.b[q].z, v[q].w + op.b[q].w);
+            if (row_ok && col < a.N) {
+                float* dst = out + (long)erow * a.ldo + col;
+                if (a.wt) st16_wt(dst, o); else *reinterpret_cast<float4*>(dst) = o;
+            }
+        }
+    } else {
+        float s1 = 0.f;
+        int nval = 0;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
+            const bool ok = col < a.N;
+            // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
+            float4 x = make_float4(v[q].x + op.b[q].x, v[q].y + op.b[q].y, v[q].z + op.b[q].z, v[q].w + op.b[q].w);
+            if constexpr (GATE) { x.x *= op.g[q].x; x.y *= op.g[q].y; x.z *= op.g[q].z; x.w *= op.g[q].w; }
+            if constexpr (RES) { x.x += op.r[q].x; x.y += op.r[q].y; x.z += op.r[q].z; x.w += op.r[q].w; }
+            v[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+            nval += ok ? 4 : 0;
+            s1 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+            if (row_ok && ok) {
+                float* dst = out + (long)erow * a.ldo + col;
+                if (a.wt) st16_wt(dst, v[q]); else *reinterpret_cast<float4*>(dst) = v[q];
+            }
+        }
+        // statistics of this tile's valid columns: (sum, M2 about their own mean); the 8 lanes of a row are neighbours
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+        nval += __shfl_xor(nval, 1, 64); nval += __shfl_xor(nval, 2, 64); nval += __shfl_xor(nval, 4, 64);
+        const float mean = nval > 0 ? s1 * __builtin_amdgcn_rcpf((float)nval) : 0.f;   // any value near the mean serves Chan's merge
+        float m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            const bool ok = col0 + 4 * ks_slot_of<SL>(q, ej) < a.N;
+            float d;
+            d = v[q].x - mean; m2 += ok ? d * d : 0.f;
+            d = v[q].y - mean; m2 += ok ? d * d : 0.f;
+            d = v[q].z - mean; m2 += ok ? d * d : 0.f;
+            d = v[q].w - mean; m2 += ok ? d * d : 0.f;
+        }
+        m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+        if (ej == 0 && row_ok) a.zstat_out[(long)erow * tilesN + tn] = make_float2(s1, m2);
+        // A' = bf16(h_new * zg) as whole 16-byte chunks (8 columns)
+        uint2 pk[SL];
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            pk[q].x = pack_bf2(v[q].x * op.z[q].x, v[q].y * op.z[q].y);
+            pk[q].y = pack_bf2(v[q].z * op.z[q].z, v[q].w * op.z[q].w);
+        }
+        bf16_t* zrow = a.zu + (long)erow * a.ld_zu;
+        auto store8 = [&](int col, uint2 lo, uint2 hi) {   // columns [col, col + 8) of this row
+            if (!row_ok || col >= a.N) return;
+            bf16_t* dst = zrow + col;
+            if (col + 8 <= a.N) {
+                const float4 f = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
+                if (a.wt) st16_wt(dst, f); else *reinterpret_cast<float4*>(dst) = f;
+            } else {   // ragged tail: N is a multiple of 4
+                *reinterpret_cast<uint2*>(dst) = lo;
+            }
+        };
+#pragma unroll
+        for (int q = 0; q + 1 < 2 * (SL / 2); q += 2) store8(col0 + 4 * ks_slot_of<SL>(q, ej), pk[q], pk[q + 1]);
+        if constexpr (SL & 1) {
+            // the single slot: lanes (2 i, 2 i + 1) hold the two halves of one 8-column chunk; the even lane stores it
+            const uint2 mine = pk[SL - 1];
+            uint2 other;
+            other.x = __shfl_xor(mine.x, 1, 64);
+            other.y = __shfl_xor(mine.y, 1, 64);
+            if ((ej & 1) == 0) store8(col0 + 4 * ks_slot_of<SL>(SL - 1, ej), mine, other);
+        }
+    }
+    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+}  // namespace

@@ -100,23 +100,28 @@ __device__ __forceinline__ void copy_out_bf16(const bf16_t* tile, int pitch, int
 }
 
 // ---- LayerNorm algebra (GemmArgs.z*): (mu, r) of one row from its per-chunk partial statistics (sum, M2 about the chunk mean), merged
-// with Chan's parallel-variance formula; chunk p holds min(64, D - 64 p) columns.  Same accuracy class as a two-pass LayerNorm.
+// with Chan's parallel-variance formula; chunk p holds min(cw, D - cw p) columns (cw = the producer's tile width).  Same accuracy class as a two-pass LayerNorm.
 constexpr int Z_MAXP = 40;   // chunks of 64 columns a row's statistics may have (2D = 2304 -> 36)
 // TPR threads per row (consecutive lanes), thread q of a row takes the chunks q, q + TPR, ...: every chunk is requested before the first use
 // and a row's chunks are read by neighbouring lanes (32 contiguous bytes per 4 lanes) -- the first build let every lane walk its own
 // row chunk by chunk (one L2 round trip per chunk, 16 lines per load instruction) and paid +11 us on the GEGLU GEMM for it.
 // All TPR lanes of the row return (mu, r).
 template <int TPR>
-__device__ __forceinline__ void z_row_stats_coop(const float2* __restrict__ st, int parts, int D, float eps, int q, float& mu, float& r) {
+struct ZStatRegs { float2 v[(Z_MAXP + TPR - 1) / TPR]; };
+template <int TPR>
+__device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st, int parts, int q, ZStatRegs<TPR>& z) {
     constexpr int NK = (Z_MAXP + TPR - 1) / TPR;
-    float2 v[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) v[k] = st[q + TPR * k < parts ? q + TPR * k : 0];
-    const int nlast = D - 64 * (parts - 1);            // columns of the last (possibly ragged) chunk
-    const float inv_last = 1.f / (float)nlast, inv_d = 1.f / (float)D;
+    for (int k = 0; k < NK; ++k) z.v[k] = st[q + TPR * k < parts ? q + TPR * k : 0];
+}
+template <int TPR>
+__device__ __forceinline__ void z_row_stats_finish(const ZStatRegs<TPR>& z, int parts, int D, int cw, float eps, int q, float& mu, float& r) {
+    constexpr int NK = (Z_MAXP + TPR - 1) / TPR;
+    const int nlast = D - cw * (parts - 1);            // columns of the last (possibly ragged) chunk
+    const float inv_last = 1.f / (float)nlast, inv_cw = 1.f / (float)cw, inv_d = 1.f / (float)D;
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) s += q + TPR * k < parts ? v[k].x : 0.f;
+    for (int k = 0; k < NK; ++k) s += q + TPR * k < parts ? z.v[k].x : 0.f;
 #pragma unroll
     for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
     mu = s * inv_d;
@@ -125,8 +130,8 @@ __device__ __forceinline__ void z_row_stats_coop(const float2* __restrict__ st, 
     for (int k = 0; k < NK; ++k) {
         const int p = q + TPR * k;
         const bool last = p == parts - 1;
-        const float d = v[k].x * (last ? inv_last : 1.f / 64.f) - mu;
-        m2 += p < parts ? fmaf(last ? (float)nlast : 64.f, d * d, v[k].y) : 0.f;
+        const float d = z.v[k].x * (last ? inv_last : inv_cw) - mu;
+        m2 += p < parts ? fmaf(last ? (float)nlast : (float)cw, d * d, z.v[k].y) : 0.f;
     }
 #pragma unroll
     for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
@@ -208,7 +213,7 @@ __device__ __forceinline__ void pp_store_direct(const GemmArgs& a, f32x4 (&acc)[
 // (branch-free: both lanes evaluate  mul * gelu(arg)  with their own selection of mul / arg).
 template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, int EPI, bool ZC>
 __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid, int z,
-                                             const float2* zrow, int slot0, unsigned long long* ts = nullptr) {
+                                             const float2* zrow, const float* zgc, int slot0, unsigned long long* ts = nullptr) {
     static_assert(EPI == EPI_GEGLU || EPI == EPI_PARTIAL, "bf16 outputs only");
     constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;   // output columns of the tile
     static_assert(OC % 8 == 0, "16-byte row chunks");
@@ -234,9 +239,10 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
             for (int j = 0; j < FN; ++j) {
                 int cp = col0 + wn * TN + j * 16 + 4 * cg;
                 cp = cp < ncl ? cp : ncl;
-                if constexpr (ZC) {
-                    g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
-                    c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
+                if constexpr (ZC) {   // parked behind the ring at kernel start (k_gemm_pp, z_finish)
+                    (void)so;
+                    g4[j] = *reinterpret_cast<const float4*>(zgc + (wn * TN + j * 16 + 4 * cg));
+                    c4[j] = *reinterpret_cast<const float4*>(zgc + BN + (wn * TN + j * 16 + 4 * cg));
                 } else {
                     g4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     c4[j] = a.bias ? *reinterpret_cast<const float4*>(a.bias + cp) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -405,7 +411,7 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
 // coincide with MFMA fragments; per-head LayerNorm + RoPE of q / k -> [B][H][Lp][DQK], V -> V^T [B][H][DV][Lp].
 template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT, bool ZC>
 __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid,
-                                             const float2* zrow, int slot0) {
+                                             const float2* zrow, const float* zgc, int slot0) {
     constexpr int NH = BN / DH, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
     static_assert(NH * DH == BN && DH % 4 == 0 && (DH * 2) % 16 == 0, "whole heads");
     float* tile = reinterpret_cast<float*>(smem);                        // [BM][PITCH] fp32, reuses the ring
@@ -423,10 +429,15 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
             float4 c4[FN], g4[FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                int cp = col0 + wn * TN + j * 16 + 4 * cg;
-                cp = cp < ncl ? cp : ncl;
-                g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
-                c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
+                if (!a.row_slot) {   // shared modulation slot: parked behind the ring at kernel start (k_gemm_pp, z_finish)
+                    g4[j] = *reinterpret_cast<const float4*>(zgc + (wn * TN + j * 16 + 4 * cg));
+                    c4[j] = *reinterpret_cast<const float4*>(zgc + BN + (wn * TN + j * 16 + 4 * cg));
+                } else {
+                    int cp = col0 + wn * TN + j * 16 + 4 * cg;
+                    cp = cp < ncl ? cp : ncl;
+                    g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
+                    c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
+                }
             }
             const float2 mr = zrow[rl];
             const float r = mr.y, rm = mr.y * mr.x;
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr int STAGE = NP * 4096;
     constexpr int PD = NS - 1;                 // prefetch distance in K tiles
     static_assert(NS >= 3 && NS <= 6, "ring depth");
-    static_assert(NS * STAGE + BM * 8 <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics)");
+    static_assert(NS * STAGE + BM * 8 + 2 * BN * 4 <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics + G' / C' of the tile's columns)");
     constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -590,16 +601,36 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr bool ZM = (VAR & 64) != 0;
     const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed in the epilogue only
     float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
+    // LayerNorm algebra, consumer side: the tile's rows' partial statistics (one contiguous block: 4 threads per row, coalesced) and the G' / C'
+    // slices of the tile's columns are REQUESTED here, in front of the prologue's LDS-DMA, and turned into (mu, r) / parked in LDS behind the
+    // ring by z_finish() right after the prologue's issue (one wait for everything that is in flight at kernel start); the epilogue reads
+    // them back many barriers later.  (Round 3 waited for the statistics before the first LDS-DMA went out -- one exposed fabric round trip
+    // -- and fetched G' / C' from global memory after the K loop -- a second one: +2.2 ... 2.9 us per consumer launch.)
+    float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only)
+    ZStatRegs<4> zst;
+    float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool z_shared_slot = a.row_slot == nullptr;
     if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-        // the tile's rows' partial statistics are one contiguous block: 4 threads per row, coalesced; lands under the prologue's first-tile wait;
-        // read back in the epilogue, many barriers later
         static_assert(BM * 4 == NT, "4 threads per row");
+        static_assert(2 * (BN / 4) <= NT, "one float4 of G' or C' per thread");
         int row = row0 + (tid >> 2);
         row = row < a.M ? row : a.M - 1;
-        float mu, r;
-        z_row_stats_coop<4>(a.zstat_in + (long)row * a.zparts, a.zparts, a.zD, a.zeps, tid & 3, mu, r);
-        if ((tid & 3) == 0) zrow[tid >> 2] = make_float2(mu, r);
+        z_row_stats_load<4>(a.zstat_in + (long)row * a.zparts, a.zparts, tid & 3, zst);
+        if (z_shared_slot && tid < 2 * (BN / 4)) {
+            const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
+            int cp = col0 + 4 * t4;
+            cp = cp < a.N - 4 ? cp : a.N - 4;
+            zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + (long)slot0 * a.zt_slot_stride + cp);
+        }
     }
+    auto z_finish = [&]() {
+        if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
+            float mu, r;
+            z_row_stats_finish<4>(zst, a.zparts, a.zD, a.zw, a.zeps, tid & 3, mu, r);
+            if ((tid & 3) == 0) zrow[tid >> 2] = make_float2(mu, r);
+            if (z_shared_slot && tid < 2 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
+        }
+    };
     // EPI_RESID: the epilogue's operands (bias, residual rows, gate, LayerNorm gain) are requested NOW, in front of the prologue's LDS-DMA, and
     // ride through the K loop in registers: after the loop nothing waits on global memory.  (Vector-memory loads complete in issue order, so
     // the first tile's wait covers them: prologue 1842 -> 3799 cycles, epilogue 10120 -> 5668 on the D x D shape.  Requesting them BEHIND the
@@ -745,6 +776,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
             for (int t = 0; t < PD; ++t)
                 if (t < nt) issue(t, IB{}, IE{});
+            z_finish();
             wait_younger<PG, PD - 1>((nt < PD ? nt : PD) - 1);
             barrier();
             if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
@@ -792,6 +824,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < PD; ++u)
                 if (((u + PD) & 1) == G && u < nt) issue(u, IB{}, IE{});
+            z_finish();
             if constexpr ((PD & 1) == G) {   // owner of tile 0
                 const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
                 wait_younger<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0);
@@ -891,13 +924,13 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
             static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");
-            pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zrow, slot0);
+            pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zrow, zgc, slot0);
         }
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
-                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, zrow, slot0, ts);
+                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, zrow, zgc, slot0, ts);
                     if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
                     return;
                 }
@@ -909,7 +942,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
-                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, zrow, slot0, ts);
+                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, zrow, zgc, slot0, ts);
                     if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
                     return;
                 }

@@ -173,9 +173,12 @@ def test_controlnet_hip_matches_reference_golden(lib, name):
 
 
 @pytest.mark.gpu
-def test_controlnet_fused_sampler_equals_stepwise_calls(lib):
+@pytest.mark.parametrize('zfuse', [0, 1])
+def test_controlnet_fused_sampler_equals_stepwise_calls(lib, zfuse):
     """The device loop with an attached ControlNet (one hipGraph per step: ControlNet + backbone + CFG/DDIM) against the
-    same step assembled from the public call surfaces, driven by the oracle's restatement of the reference loop."""
+    same step assembled from the public call surfaces, driven by the oracle's restatement of the reference loop.
+    zfuse: both settings of the LayerNorm-algebra path -- its consumers must index their G' / C' tables with the BACKBONE's step
+    counter inside the attached ControlNet too (round-3 ADVICE: they read the ControlNet's own, never-advanced counter)."""
     import torch
     from ezaudio_amd.sampler import LatentSampler
     from ezaudio_amd.scheduler import DDIMScheduler
@@ -183,6 +186,8 @@ def test_controlnet_fused_sampler_equals_stepwise_calls(lib):
     from tests.util import DIFF
     cfg, sd, csd, inp, cond, g, meta = cn_case('cn_xs')
     m, cn = _models(cfg, sd, csd)
+    for hdl in (m._h, cn._h):
+        assert lib.ezdit_set_option(hdl, b'zfuse', zfuse) == 0
     C, L, steps, scale = cfg['out_chans'], meta['L'], 6, 0.8
     s3 = np.float32(np.sqrt(3.0))
     init = (uniform_pm1('c.init', C * L, 1) * s3).reshape(1, C, L)
@@ -219,6 +224,8 @@ def test_controlnet_fused_sampler_equals_stepwise_calls(lib):
     x_probe = np.concatenate([init, init], 0)
     again = denoise(x_probe, 499, inp['ctx'], inp['ctx_mask'], None, None)
     m2, cn2 = _models(cfg, sd, csd)   # a pair that never saw a fused run
+    for hdl in (m2._h, cn2._h):
+        assert lib.ezdit_set_option(hdl, b'zfuse', zfuse) == 0
     fresh = denoise(x_probe, 499, inp['ctx'], inp['ctx_mask'], None, None, m2, cn2)
     np.testing.assert_array_equal(again, fresh)
     # and the ControlNet really matters: detaching it changes the trajectory

@@ -105,6 +105,24 @@ def t_(a, dev='cuda:0'):
     (1000, 1152, 1152, 65 * 4 + 1, 3),
     (300, 256, 64, 65 * 4 + 0, 1),
     (300, 256, 320, 16000 + 65 * 4 + 1, 1),
+    # K-split-inside-the-workgroup kernel (k_gemm_ks; 70: 48x96, 71: 64x64, 72: 32x96, 73: 48x64, 75: 32x128): K chunk counts below, at and
+    # above the eight waves (idle waves, uneven shares), ragged M / N
+    (1000, 1152, 1152, 70 * 4 + 0, 1),
+    (1000, 1152, 4608, 70 * 4 + 0, 1),
+    (1000, 1152, 2304, 70 * 4 + 0, 1),
+    (1000, 1024, 1024, 70 * 4 + 0, 1),         # ragged last N tile (1024 = 10 * 96 + 64)
+    (77, 100, 64, 70 * 4 + 0, 1),              # one chunk: seven waves idle
+    (130, 96, 192, 70 * 4 + 0, 1),
+    (50, 200, 576, 70 * 4 + 0, 1),             # nine chunks
+    (4000, 1152, 1152, 70 * 4 + 0, 1),
+    (1000, 1152, 1152, 71 * 4 + 0, 1),
+    (100, 60, 320, 71 * 4 + 0, 1),
+    (1000, 1152, 1152, 72 * 4 + 0, 1),
+    (90, 100, 128, 72 * 4 + 0, 1),
+    (1000, 1152, 1152, 73 * 4 + 0, 1),
+    (90, 100, 640, 73 * 4 + 0, 1),
+    (1000, 1152, 1152, 75 * 4 + 0, 1),
+    (33, 130, 192, 75 * 4 + 0, 1),
 ])
 def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     g = torch.Generator().manual_seed(M + N + K)
@@ -139,10 +157,17 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('M,N,K', [(1000, 1152, 1152), (1000, 1152, 4608), (192, 144, 192), (192, 128, 128), (77, 576, 64), (500, 1024, 320)])
-def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K):
-    """Producer side of the LayerNorm algebra (EPI_RESID of k_gemm_pp): h_new = h + gate * (A W^T + b) in fp32, its per-64-column-chunk
+ZW = {63: 64, 70: 96, 71: 64, 72: 96, 73: 64, 75: 128}   # statistics chunk width = the producer's tile width
+
+
+@pytest.mark.parametrize('tile,mode', [(63, 'gr'), (70, 'gr'), (70, 'r'), (70, ''), (71, 'gr'), (72, 'gr'), (73, 'r'), (75, 'gr'), (75, '')])
+@pytest.mark.parametrize('M,N,K', [(1000, 1152, 1152), (1000, 1152, 4608), (192, 144, 192), (192, 128, 128), (77, 576, 64), (500, 1024, 320), (1000, 1152, 2304)])
+def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K, tile, mode):
+    """Producer side of the LayerNorm algebra (EPI_RESID; tile 63: k_gemm_pp, 70+: the K-split-inside-the-workgroup kernel k_gemm_ks):
+    h_new = h + gate * (A W^T + b) in fp32 (mode 'gr'; 'r': no gate; '': no residual either -- skip_linear), its per-column-tile
     (sum, M2) statistics -- merged here with Chan's formula and compared with the row's true mean / variance -- and A' = bf16(h_new * g)."""
+    if tile == 63 and mode != 'gr':
+        pytest.skip('the ping-pong producer always has a residual')
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16)
     Np = (N + 127) // 128 * 128
@@ -150,21 +175,26 @@ def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K):
     W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
     bias, gate, zg = torch.randn(N, generator=g), torch.rand(N, generator=g), 1 + 0.3 * torch.randn(N, generator=g)
     h_in = torch.randn(M, N, generator=g) + 0.7          # a row mean that is not small against the spread
-    ref = h_in.double() + gate.double() * (A.float().double() @ W[:N].float().double().T + bias.double())
+    ref = A.float().double() @ W[:N].float().double().T + bias.double()
+    if 'g' in mode or tile == 63:
+        ref = gate.double() * ref
+    if 'r' in mode:
+        ref = h_in.double() + ref
     ld = (N + 63) // 64 * 64
-    parts = (N + 63) // 64
+    cw = ZW[tile]
+    parts = (N + cw - 1) // cw
     Ad, Wd, bd, gd, zd, hd = A.to(dev), W.to(dev), bias.to(dev), gate.to(dev), zg.to(dev), h_in.to(dev)
     h_out = torch.full((M, N), float('nan'), device=dev)
     zu = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
     zs = torch.zeros(M, parts, 2, device=dev)
-    rc = lib.ezdit_test_resid(Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), hd.data_ptr(), gd.data_ptr(), zd.data_ptr(), h_out.data_ptr(),
-                              zu.data_ptr(), ld, zs.data_ptr(), M, N, K, None)
+    rc = lib.ezdit_test_resid(tile, Ad.data_ptr(), K, Wd.data_ptr(), K, bd.data_ptr(), hd.data_ptr() if 'r' in mode else None,
+                              gd.data_ptr() if 'g' in mode else None, zd.data_ptr(), h_out.data_ptr(), zu.data_ptr(), ld, zs.data_ptr(), M, N, K, None)
     assert rc == 0
     torch.cuda.synchronize()
     got = h_out.cpu().double()
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
     st = zs.cpu().double()
-    n = torch.tensor([min(64, N - 64 * p) for p in range(parts)], dtype=torch.float64)
+    n = torch.tensor([min(cw, N - cw * p) for p in range(parts)], dtype=torch.float64)
     mean = st[:, :, 0].sum(1) / N
     m2 = (st[:, :, 1] + n * (st[:, :, 0] / n - mean[:, None]) ** 2).sum(1)
     np.testing.assert_allclose(mean.numpy(), ref.mean(1).numpy(), rtol=0, atol=2e-5)
@@ -272,7 +302,7 @@ def test_forward_matches_reference_golden(lib, dev, name):
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, t, r, a)
 
 
-@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'xl'])
+@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'l', 'xl', 'xl_b8'])
 def test_layernorm_algebra_path_matches_reference_golden(lib, dev, name):
     """Option zfuse (off by default: measured slower): un-split residual projections whose epilogue emits h, partial LayerNorm
     statistics and the next GEMM's operand h * g, the consumer GEMM finishing the LayerNorm as r (acc - mu G') + C' in its epilogue.  Same
@@ -290,7 +320,7 @@ def test_layernorm_algebra_path_matches_reference_golden(lib, dev, name):
     finally:
         assert lib.ezdit_set_option(m._h, b'zfuse', 0) == 0
     nblk = cfg['depth'] + 1
-    assert n_z == n_base - (2 * nblk + cfg['depth'] // 2)      # attention-out and cross-out of every block, MLP-out in front of in / mid blocks
+    assert n_z == n_base - (2 * nblk + cfg['depth'])      # attention-out and cross-out of every block, MLP-out in front of in / mid blocks, skip_linear of the out-blocks
     r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
     print(f'{name} t={t} zfuse: rel-L2 {r:.3e} max-abs {a:.3e} (default path {rel_l2(base, ref):.3e}); launches {n_base} -> {n_z}')
     assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
     const int iters = 40;
     const Shape shapes[] = {
         {"geglu", 1000, 9216, 1152}, {"geglu4k", 1000, 9216, 4608}, {"qkv", 1000, 3456, 1152}, {"dxd", 1000, 1152, 1152},
-        {"skip", 1000, 1152, 2304}, {"mlpout", 1000, 1152, 4608}, {"geglu_b4", 4000, 9216, 1152}, {"odd", 77, 288, 192}, {"odd1", 130, 576, 64}, {"odd2", 200, 432, 128}, {"odd5", 1000, 288, 320},
+        {"skip", 1000, 1152, 2304}, {"mlpout", 1000, 1152, 4608}, {"dxd_b4", 4000, 1152, 1152}, {"mlpout_b4", 4000, 1152, 4608}, {"geglu_b4", 4000, 9216, 1152}, {"odd", 77, 288, 192}, {"odd1", 130, 576, 64}, {"odd2", 200, 432, 128}, {"odd5", 1000, 288, 320},
     };
     // which configurations run on which shape
     std::vector<Cfg> wide = {   // N >= 3456
@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
         {"pp64 128x144 s2 split1", 64, 1, 1, 0, 0}, {"pp64 split2", 64, 1, 2, 0, 0}, {"pp64 split3", 64, 1, 3, 0, 0},
         {"pp61 128x144 r4 split3", 61, 1, 3, 0, 0}, {"pp61 split4", 61, 1, 4, 0, 0},
         {"pp63 f32 bias", 63, 0, 1, 0, 0}, {"pp65 f32 bias", 65, 0, 1, 0, 0},
+        {"ks 48x96 f32 bias (70)", 70, 0, 1, 0, 0}, {"ks 64x64 f32 bias (71)", 71, 0, 1, 0, 0}, {"ks 32x96 f32 bias (72)", 72, 0, 1, 0, 0}, {"ks 48x64 f32 bias (73)", 73, 0, 1, 0, 0}, {"ks 32x128 f32 bias (75)", 75, 0, 1, 0, 0},
     };
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
@@ -192,27 +193,68 @@ int main(int argc, char** argv) {
             CHECK(hipMalloc(&dh, (size_t)Mp * N * 4)); CHECK(hipMalloc(&dg, N * 4)); CHECK(hipMalloc(&dz, N * 4));
             CHECK(hipMalloc(&dzu, (size_t)Mp * N * 2)); CHECK(hipMalloc(&dzs, (size_t)Mp * (N / 64) * 8));
             CHECK(hipMemset(dh, 0, (size_t)Mp * N * 4)); CHECK(hipMemcpy(dg, hb.data(), N * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dz, hb.data(), N * 4, hipMemcpyHostToDevice));
-            auto run = [&]() { return ezdit_test_resid(dA, K, dW, K, db, dh, dg, dz, dout, dzu, N, dzs, M, N, K, st); };
-            if (run()) { printf("   resid unsupported (%s)\n", ezdit_last_error()); }
-            else {
+            static char* dflush = nullptr;
+            const size_t FLUSH = (size_t)768 << 20;   // > L2 + Infinity Cache
+            if (!dflush) CHECK(hipMalloc(&dflush, FLUSH));
+            const int tiles[] = {63, 70, 71, 72, 73, 75};
+            for (int tile : tiles) {
+                auto run = [&]() { return ezdit_test_resid(tile, dA, K, dW, K, db, dh, dg, dz, dout, dzu, N, dzs, M, N, K, st); };
+                char name[64]; snprintf(name, sizeof name, "EPI_RESID un-split tile %d", tile);
+                if (run()) { printf("   %-34s unsupported (%s)\n", name, ezdit_last_error()); continue; }
                 CHECK(hipStreamSynchronize(st));
+                // check h_out = 0 + b * (acc + b) against the reference (gate = zg = bias vector here)
+                {
+                    std::vector<float> ho((size_t)M * N);
+                    CHECK(hipMemcpy(ho.data(), dout, ho.size() * 4, hipMemcpyDeviceToHost));
+                    double max_err = 0; long bad = 0;
+                    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+                        const double ref = (double)hb[n] * (hC[(size_t)m * N + n] + hb[n]);
+                        const double err = fabs(ho[(size_t)m * N + n] - ref);
+                        if (err > max_err) max_err = err;
+                        if (!(err <= 1e-3 * fabs(ref) + 1e-3)) ++bad;
+                    }
+                    if (bad) printf("      *** MISMATCH *** %ld elements, max err %.3e\n", bad, max_err);
+                }
                 hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
                 for (int i = 0; i < 5; ++i) run();
                 CHECK(hipEventRecord(e0, st));
                 for (int i = 0; i < iters; ++i) run();
                 CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
                 float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
-                printf("   %-34s %8.2f us  %7.1f TF\n", "pp 64x128 s2 EPI_RESID (un-split)", ms * 1e3 / iters, 2.0 * M * N * K / (ms * 1e3 / iters) * 1e-6);
+                const double warm_us = ms * 1e3 / iters;
+                // cold operands: everything evicted (768 MB memset), then the activations re-written (as the producing kernel of the live step
+                // would leave them: in the Infinity Cache, not in this XCD's L2); the weights come from HBM
+                double cold_us = 0;
+                const int citers = 10;
+                std::vector<hipEvent_t> ev(2 * citers);
+                for (auto& e : ev) CHECK(hipEventCreate(&e));
+                for (int i = 0; i < citers; ++i) {
+                    CHECK(hipMemsetAsync(dflush, i, FLUSH, st));
+                    CHECK(hipMemcpyAsync(dA, dA + (size_t)Mp * K / 2, 0, hipMemcpyDeviceToDevice, st));
+                    CHECK(hipMemcpyAsync(dflush, dA, (size_t)Mp * K * 2, hipMemcpyDeviceToDevice, st));
+                    CHECK(hipMemcpyAsync(dA, dflush, (size_t)Mp * K * 2, hipMemcpyDeviceToDevice, st));
+                    CHECK(hipEventRecord(ev[2 * i], st));
+                    run();
+                    CHECK(hipEventRecord(ev[2 * i + 1], st));
+                }
+                CHECK(hipStreamSynchronize(st));
+                for (int i = 0; i < citers; ++i) { float m1 = 0; CHECK(hipEventElapsedTime(&m1, ev[2 * i], ev[2 * i + 1])); cold_us += m1 * 1e3 / citers; }
+                for (auto& e : ev) CHECK(hipEventDestroy(e));
+                printf("   %-34s %8.2f us warm  %8.2f us cold (event pair around one launch)  %7.1f TF warm\n", name, warm_us, cold_us, 2.0 * M * N * K / warm_us * 1e-6);
                 const int NWG = 8192;
                 unsigned long long* dts; CHECK(hipMalloc(&dts, NWG * 8 * 8)); CHECK(hipMemsetAsync(dts, 0, NWG * 8 * 8, st));
                 ezdit_debug_gemm_timestamps(dts); run(); ezdit_debug_gemm_timestamps(nullptr);
                 CHECK(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hts(NWG * 8);
                 CHECK(hipMemcpy(hts.data(), dts, NWG * 8 * 8, hipMemcpyDeviceToHost));
-                double pro = 0, loop = 0, epi = 0; int n = 0;
-                for (int w = 0; w < NWG; ++w) { const unsigned long long* t = &hts[8 * w]; if (!t[0] || !t[3]) continue; ++n; pro += t[1] - t[0]; loop += t[2] - t[1]; epi += t[3] - t[2]; }
-                if (n) printf("      stamps (%d WGs): prologue %.0f | loop %.0f (%.1f per K tile) | epilogue %.0f\n", n, pro / n, loop / n, loop / n / (K / 64), epi / n);
+                double pro = 0, loop = 0, epi = 0, red = 0; int n = 0;
+                unsigned long long r0 = ~0ull, r1 = 0;
+                for (int w = 0; w < NWG; ++w) { const unsigned long long* t = &hts[8 * w]; if (!t[0] || !t[3]) continue; ++n; pro += t[1] - t[0]; loop += t[2] - t[1]; epi += t[3] - t[2]; if (t[4]) red += t[4] - t[2];
+                    if (t[6] < r0) r0 = t[6]; if (t[7] > r1) r1 = t[7]; }
+                if (n) printf("      stamps (%d WGs, wave 0): prologue %.0f | loop %.0f (%.1f per K tile) | epilogue %.0f (park + barrier %.0f) | first start -> last end %.2f us\n", n, pro / n, loop / n, loop / n / (K / 64), epi / n, red / n, (r1 - r0) * 0.01);
                 CHECK(hipFree(dts));
+                CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
+                fflush(stdout);
             }
             CHECK(hipFree(dh)); CHECK(hipFree(dg)); CHECK(hipFree(dz)); CHECK(hipFree(dzu)); CHECK(hipFree(dzs));
         }
