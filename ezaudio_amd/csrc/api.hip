@@ -123,9 +123,10 @@ struct ezdit_handle {
     // statistics / G' / C' loads.  profiles/r03_zfuse_*.txt; DESIGN.md section 4.  Needs gemm_pp bits 0 and 1 and the fused q projection.
     int opt_zfuse = 0;
     int opt_ztile = 70;   // producer of the LayerNorm algebra: 70-75 = K-split-inside-the-workgroup kernel (gemm_ks.h; 70 = 48 x 96 tiles), 63 = ping-pong 64 x 128
+    int opt_zfake = 0;   // DIAGNOSTIC: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
     int opt_zmlp = 1;     // MLP-out projection (K = 4 D) in front of an in / mid block on the un-split producer too (0: split-K slabs + row kernel)
     int opt_zskip = 1;    // skip_linear (K = 2 D) of the out-blocks on the un-split producer
-    int zwidth() const { return opt_ztile == 63 ? 64 : opt_ztile == 70 || opt_ztile == 72 ? 96 : opt_ztile == 75 ? 128 : 64; }   // statistics chunk = the producer's tile width
+    int zwidth() const { return opt_ztile == 75 ? 128 : opt_ztile == 71 || opt_ztile == 73 || opt_ztile == 77 ? 64 : 96; }   // statistics chunk = the producer's tile width
     int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 2;   // write-through (sc1) output stores: 0 off, 1 on, 2 = on while B L <= 2048.  The end-of-kernel write-back then has nothing left to flush: -3.5 % step time
@@ -394,6 +395,8 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         add("zt_q2", (size_t)nblk * 2 * D * 4);
         add("zA", (size_t)rup(4 * ns, 128) * h->ldD * 2);
         add("ztmp", (size_t)rup(4 * ns, 128) * nmax * 4);
+        add("zneutral", (size_t)Z_MAXP * Mp * 8);
+        add("zzeros", (size_t)nmax * 4);
     }
     return off;
 }
@@ -462,8 +465,12 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; g.xcd_qkv = h->opt_qkv_affine && h->opt_attn_xcd; }
     if (c.panel) { g.xcd_panel = 1; c.panel = false; }
+    if (!c.zG && h->opt_zfake && (epi == EPI_QKV || epi == EPI_GEGLU) && (tile == 60 || tile == 61) && (h->D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
+        g.zw = h->zwidth(); g.zstat_in = h->buf<float2>("zneutral"); g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D;
+        g.zG = h->buf<float>("zzeros"); g.zC = bias ? bias : g.zG; g.zt_slot_stride = 0; g.zeps = 1e-5f; g.rows_per_b = h->L;
+    }
     if (c.zG) {
-        g.zw = h->zwidth(); g.zstat_in = h->p.zstat; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
+        g.zw = h->zwidth(); g.zstat_in = h->p.zstat; g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
         g.cur_step = c.cur ? c.cur : h->p.ints; g.row_slot = c.cur ? c.row_slot : (h->per_row ? h->p.ints + 16 : nullptr); g.rows_per_b = h->L;
         c.zG = nullptr;
     }
@@ -687,6 +694,16 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     // zero everything once: all padding rows / columns / keys stay zero for the lifetime of the binding
     HIPCHK(hipMemsetAsync(ws, 0, need, st));
     launch_rope_table(h->buf<float>("rope_cos"), h->buf<float>("rope_sin"), h->cfg.max_len, h->dh, st);
+    {   // zfake diagnostic: statistics of a zero-mean, unit-variance row in parts of zwidth() columns
+        const int zw = h->zwidth(), parts = (h->D + zw - 1) / zw;
+        if (parts <= Z_MAXP) {
+            std::vector<float2> hst((size_t)Z_MAXP * h->Mp, make_float2(0.f, 0.f));
+            for (int k = 0; k < parts; ++k)
+                for (int r = 0; r < h->Mp; ++r) hst[(size_t)k * h->Mp + r] = make_float2(0.f, (float)(k == parts - 1 ? h->D - zw * (parts - 1) : zw));
+            HIPCHK(hipMemcpyAsync(h->buf<float2>("zneutral"), hst.data(), hst.size() * sizeof(float2), hipMemcpyHostToDevice, st));
+            HIPCHK(hipStreamSynchronize(st));
+        }
+    }
     return EZDIT_OK;
 }
 
@@ -907,7 +924,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
     const int qkv_mode = !(h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64)) ? 0
                          : ((h->opt_gemm_pp & 2) && M <= h->opt_pp_max_m && D % (2 * h->dh) == 0) ? 2 : (D % (4 * h->dh) == 0 ? 1 : 0);
-    const bool zf = h->opt_zfuse && h->z_tables_ready && M <= h->opt_pp_max_m && (h->opt_gemm_pp & 1) && h->geglu_tile < 0 && qkv_mode == 2 &&
+    const bool zf = h->opt_zfuse && h->z_tables_ready && h->opt_ztile >= 70 && (D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP && M <= h->opt_pp_max_m && (h->opt_gemm_pp & 1) && h->geglu_tile < 0 && qkv_mode == 2 &&
                     h->opt_fuse_q2 && ((long)h->B * h->H * ((h->L + 63) / 64) <= 512 || h->opt_fuse_q2 == 2) && h->Lcp % 128 == 0;
     auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
                        const float* zg, long zg_stride) {
@@ -918,7 +935,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.xcd_map = h->opt_xcd_map; g.wt = h->wt(); g.debug = h->opt_gemm_debug;
         g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
-        g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat;
+        g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat; g.zs_stride = h->Mp;
         g.ts = c.stamps();
         c.launched("k_gemm (un-split residual)", launch_gemm(g, st));
         u_is_z = true;
@@ -961,7 +978,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            if (zf && h->opt_zskip && h->opt_ztile >= 70) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot);
+            if (zf && h->opt_zskip) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot);
             else resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
@@ -1027,8 +1044,12 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
             at.xw_rows = w.wq2.rows; at.xK = at.ldw;
             at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
+            if (!u_is_z && h->opt_zfake && (D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
+                at.zw = h->zwidth(); at.zstat_in = h->buf<float2>("zneutral"); at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
+                at.zG = h->buf<float>("zzeros"); at.zC = at.zG;
+            }
             if (u_is_z) {
-                at.zw = h->zwidth(); at.zstat_in = p.zstat; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
+                at.zw = h->zwidth(); at.zstat_in = p.zstat; at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
                 at.zG = p.zt_q2 + (long)b * 2 * D; at.zC = at.zG + D;
             }
         } else {
@@ -1351,11 +1372,10 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
         // C' = bias): same results as the plain epilogue up to the factor rsqrt(1 + 1e-5), same code path and memory traffic as the real thing
         static float2* zs = nullptr; static float* zg0 = nullptr; static float* zc = nullptr; static size_t cap_rows = 0, cap_n = 0;
         const size_t rows = (size_t)rup(M, 128), nn = (size_t)rup(N, 128);
-        if (rows > cap_rows) { if (zs) (void)hipFree(zs); HIPCHK(hipMalloc(&zs, rows * 18 * sizeof(float2))); cap_rows = rows;
-            std::vector<float2> hst(rows * 18, make_float2(0.f, 64.f)); HIPCHK(hipMemcpy(zs, hst.data(), hst.size() * sizeof(float2), hipMemcpyHostToDevice)); }
-        if (nn > cap_n) { if (zg0) (void)hipFree(zg0); if (zc) (void)hipFree(zc); HIPCHK(hipMalloc(&zg0, nn * 4)); HIPCHK(hipMalloc(&zc, nn * 4)); cap_n = nn; HIPCHK(hipMemset(zg0, 0, nn * 4)); }
-        if (bias) HIPCHK(hipMemcpyAsync(zc, bias, (size_t)N * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream)); else HIPCHK(hipMemsetAsync(zc, 0, nn * 4, (hipStream_t)stream));
-        g.zstat_in = zs; g.zparts = 18; g.zD = 1152; g.zw = 64; g.zG = zg0; g.zC = zc; g.zt_slot_stride = 0; g.zeps = 1e-5f;
+        if (rows > cap_rows) { if (zs) (void)hipFree(zs); HIPCHK(hipMalloc(&zs, rows * 12 * sizeof(float2))); cap_rows = rows;
+            std::vector<float2> hst(rows * 12, make_float2(0.f, 96.f)); HIPCHK(hipMemcpy(zs, hst.data(), hst.size() * sizeof(float2), hipMemcpyHostToDevice)); }
+        if (nn > cap_n) { if (zg0) (void)hipFree(zg0); if (zc) (void)hipFree(zc); HIPCHK(hipMalloc(&zg0, nn * 4)); HIPCHK(hipMalloc(&zc, nn * 4)); cap_n = nn; HIPCHK(hipMemset(zg0, 0, nn * 4)); HIPCHK(hipMemset(zc, 0, nn * 4)); }
+        g.zstat_in = zs; g.zs_stride = (long)cap_rows; g.zparts = 12; g.zD = 1152; g.zw = 96; g.zG = zg0; g.zC = bias ? bias : zc;   // C' = the bias itself: no copy in the timed path g.zt_slot_stride = 0; g.zeps = 1e-5f;
         g.debug &= ~64;
     }
     if (g.epi > EPI_GEGLU || g.tile > 127) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
@@ -1377,7 +1397,7 @@ int ezdit_test_resid(int tile, const void* A, int lda, const void* W, int ldw, c
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias;
     g.out = h_out; g.ldo = N; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_RESID; g.tile = tile; g.xcd_map = 1;
     g.resid = h_in; g.ldr = N; g.gate = gate; g.rows_per_b = 1;
-    g.zu = (bf16_t*)zu; g.ld_zu = ld_zu; g.zg = zg; g.zstat_out = (float2*)zstat;
+    g.zu = (bf16_t*)zu; g.ld_zu = ld_zu; g.zg = zg; g.zstat_out = (float2*)zstat; g.zs_stride = M;   // zstat [N tiles][M]
     g.ts = g_gemm_ts;
     (void)hipGetLastError();
     if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "residual GEMM configuration not supported");
@@ -1455,6 +1475,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
     else if (!strcmp(name, "ztile")) h->opt_ztile = value;
     else if (!strcmp(name, "zmlp")) h->opt_zmlp = value;
+    else if (!strcmp(name, "zfake")) h->opt_zfake = value;
     else if (!strcmp(name, "zskip")) h->opt_zskip = value;
     else if (!strcmp(name, "pp_max_m")) h->opt_pp_max_m = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

@@ -48,7 +48,9 @@ struct HeadGeom<72> { static constexpr int DQK = 80, DV = 96; };
 // NKH = key sub-blocks (of 32 keys) per staged tile = waves per query sub-block.  2: 64-key tiles, 4 waves.  4: 128-key tiles,
 // 8 waves -- twice the waves per CU (one prompt = one workgroup per CU, so a SIMD otherwise hosts a single wave and its
 // softmax VALU work never overlaps MFMAs) and half the tile-loop trips; needs Lkp % 128 == 0.
-template <int DH, int NKH>
+// ZQ: the fused projection finishes a LayerNorm in its epilogue (LayerNorm algebra, AttnArgs.z*): a template switch so that the plain kernel
+// carries neither the registers nor the code
+template <int DH, int NKH, bool ZQ = false>
 __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int NT = 128 * NKH;
     constexpr int TK = 32 * NKH;   // keys per staged tile
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int PSTAGE = (64 + DN) * 128, PRING = 6 * PSTAGE;   // 3 ring slots of TWO K tiles each (a.xk2) or 3 of one
     constexpr int PRED = 4 * 64 * DS * 4, PQS = 64 * DQK * 2;
     constexpr int SMEM = NKH == 4 ? (2 * BUF > PRED + PQS ? (2 * BUF > PRING ? 2 * BUF : PRING) : (PRED + PQS > PRING ? PRED + PQS : PRING)) : 2 * BUF;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    constexpr int ZX = ZQ ? 64 * 8 + 2 * DQK * 4 : 0;   // fused projection with the LayerNorm algebra: (mu, r) of the 64 query rows + G' | C' of the head
+    __shared__ __attribute__((aligned(16))) char smem[SMEM + ZX];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,35 +114,23 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             constexpr int FN = DN / 32;
             const int mh = wave & 1, kq = wave >> 1;
             const int rowb = b * a.Lq;
-            // LayerNorm algebra: (mu, r) of the operand row that query row (tid >> 3) of this tile is projected from, requested NOW (every
-            // chunk up front) so that the loads land under the projection's K loop; used in phase 1b
-            float zmu = 0.f, zr = 1.f;
-            if (a.zstat_in) {   // 8 threads per row (the phase-1b thread layout): thread q takes the chunks q, q + 8, ...; all 8 end up with (mu, r)
-                constexpr int NK = 5;   // up to 40 chunks
-                const int q = tid & 7;
-                int qr = qt * 64 + (tid >> 3);
-                qr = qr < a.Lq ? qr : a.Lq - 1;
-                const float2* st = a.zstat_in + (long)(rowb + qr) * a.zparts;
-                float2 sv[NK];
-#pragma unroll
-                for (int k = 0; k < NK; ++k) sv[k] = st[q + 8 * k < a.zparts ? q + 8 * k : 0];
-                const int nlast = a.zD - a.zw * (a.zparts - 1);
-                const float inv_last = 1.f / (float)nlast, inv_cw = 1.f / (float)a.zw, inv_d = 1.f / (float)a.zD;
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) s += q + 8 * k < a.zparts ? sv[k].x : 0.f;
-                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-                zmu = s * inv_d;
-                float m2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const int p = q + 8 * k;
-                    const bool last = p == a.zparts - 1;
-                    const float d = sv[k].x * (last ? inv_last : inv_cw) - zmu;
-                    m2 += p < a.zparts ? fmaf(last ? (float)nlast : (float)a.zw, d * d, sv[k].y) : 0.f;
+            // LayerNorm algebra: the partial statistics of the 64 operand rows of this tile (wave 0: one row per lane, part-major table: every
+            // load is one contiguous 512-byte run) and G' | C' of this head's columns (one float4 per thread of wave 1) are requested NOW, land
+            // under the projection's K loop, and are merged / parked in LDS behind the loop's last barrier; used in phase 1b
+            float2* zrow_l = reinterpret_cast<float2*>(smem + SMEM);            // [64] (mu, r)
+            float* zgc_l = reinterpret_cast<float*>(smem + SMEM + 64 * 8);      // [2][DQK] G' | C'
+            ZStatRegs zst;
+            float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (ZQ) {
+                if (tid < 64) {
+                    int qr = qt * 64 + tid;
+                    qr = qr < a.Lq ? qr : a.Lq - 1;
+                    z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, zst);
                 }
-                m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
-                zr = rsqrtf(m2 * inv_d + a.zeps);
+                if (tid < 2 * (DH / 4)) {
+                    const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
+                    zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + h * DH + 4 * t4);
+                }
             }
             uint32_t aoff[1], boff[(DW * 8 + NT - 1) / NT];
             stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
@@ -218,6 +209,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[j]));
+            if constexpr (ZQ) {   // behind the two barriers below: read in phase 1b
+                if (tid < 64) zrow_l[tid] = z_row_stats_finish(zst, a.zparts, a.zD, a.zeps);
+                if (tid < 2 * (DH / 4)) {
+                    const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
+                    *reinterpret_cast<float4*>(zgc_l + which * DQK + 4 * t4) = zgc_reg;
+                }
+            }
             __syncthreads();   // the ring is dead: it becomes the reduction area
             // lane owns row 32 mh + r32 and columns 32 j + 8 g + 4 hi + {0..3}
             float* red = reinterpret_cast<float*>(smem);   // [kq][64][DS]
@@ -238,12 +236,14 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 const int row = tid >> 3, part = tid & 7;
                 float v[CP];
                 float s1 = 0.f;
+                const float2 zmr = ZQ ? zrow_l[row] : make_float2(0.f, 1.f);
+                const float zmu = zmr.x, zr = zmr.y;
 #pragma unroll
                 for (int e = 0; e < CP; ++e) {
                     const int col = part * CP + e;
                     v[e] = red[(0 * 64 + row) * DS + col] + red[(1 * 64 + row) * DS + col] + red[(2 * 64 + row) * DS + col] +
                            red[(3 * 64 + row) * DS + col];
-                    if (a.zstat_in) v[e] = fmaf(zr, v[e], fmaf(-zr * zmu, a.zG[h * DH + col], a.zC[h * DH + col]));
+                    if constexpr (ZQ) v[e] = fmaf(zr, v[e], fmaf(-zr * zmu, zgc_l[col], zgc_l[DQK + col]));
                     s1 += v[e];
                 }
                 s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
@@ -574,11 +574,15 @@ int launch_attention(const AttnArgs& a0, hipStream_t st) {
     if (a.Lkp % 128) nkh = 2;
     if (a.xu && nkh != 4) return 1;   // the fused projection exists in the 8-wave form only (needs Lkp % 128 == 0)
     if (a.dh != 64 && a.dh != 72) return 1;
+    const bool zq = a.xu && a.zstat_in;
+    if (zq && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
     if (a.dh == 64) {
-        if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);
+        if (nkh == 4 && zq) hipLaunchKernelGGL((k_attn<64, 4, true>), grid, dim3(512), 0, st, a);
+        else if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attn<64, 2>), grid, dim3(256), 0, st, a);
     } else {
-        if (nkh == 4) hipLaunchKernelGGL((k_attn<72, 4>), grid, dim3(512), 0, st, a);
+        if (nkh == 4 && zq) hipLaunchKernelGGL((k_attn<72, 4, true>), grid, dim3(512), 0, st, a);
+        else if (nkh == 4) hipLaunchKernelGGL((k_attn<72, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((k_attn<72, 2>), grid, dim3(256), 0, st, a);
     }
     return 0;

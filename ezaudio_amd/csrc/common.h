@@ -55,8 +55,8 @@ enum GemmEpi {
     EPI_F32 = 0,      // out fp32 [M][ldo] = acc (+ bias[col])
     EPI_PARTIAL = 1,  // out fp32 slab z: [z][Mp][ldo] = acc          (split-K partials)
     EPI_GEGLU = 2,    // out bf16 [M][ldo]: (val + b) * gelu_erf(gate + b), W rows interleaved 8 value / 8 gate
-    // un-split residual GEMM of the ping-pong kernel: out (fp32) = resid + gate * (acc + bias) as EPI_F32, AND the bf16 operand of the next
-    // GEMM, A' = h_new * zg (the LayerNorm gain only), AND per-(row, 64-column chunk) partial statistics of h_new: the LayerNorm itself
+    // un-split residual GEMM (k_gemm_ks): out (fp32) = resid + gate * (acc + bias) as EPI_F32, AND the bf16 operand of the next
+    // GEMM, A' = h_new * zg (the LayerNorm gain only), AND per-(row, column tile) partial statistics of h_new: the LayerNorm itself
     // is finished by the CONSUMER (GemmArgs.z*, "LN algebra" in DESIGN.md).  Replaces split-K slabs + the row kernel.
     EPI_RESID = 4,
     EPI_QKV = 3       // fused q|k|v projection (tile 64 x 4 whole heads: 64x288 for head_dim 72, 64x256 for 64): per-head LayerNorm + RoPE of q / k and
@@ -65,6 +65,40 @@ enum GemmEpi {
 
 // ---- LDS-DMA staging of a bf16 operand tile with K = 64 (one 128-byte LDS row per tile row), shared by gemm.hip and attn.hip ----
 constexpr int BK = 64;
+constexpr int Z_MAXP = 12;   // LayerNorm algebra: column tiles (partial statistics) a row may have: D <= 12 x the producer's tile width (1152 = 12 x 96)
+
+// ---- LayerNorm algebra (GemmArgs.z*), consumer side: (mu, r) of one row from the partial statistics its producer left per column tile:
+// (S_k, Q_k) = (sum, sum of squares) of the row over the tile's columns, so that merging is two plain sums:
+//      mu = sum_k S_k / D,   var = sum_k Q_k / D - mu^2
+// (the textbook one-pass form: its relative error on var is eps_fp32 (1 + mu^2 / var) -- harmless while a row's mean is not orders of
+// magnitude above its spread, which holds for the residual stream; the (sum, M2-about-the-tile-mean) form of round 3 needed a 12-term Chan
+// merge with a data-dependent correction per part: 130 instructions on the one wave every other wave of the workgroup waits for).
+// The statistics are stored PART-MAJOR ([part][row], GemmArgs.zs_stride rows apart): ONE thread per row loads the row's parts (consecutive
+// lanes = consecutive rows: every load instruction is one contiguous 512-byte run) at kernel start and merges them after the K loop --
+// nothing at kernel start waits on them (round 3 let four threads per row gather 8-byte pieces of a row-major table and wait for them
+// before the first LDS-DMA went out).
+struct ZStatRegs { float2 v[Z_MAXP]; };
+// The loads are UNCONDITIONAL (part index clamped) and their results are not touched here: a select on a loaded value made hipcc wait for
+// the loads at kernel start, in front of the first LDS-DMA (k_attn: +1.7 us per launch); the unused parts are masked in z_row_stats_finish
+__device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st /* + row */, long stride, int parts, ZStatRegs& z) {
+#pragma unroll
+    for (int k = 0; k < Z_MAXP; ++k) z.v[k] = st[(k < parts ? k : parts - 1) * stride];
+}
+__device__ __forceinline__ float2 z_row_stats_finish(ZStatRegs& z, int parts, int D, float eps) {
+    // nothing below may be hoisted above this point (hipcc moved the first addition up to the loads and waited for them at kernel start)
+#pragma unroll
+    for (int k = 0; k < Z_MAXP; ++k) asm volatile("" : "+v"(z.v[k].x), "+v"(z.v[k].y));
+    const float inv_d = __builtin_amdgcn_rcpf((float)D);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < Z_MAXP; ++k) {   // fixed order: bit-reproducible
+        s += k < parts ? z.v[k].x : 0.f;
+        q += k < parts ? z.v[k].y : 0.f;
+    }
+    const float mu = s * inv_d;
+    const float var = fmaxf(fmaf(q, inv_d, -mu * mu), 0.f);
+    return make_float2(mu, rsqrtf(var + eps));
+}
 
 // Per-thread byte offsets of the 16-byte chunks this thread stages for one operand tile (K offset excluded): computed
 // ONCE per workgroup.  Chunk q of the tile = (row q>>3, 16-byte slot q&7); the slot is filled from global chunk
@@ -163,9 +197,10 @@ struct GemmArgs {
     // producer (EPI_RESID):
     bf16_t* zu; int ld_zu;                      // A' [M][ld_zu]
     const float* zg; long zg_slot_stride;       // LayerNorm gain of the consumer (per slot when the stride is non-zero)
-    float2* zstat_out;                          // [M][N tiles]: (sum, M2 about the chunk mean) of h_new over the columns of each N tile (k_gemm_ks: 96; k_gemm_pp: 64-column chunks)
+    float2* zstat_out;                          // [N tiles][zs_stride]: (sum, sum of squares) of h_new over the columns of each N tile, PART-MAJOR
+    long zs_stride;                             // rows (elements) between the parts of zstat_out / zstat_in
     // consumer (EPI_QKV, EPI_GEGLU; null zstat_in = plain GEMM):
-    const float2* zstat_in; int zparts; int zD; int zw; // [M][zparts] partial statistics of the operand's rows: zparts = ceil(zD / zw) chunks of zw columns (the last one ragged; zw = the producer's tile width)
+    const float2* zstat_in; int zparts; int zD; int zw; // [zparts][zs_stride] partial statistics of the operand's rows: zparts = ceil(zD / zw) <= Z_MAXP parts of zw columns (the last one ragged; zw = the producer's tile width)
     const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]
     float zeps;
     unsigned long long* ts;   // test hook (k_gemm_pp): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
@@ -196,7 +231,7 @@ struct AttnArgs {
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
     // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)
     // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)
-    const float2* zstat_in; int zparts; int zD; int zw; const float* zG; const float* zC; float zeps;
+    const float2* zstat_in; long zs_stride; int zparts; int zD; int zw; const float* zG; const float* zC; float zeps;   // zstat_in [zparts][zs_stride], part-major
     unsigned long long* ts;     // test hook: [workgroup][8] shader-clock stamps (start, operands staged, tile loop end, merge end, end), nullable
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported

@@ -728,13 +728,16 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
-// K-split-inside-the-workgroup kernel (gemm_ks.h): 8 waves, each with a private LDS slot for its own K chunks, no barrier in the K loop
-template <int FM, int FN, int EPI, bool GATE, bool RES>
+// K-split-inside-the-workgroup kernel (gemm_ks.h): 8 waves, each with private LDS slots for its own K chunks, no barrier in the K loop
+template <int FM, int FN, int EPI, bool GATE, bool RES, int CK>
 int launch_ks(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.xcd_qkv = 0; a.xcd_panel = 0; a.splitk = 1;
     constexpr int BM = 16 * FM, BN = 16 * FN;
-    dim3 grid(pick_boxes(a, BM, BN), 1, 1);
+    (void)pick_boxes(a, BM, BN);   // pm x pn XCD boxes with the smallest operand footprint; the tiles of an N group are then dealt in equal runs (ks_tile_of_block)
+    const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
+    const int gw = a.bn < tilesN ? a.bn : tilesN;
+    dim3 grid(8 * ((tilesM * gw + a.pm - 1) / a.pm), 1, 1);
     constexpr int SMEM = 8 * (BM + BN) * 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     static std::atomic<bool> attr_set[32];   // per (kernel, device)
@@ -742,22 +745,25 @@ int launch_ks(const GemmArgs& a0, hipStream_t st) {
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return 1;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES, CK>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
         attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES>), grid, dim3(512), SMEM, st, a);
+    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES, CK>), grid, dim3(512), SMEM, st, a);
     return 0;
 }
-// tile ids of the K-split kernel: 70 = 48 x 96 (21 x 12 = 252 workgroups at M = 1000, N = 1152), 71 = 64 x 64, 72 = 32 x 96, 73 = 48 x 64, 75 = 32 x 128
+// tile ids of the K-split kernel: 70 = 48 x 96 (21 x 12 = 252 workgroups at M = 1000, N = 1152), 71 = 64 x 64, 72 = 32 x 96, 73 = 48 x 64,
+// 75 = 32 x 128 with one 64-wide K chunk per wave in flight; 76 = 48 x 96, 77 = 48 x 64 with two 32-wide chunks per wave
 template <int EPI, bool GATE, bool RES>
 int launch_ks_tile(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
-        case 70: return launch_ks<3, 6, EPI, GATE, RES>(a, st);
-        case 71: return launch_ks<4, 4, EPI, GATE, RES>(a, st);
-        case 72: return launch_ks<2, 6, EPI, GATE, RES>(a, st);
-        case 73: return launch_ks<3, 4, EPI, GATE, RES>(a, st);
-        case 75: return launch_ks<2, 8, EPI, GATE, RES>(a, st);
+        case 70: return launch_ks<3, 6, EPI, GATE, RES, 64>(a, st);
+        case 71: return launch_ks<4, 4, EPI, GATE, RES, 64>(a, st);
+        case 72: return launch_ks<2, 6, EPI, GATE, RES, 64>(a, st);
+        case 73: return launch_ks<3, 4, EPI, GATE, RES, 64>(a, st);
+        case 75: return launch_ks<2, 8, EPI, GATE, RES, 64>(a, st);
+        case 76: return launch_ks<3, 6, EPI, GATE, RES, 32>(a, st);
+        case 77: return launch_ks<3, 4, EPI, GATE, RES, 32>(a, st);
         default: return 1;
     }
 }
@@ -822,6 +828,7 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 //   61  128x144  4x1 per group        ring 4  144 KB  k_gemm_pp SCHED 2 (k-split); fused QKV GEMM (two heads of 72 per tile)
 //   62  128x128  4x2 (32x64)          ring 3   96 KB  k_gemm_pp SCHED 1
 //   63  64x128   2x2 per group        ring 4   96 KB  k_gemm_pp SCHED 2
+//   70-77  k_gemm_ks (K split over the waves of a workgroup, no ring): see launch_ks_tile
 //   64  128x144  4x1 per group        ring 3  108 KB  k_gemm_pp SCHED 2
 //   65  128x128  2x2 per group (64x64) ring 4 128 KB  k_gemm_pp SCHED 2
 template <int EPI>
@@ -870,7 +877,7 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.K <= 0 || a.K % BK) return 1;
     if (a.epi == EPI_QKV && a.tile >= 60) {   // ping-pong kernel, k-split schedule: 128 x (2 whole heads), ring 4
-        if (a.zstat_in && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= 40)) return 1;
+        if (a.zstat_in && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
         if (a.hn.dh == 72) return a.zstat_in ? launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2, 64>(a, st) : launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2>(a, st);
         if (a.hn.dh == 64) return a.zstat_in ? launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2, 64>(a, st) : launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2>(a, st);
         return 1;
@@ -881,7 +888,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         return 1;
     }
     if (a.epi == EPI_RESID && a.tile >= 70) {   // K-split-inside-the-workgroup kernel: residual (optional) + gate (optional) + statistics + next operand
-        if (!a.zu || !a.zg || !a.zstat_out || !a.out || a.splitk != 1 || (a.gate && !a.resid)) return 1;
+        if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.out || !a.bias || a.splitk != 1 || (a.gate && !a.resid)) return 1;
         if (a.gate) return launch_ks_tile<EPI_RESID, true, true>(a, st);
         if (a.resid) return launch_ks_tile<EPI_RESID, false, true>(a, st);
         return launch_ks_tile<EPI_RESID, false, false>(a, st);
@@ -890,13 +897,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         if (a.resid || a.conv_cpb) return 1;
         return launch_ks_tile<EPI_F32, false, false>(a, st);
     }
-    if (a.epi == EPI_RESID) {   // un-split residual projection of the ping-pong kernel (k-split schedule, 64 x 128 tiles, ring 4)
-        if (!a.zu || !a.zg || !a.zstat_out || !a.out || !a.bias || !a.resid || a.splitk != 1) return 1;
-        if (a.debug & 1) return a.gate ? launch_pp<64, 128, 2, 2, 4, EPI_RESID, 2, 64>(a, st) : launch_pp<64, 128, 2, 2, 4, EPI_RESID, 2>(a, st);   // A/B: ring 4
-        return a.gate ? launch_pp<64, 128, 2, 2, 6, EPI_RESID, 2, 64>(a, st) : launch_pp<64, 128, 2, 2, 6, EPI_RESID, 2>(a, st);
-    }
+    if (a.epi == EPI_RESID) return 1;   // the K-split kernel is the only producer
     if (a.epi == EPI_GEGLU && a.zstat_in) {   // GEGLU GEMM that finishes the LayerNorm of its operand (LayerNorm algebra): ping-pong kernel only
-        if (a.tile != 60 || !(a.zG && a.zC && a.zparts > 0 && a.zparts <= 40)) return 1;
+        if (a.tile != 60 || !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
         return launch_pp<128, 288, 4, 2, 3, EPI_GEGLU, 1, 64>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);

@@ -37,14 +37,41 @@ __device__ __forceinline__ int ks_slot_of(int q, int j) {
     return q < 2 * NP ? 16 * (q >> 1) + 2 * j + (q & 1) : 16 * NP + j;
 }
 
-template <int FM, int FN, int EPI, bool GATE, bool RES>
+// workgroup -> tile map of the K-split kernel: the N tiles are cut into a.pn groups of a.bn tiles, the (M tile, N tile) pairs of a group are
+// linearised M-major and dealt in a.pm equal contiguous runs to the a.pm XCDs of the group (XCD = blockIdx % 8): every XCD sees a.bn weight
+// panels and 1 / a.pm of the rows like the box map (tile_of_block), but no XCD gets more than ceil(tiles of a group / a.pm) workgroups --
+// 21 x 12 tiles on 2 x 4 boxes are 33 / 30 tiles per XCD, i.e. a SECOND ROUND on the 32 CUs of four XCDs; the runs are 32 / 31
+__device__ __forceinline__ bool ks_tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn) {
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int xm = xcd % a.pm, gn = xcd / a.pm;
+    const int n0 = gn * a.bn;
+    int gw = tilesN - n0;                          // N tiles of this group
+    gw = gw < a.bn ? gw : a.bn;
+    if (gw <= 0) return false;
+    const int T = tilesM * gw, run = (T + a.pm - 1) / a.pm;
+    const int t = xm * run + l;
+    if (l >= run || t >= T) return false;
+    tm = t / gw;
+    tn = n0 + t % gw;
+    return true;
+}
+
+// CK = K columns per chunk: 64 (one slot per wave) or 32 (two slots per wave: one is always in flight)
+template <int FM, int FN, int EPI, bool GATE, bool RES, int CK>
 __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     static_assert(EPI == EPI_F32 || EPI == EPI_RESID, "epilogues");
     static_assert(FN % 2 == 0 && FM >= 1 && FM <= 4, "tile geometry: 8 lanes per output row, FN / 2 column slots each");
+    static_assert(CK == 64 || CK == 32, "chunk width");
     constexpr int BM = 16 * FM, BN = 16 * FN;
-    constexpr int NPC = (BM + BN) / 8;             // 1-KB LDS-DMA pieces per chunk
-    constexpr int PA = BM / 8;                     // pieces [0, PA) come from A
-    constexpr int SLOT = (BM + BN) * 128;          // bytes of a wave's slot = one K chunk = (after the loop) its partial tile [BM][BN] fp32
+    constexpr int RPP = 1024 / (2 * CK);           // rows per 1-KB LDS-DMA piece: 8 (128-byte rows) or 16 (64-byte rows)
+    constexpr int LPR = 64 / RPP;                  // lanes per row of a piece
+    constexpr int NPC = (BM + BN) / RPP;           // pieces per chunk
+    constexpr int PA = BM / RPP;                   // pieces [0, PA) come from A
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "whole pieces");
+    constexpr int NSL = 64 / CK;                   // slots per wave
+    constexpr int CHUNK = (BM + BN) * 2 * CK;      // bytes of a chunk
+    constexpr int SLOT = NSL * CHUNK;              // bytes of a wave's LDS region = NSL chunks = (after the loop) its partial tile [BM][BN] fp32
+    constexpr int KSTEPS = CK / 32;                // MFMA k-steps per chunk
     static_assert(BM * BN * 4 <= SLOT, "partial tile must fit the slot");
     static_assert(8 * SLOT <= 160 * 1024, "LDS budget of a CU");
     constexpr int SL = FN / 2;                     // 16-byte column slots per thread in the epilogue
@@ -57,71 +84,58 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
 
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
-    int tm, tn, z;
-    if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
+    int tm, tn;
+    if (!ks_tile_of_block(a, tilesM, tilesN, tm, tn)) return;
     const int row0 = tm * BM, col0 = tn * BN;
-    const int nk = a.K / BK;
+    const int nk = a.K / CK;
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
     if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }
 
-    // ---- epilogue operands: thread (row er, lane-in-row ej) of the first 8 BM threads; requested NOW, in front of the first LDS-DMA (vector
-    // memory returns in issue order, so the first chunk's wait covers them) and carried through the K loop in registers
+    // epilogue thread layout: (row er, lane-in-row ej) of the first 8 BM threads
     const int er = tid >> 3, ej = tid & 7;
     const bool epi_thread = tid < 8 * BM;
     int erow = row0 + er;
     const bool row_ok = epi_thread && erow < a.M;
     erow = erow < a.M ? erow : a.M - 1;
     const int ncl = a.N - 4;                       // N is a multiple of 4 for every caller
-    KsOperands<SL> op = {};
-    if (epi_thread) {
-        int slot = 0;
-        if constexpr (EPI == EPI_RESID) slot = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[erow / a.rows_per_b] : 0);
-#pragma unroll
-        for (int q = 0; q < SL; ++q) {
-            int col = col0 + 4 * ks_slot_of<SL>(q, ej);
-            col = col < ncl ? col : ncl;
-            op.b[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (EPI == EPI_RESID) {
-                if constexpr (RES) op.r[q] = *reinterpret_cast<const float4*>(a.resid + (long)erow * a.ldr + col);
-                if constexpr (GATE) op.g[q] = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
-                op.z[q] = *reinterpret_cast<const float4*>(a.zg + (long)slot * a.zg_slot_stride + col);
-            }
-        }
-    }
 
     // ---- loop-invariant addressing: byte offset of this lane's 16 bytes of piece p (K offset excluded)
     uint32_t poff[NPC];
 #pragma unroll
     for (int p = 0; p < NPC; ++p) {
-        const int row = 8 * p + (lane >> 3), c = lane & 7;
+        const int row = RPP * p + lane / LPR, c = lane % LPR;
+        // bank swizzle on the source: 128-byte rows: slot c ^ ((row >> 1) & 7); 64-byte rows (four rows span the 64 banks): c ^ ((row >> 2) & 3)
+        const int r2 = p < PA ? row : row - BM;
+        const int gc = CK == 64 ? (c ^ ((r2 >> 1) & 7)) : (c ^ ((r2 >> 2) & 3));
         if (p < PA) {
             int grow = row0 + row;
             grow = grow < a.M ? grow : a.M - 1;
-            poff[p] = (uint32_t)(grow * a.lda + ((c ^ ((row >> 1) & 7)) << 3)) * 2u;
+            poff[p] = (uint32_t)(grow * a.lda + (gc << 3)) * 2u;
         } else {
-            const int r2 = row - BM;
             int gr = col0 + r2;
             gr = gr < a.wrows ? gr : a.wrows - 1;
-            poff[p] = (uint32_t)(gr * a.ldw + ((c ^ ((r2 >> 1) & 7)) << 3)) * 2u;
+            poff[p] = (uint32_t)(gr * a.ldw + (gc << 3)) * 2u;
         }
     }
     const char* gA = reinterpret_cast<const char*>(a.A);
     const char* gW = reinterpret_cast<const char*>(a.W);
     char* slot = smem + wave * SLOT;               // wave-uniform
-    auto issue = [&](int c) {
-        const long koff = (long)c * (BK * 2);
+    auto issue = [&](int c, char* dst) {           // chunk c (K columns [c CK, (c + 1) CK)) -> LDS at dst
+        const long koff = (long)c * (CK * 2);
 #pragma unroll
         for (int p = 0; p < NPC; ++p) {
             const char* src = (p < PA ? gA : gW) + koff + poff[p];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(slot + p * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
         }
     };
-    // fragment read offsets (k_gemm_pp): row (lane & 15) of a 16-row fragment, k-step ks (32 of K) -> 16-byte slot (4 ks + (lane >> 4)) ^ ((row >> 1) & 7)
+    // fragment read offsets (k_gemm_pp): row (lane & 15) of a 16-row fragment, k-step ks (32 of K) -> the swizzled 16-byte slot of that row
     const int r16 = lane & 15, kq = lane >> 4;
-    uint32_t foff[2];
+    uint32_t foff[KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = r16 * 128 + (((4 * ks + kq) ^ (r16 >> 1)) << 4);
+    for (int ks = 0; ks < KSTEPS; ++ks)
+        foff[ks] = CK == 64 ? r16 * 128 + (((4 * ks + kq) ^ (r16 >> 1)) << 4) : r16 * 64 + ((kq ^ ((r16 >> 2) & 3)) << 4);
+    constexpr int FRAG = 16 * 2 * CK;              // bytes of a 16-row fragment
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -129,34 +143,70 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int c = wave;
-    if (c < nk) issue(c);
+    // chunks of this wave: wave, wave + 8, ...; chunk number i lives in slot i % NSL
+    const int nmine = wave < nk ? (nk - wave + 7) / 8 : 0;
+#pragma unroll
+    for (int i = 0; i < NSL; ++i)
+        if (i < nmine) issue(wave + 8 * i, slot + i * CHUNK);
+    // ---- epilogue operands (bias, residual rows, gate, LayerNorm gain), requested BEHIND the first chunks -- their addresses need the device
+    // step counter, a scalar round trip that sat in front of the first LDS-DMA (2.6 us from kernel start to the first piece in situ) -- and
+    // carried through the K loop in registers.  EVERY thread issues them (rows / columns clamped; the threads beyond the 8 BM epilogue threads
+    // never use theirs) so that each wave has exactly NOPL loads behind its prologue chunks: the counted waits below rely on it
+    constexpr int NOPL = SL * (1 + (EPI == EPI_RESID ? 1 + (RES ? 1 : 0) + (GATE ? 1 : 0) : 0));
+    KsOperands<SL> op = {};
+    {
+        int slot_m = 0;
+        if constexpr (EPI == EPI_RESID) slot_m = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[erow / a.rows_per_b] : 0);
+        const float* bsrc = a.bias ? a.bias : reinterpret_cast<const float*>(a.W);   // null bias: any valid address, the value is dropped below
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            int col = col0 + 4 * ks_slot_of<SL>(q, ej);
+            col = col < ncl ? col : ncl;
+            op.b[q] = *reinterpret_cast<const float4*>(bsrc + col);
+            if constexpr (EPI == EPI_RESID) {
+                if constexpr (RES) op.r[q] = *reinterpret_cast<const float4*>(a.resid + (long)erow * a.ldr + col);
+                if constexpr (GATE) op.g[q] = *reinterpret_cast<const float4*>(a.gate + (long)slot_m * a.gate_slot_stride + col);
+                op.z[q] = *reinterpret_cast<const float4*>(a.zg + (long)slot_m * a.zg_slot_stride + col);
+            }
+        }
+    }
     if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
-    for (; c < nk; c += 8) {
-        // own LDS-DMA landed (nothing else orders a ds_read behind it); no other wave touches this slot: no barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bf16x8 af[FM][2], bfr[FN][2];
+    for (int i = 0; i < nmine; ++i) {
+        // own LDS-DMA of chunk i landed (nothing else orders a ds_read behind it): wait until only the loads issued AFTER it are outstanding
+        // -- the operand loads (behind the NSL prologue chunks) and, with two slots, the next chunk.  No other wave touches this slot: no barrier
+        {
+            const bool nxt = NSL == 2 && i + 1 < nmine;
+            if (i < NSL) {
+                if (nxt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC + NOPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NOPL) : "memory");
+            } else {
+                if (nxt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        char* cur = slot + (NSL == 2 ? (i & 1) * CHUNK : 0);
+        bf16x8 af[FM][KSTEPS], bfr[FN][KSTEPS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i][ks] = *reinterpret_cast<const bf16x8*>(slot + foff[ks] + i * 2048);
+            for (int ii = 0; ii < FM; ++ii) af[ii][ks] = *reinterpret_cast<const bf16x8*>(cur + foff[ks] + ii * FRAG);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j][ks] = *reinterpret_cast<const bf16x8*>(slot + BM * 128 + foff[ks] + j * 2048);
+            for (int j = 0; j < FN; ++j) bfr[j][ks] = *reinterpret_cast<const bf16x8*>(cur + BM * 2 * CK + foff[ks] + j * FRAG);
         }
         // the reads must have returned before the refill may overwrite the slot
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 8 < nk) issue(c + 8);
+        if (i + NSL < nmine) issue(wave + 8 * (i + NSL), cur);
         __builtin_amdgcn_sched_barrier(0);
         // transposed product (W fragment as the A operand): a lane owns output row lane & 15 and columns 4 (lane >> 4) + {0..3} of a fragment
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int ii = 0; ii < FM; ++ii)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(bfr[j][ks]), "v"(af[i][ks]));
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ii][j]) : "v"(bfr[j][ks]), "v"(af[ii][ks]));
     }
     if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
     // the last MFMA's result is not interlocked against the reads below (inline asm): 20 wait states tied to the accumulators
@@ -205,7 +255,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
-            const float4 o = make_float4(v[q].x + op.b[q].x, v[q].y + op.b[q].y, v[q].z + op.b[q].z, v[q].w + op.b[q].w);
+            const float4 bb = a.bias ? op.b[q] : make_float4(0.f, 0.f, 0.f, 0.f);   // (a select: the dummy load of a null bias may hold NaN bit patterns)
+            const float4 o = make_float4(v[q].x + bb.x, v[q].y + bb.y, v[q].z + bb.z, v[q].w + bb.w);
             if (row_ok && col < a.N) {
                 float* dst = out + (long)erow * a.ldo + col;
                 if (a.wt) st16_wt(dst, o); else *reinterpret_cast<float4*>(dst) = o;
@@ -213,7 +264,6 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         }
     } else {
         float s1 = 0.f;
-        int nval = 0;
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
@@ -223,29 +273,19 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             if constexpr (GATE) { x.x *= op.g[q].x; x.y *= op.g[q].y; x.z *= op.g[q].z; x.w *= op.g[q].w; }
             if constexpr (RES) { x.x += op.r[q].x; x.y += op.r[q].y; x.z += op.r[q].z; x.w += op.r[q].w; }
             v[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-            nval += ok ? 4 : 0;
             s1 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
             if (row_ok && ok) {
                 float* dst = out + (long)erow * a.ldo + col;
                 if (a.wt) st16_wt(dst, v[q]); else *reinterpret_cast<float4*>(dst) = v[q];
             }
         }
-        // statistics of this tile's valid columns: (sum, M2 about their own mean); the 8 lanes of a row are neighbours
-        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
-        nval += __shfl_xor(nval, 1, 64); nval += __shfl_xor(nval, 2, 64); nval += __shfl_xor(nval, 4, 64);
-        const float mean = nval > 0 ? s1 * __builtin_amdgcn_rcpf((float)nval) : 0.f;   // any value near the mean serves Chan's merge
-        float m2 = 0.f;
+        // statistics of this tile's valid columns: (sum, sum of squares) -- invalid columns hold zeros; the 8 lanes of a row are neighbours
+        float s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < SL; ++q) {
-            const bool ok = col0 + 4 * ks_slot_of<SL>(q, ej) < a.N;
-            float d;
-            d = v[q].x - mean; m2 += ok ? d * d : 0.f;
-            d = v[q].y - mean; m2 += ok ? d * d : 0.f;
-            d = v[q].z - mean; m2 += ok ? d * d : 0.f;
-            d = v[q].w - mean; m2 += ok ? d * d : 0.f;
-        }
-        m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
-        if (ej == 0 && row_ok) a.zstat_out[(long)erow * tilesN + tn] = make_float2(s1, m2);
+        for (int q = 0; q < SL; ++q) s2 = fmaf(v[q].x, v[q].x, fmaf(v[q].y, v[q].y, fmaf(v[q].z, v[q].z, fmaf(v[q].w, v[q].w, s2))));
+        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+        if (ej == 0 && row_ok) a.zstat_out[(long)tn * a.zs_stride + erow] = make_float2(s1, s2);   // part-major: the consumer's loads are contiguous over rows
         // A' = bf16(h_new * zg) as whole 16-byte chunks (8 columns)
         uint2 pk[SL];
 #pragma unroll

@@ -99,44 +99,6 @@ __device__ __forceinline__ void copy_out_bf16(const bf16_t* tile, int pitch, int
     }
 }
 
-// ---- LayerNorm algebra (GemmArgs.z*): (mu, r) of one row from its per-chunk partial statistics (sum, M2 about the chunk mean), merged
-// with Chan's parallel-variance formula; chunk p holds min(cw, D - cw p) columns (cw = the producer's tile width).  Same accuracy class as a two-pass LayerNorm.
-constexpr int Z_MAXP = 40;   // chunks of 64 columns a row's statistics may have (2D = 2304 -> 36)
-// TPR threads per row (consecutive lanes), thread q of a row takes the chunks q, q + TPR, ...: every chunk is requested before the first use
-// and a row's chunks are read by neighbouring lanes (32 contiguous bytes per 4 lanes) -- the first build let every lane walk its own
-// row chunk by chunk (one L2 round trip per chunk, 16 lines per load instruction) and paid +11 us on the GEGLU GEMM for it.
-// All TPR lanes of the row return (mu, r).
-template <int TPR>
-struct ZStatRegs { float2 v[(Z_MAXP + TPR - 1) / TPR]; };
-template <int TPR>
-__device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st, int parts, int q, ZStatRegs<TPR>& z) {
-    constexpr int NK = (Z_MAXP + TPR - 1) / TPR;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) z.v[k] = st[q + TPR * k < parts ? q + TPR * k : 0];
-}
-template <int TPR>
-__device__ __forceinline__ void z_row_stats_finish(const ZStatRegs<TPR>& z, int parts, int D, int cw, float eps, int q, float& mu, float& r) {
-    constexpr int NK = (Z_MAXP + TPR - 1) / TPR;
-    const int nlast = D - cw * (parts - 1);            // columns of the last (possibly ragged) chunk
-    const float inv_last = 1.f / (float)nlast, inv_cw = 1.f / (float)cw, inv_d = 1.f / (float)D;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) s += q + TPR * k < parts ? z.v[k].x : 0.f;
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
-    mu = s * inv_d;
-    float m2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const int p = q + TPR * k;
-        const bool last = p == parts - 1;
-        const float d = z.v[k].x * (last ? inv_last : inv_cw) - mu;
-        m2 += p < parts ? fmaf(last ? (float)nlast : (float)cw, d * d, z.v[k].y) : 0.f;
-    }
-#pragma unroll
-    for (int o = 1; o < TPR; o <<= 1) m2 += __shfl_xor(m2, o, 64);
-    r = rsqrtf(m2 * inv_d + eps);
-}
 // modulation slot of a row: the device step counter (slot0, read once per kernel) + the row's batch element offset (per-row timesteps only)
 __device__ __forceinline__ int z_slot(const GemmArgs& a, int slot0, int rowc) {
     return slot0 + (a.row_slot ? a.row_slot[rowc / a.rows_per_b] : 0);
@@ -239,7 +201,7 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
             for (int j = 0; j < FN; ++j) {
                 int cp = col0 + wn * TN + j * 16 + 4 * cg;
                 cp = cp < ncl ? cp : ncl;
-                if constexpr (ZC) {   // parked behind the ring at kernel start (k_gemm_pp, z_finish)
+                if constexpr (ZC) {   // parked behind the ring after the K loop (k_gemm_pp, z_finish)
                     (void)so;
                     g4[j] = *reinterpret_cast<const float4*>(zgc + (wn * TN + j * 16 + 4 * cg));
                     c4[j] = *reinterpret_cast<const float4*>(zgc + BN + (wn * TN + j * 16 + 4 * cg));
@@ -307,105 +269,6 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
     copy_out_bf16<NT>(tile, PITCH, BM, OC, out, a.ldo, row0, EPI == EPI_GEGLU ? col0 / 2 : col0, a.M, EPI == EPI_GEGLU ? a.N / 2 : a.N, a.wt, tid);
 }
 
-// EPI_RESID: the un-split residual projection.  h_new = resid + gate * (acc + bias) (fp32, stored), its per-(row, 64-column chunk) partial
-// LayerNorm statistics, and A' = bf16(h_new * zg) -- the operand of the NEXT GEMM, whose epilogue finishes the LayerNorm (GemmArgs.z*).
-// One wave holds 16 rows x 64 columns here (TN == 64): a row's chunk statistics are an in-lane sum over 4 fragments plus two xor-shuffles.
-// The epilogue's operands (bias, residual rows, gate, LayerNorm gain) are requested at KERNEL START (pp_resid_operands) and ride through the K
-// loop in registers: after the loop nothing waits on global memory any more.
-template <int FM, int FN, int TM, int TN, bool GATE>
-__device__ __forceinline__ void pp_resid_operands(const GemmArgs& a, int row0, int col0, int wm, int wn, int lane, int slot0,
-                                                  float4 (&b4)[FM][FN], float4 (&r4)[FM][FN], float4 (&g4)[FM][FN], float4 (&z4)[FM][FN]) {
-    const int m_in = lane & 15, cg = lane >> 4;
-    const int ncl = a.N - 4;
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int row = row0 + wm * TM + i * 16 + m_in;
-        const int rowc = row < a.M ? row : a.M - 1;
-        const int slot = z_slot(a, slot0, rowc);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {   // unconditional, clamped; bias and resid are mandatory, the gate is a template switch: a null-pointer test
-            int col = col0 + wn * TN + j * 16 + 4 * cg;   // per operand made hipcc serialise the loads behind vmcnt(0) waits
-            col = col < ncl ? col : ncl;
-            b4[i][j] = *reinterpret_cast<const float4*>(a.bias + col);
-            r4[i][j] = *reinterpret_cast<const float4*>(a.resid + (long)rowc * a.ldr + col);
-            if constexpr (GATE) g4[i][j] = *reinterpret_cast<const float4*>(a.gate + (long)slot * a.gate_slot_stride + col);
-            else g4[i][j] = make_float4(1.f, 1.f, 1.f, 1.f);
-            z4[i][j] = *reinterpret_cast<const float4*>(a.zg + (long)slot * a.zg_slot_stride + col);
-        }
-    }
-}
-template <int BM, int BN, int FM, int FN, int TM, int TN, int NT>
-__device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid,
-                                               const float4 (&b4a)[FM][FN], const float4 (&r4a)[FM][FN], const float4 (&g4a)[FM][FN], const float4 (&z4a)[FM][FN]) {
-    static_assert(TN == 64 && FN == 4, "one 64-column statistics chunk per wave");
-    constexpr int PITCH = BN + 8;
-    static_assert(BN % 8 == 0, "16-byte row chunks");
-    bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
-    const int m_in = lane & 15, cg = lane >> 4;
-    float* out = reinterpret_cast<float*>(a.out);
-    uint2 pk[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int row = row0 + wm * TM + i * 16 + m_in;
-        const float4 (&b4)[FN] = b4a[i];
-        const float4 (&r4)[FN] = r4a[i];
-        const float4 (&g4)[FN] = g4a[i];
-        const float4 (&z4)[FN] = z4a[i];
-        float4 hn[FN];
-        float s1 = 0.f;
-        int nval = 0;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int col = col0 + wn * TN + j * 16 + 4 * cg;
-            const bool ok = col < a.N;
-            // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
-            hn[j].x = ok ? r4[j].x + g4[j].x * (acc[i][j][0] + b4[j].x) : 0.f;
-            hn[j].y = ok ? r4[j].y + g4[j].y * (acc[i][j][1] + b4[j].y) : 0.f;
-            hn[j].z = ok ? r4[j].z + g4[j].z * (acc[i][j][2] + b4[j].z) : 0.f;
-            hn[j].w = ok ? r4[j].w + g4[j].w * (acc[i][j][3] + b4[j].w) : 0.f;
-            nval += ok ? 4 : 0;
-            s1 += (hn[j].x + hn[j].y) + (hn[j].z + hn[j].w);
-            if (ok && row < a.M) {
-                float* dst = out + (long)row * a.ldo + col;
-                if (a.wt) st16_wt(dst, hn[j]); else *reinterpret_cast<float4*>(dst) = hn[j];
-            }
-        }
-        // chunk statistics over the valid columns of this wave's 64: the 4 lanes (cg) of a row sit 16 lanes apart
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        nval += __shfl_xor(nval, 16, 64);
-        nval += __shfl_xor(nval, 32, 64);
-        const float mean = nval > 0 ? s1 * __builtin_amdgcn_rcpf((float)nval) : 0.f;   // any value near the mean serves Chan's merge (the consumer recomputes the mean from the sums)
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const bool ok = col0 + wn * TN + j * 16 + 4 * cg < a.N;
-            float d;
-            d = hn[j].x - mean; q += ok ? d * d : 0.f;
-            d = hn[j].y - mean; q += ok ? d * d : 0.f;
-            d = hn[j].z - mean; q += ok ? d * d : 0.f;
-            d = hn[j].w - mean; q += ok ? d * d : 0.f;
-        }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
-        const int chunk = (col0 + wn * TN) >> 6;
-        if (cg == 0 && row < a.M && chunk * 64 < a.N) a.zstat_out[(long)row * ((a.N + 63) >> 6) + chunk] = make_float2(s1, q);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            pk[i][j].x = pack_bf2(hn[j].x * z4[j].x, hn[j].y * z4[j].y);
-            pk[i][j].y = pack_bf2(hn[j].z * z4[j].z, hn[j].w * z4[j].w);
-        }
-    }
-    __syncthreads();   // the exchange area of the k-split schedule is dead: park A'
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-            *reinterpret_cast<uint2*>(tile + (wm * TM + i * 16 + m_in) * PITCH + wn * TN + j * 16 + 4 * cg) = pk[i][j];
-    __syncthreads();
-    copy_out_bf16<NT>(tile, PITCH, BM, BN, a.zu, a.ld_zu, row0, col0, a.M, a.N, a.wt, tid);
-}
-
 // fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile
 // holds NH = BN / head_dim WHOLE heads of q, of k or of v (D is a multiple of BN), parked in LDS as fp32 so that head boundaries need not
 // coincide with MFMA fragments; per-head LayerNorm + RoPE of q / k -> [B][H][Lp][DQK], V -> V^T [B][H][DV][Lp].
@@ -420,19 +283,26 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
     const int m_in = lane & 15, cg = lane >> 4;
     if constexpr (ZC) {   // LayerNorm algebra: the projection of LN(x) g + c is  r (acc - mu G') + C'
         const int ncl = a.N - 4;
+        float4 c4[FN], g4[FN];
+        // shared modulation slot: G' / C' of the tile's columns were parked behind the ring (k_gemm_pp, z_finish).  The LDS and the global
+        // variant are two separate loops on purpose: as one loop with a per-element choice hipcc merged them into FLAT loads of a selected
+        // address (18 flat_load_dwordx4 in the epilogue: +2.5 us per launch)
+        if (!a.row_slot) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                g4[j] = *reinterpret_cast<const float4*>(zgc + (wn * TN + j * 16 + 4 * cg));
+                c4[j] = *reinterpret_cast<const float4*>(zgc + BN + (wn * TN + j * 16 + 4 * cg));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int rl = wm * TM + i * 16 + m_in;
-            int row = row0 + rl;
-            row = row < a.M ? row : a.M - 1;
-            const long so = (long)z_slot(a, slot0, row) * a.zt_slot_stride;
-            float4 c4[FN], g4[FN];
+            if (a.row_slot) {   // per-row timesteps: the slot differs between rows
+                int row = row0 + rl;
+                row = row < a.M ? row : a.M - 1;
+                const long so = (long)z_slot(a, slot0, row) * a.zt_slot_stride;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if (!a.row_slot) {   // shared modulation slot: parked behind the ring at kernel start (k_gemm_pp, z_finish)
-                    g4[j] = *reinterpret_cast<const float4*>(zgc + (wn * TN + j * 16 + 4 * cg));
-                    c4[j] = *reinterpret_cast<const float4*>(zgc + BN + (wn * TN + j * 16 + 4 * cg));
-                } else {
+                for (int j = 0; j < FN; ++j) {
                     int cp = col0 + wn * TN + j * 16 + 4 * cg;
                     cp = cp < ncl ? cp : ncl;
                     g4[j] = *reinterpret_cast<const float4*>(a.zG + so + cp);
@@ -549,7 +419,7 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
     }
 }
 
-// VAR bits: 64 = LayerNorm algebra in the epilogue (EPI_GEGLU / EPI_QKV consumers; EPI_RESID: the residual has a gate) -- a template
+// VAR bits: 64 = LayerNorm algebra in the epilogue (EPI_GEGLU / EPI_QKV consumers) -- a template
 // switch, not a run-time test, so that the epilogue's loads are straight-line;
 // timing ablations (results are garbage; EZ_ABLATE builds): 8 = no MFMAs, 16 = no fragment reads, 32 = no LDS-DMA refill inside the loop.  Measured and dropped (MI355X, 128x288 tile, cycles per K tile): s_setprio(1) over the MFMA phase 1809 vs 1793,
 // over the LOAD phase 1806, static priority for group 1 1819 -- priorities do not move this loop.
@@ -597,48 +467,47 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     const int ke = nk * (z + 1) / a.splitk;
     const int nt = ke - kb;
 
-    // VAR & 64 ("ZM"): EPI_GEGLU / EPI_QKV finish a LayerNorm in their epilogue (GemmArgs.z*, consumer side); EPI_RESID has a gate
+    // VAR & 64 ("ZM"): EPI_GEGLU / EPI_QKV finish a LayerNorm in their epilogue (GemmArgs.z*, consumer side)
     constexpr bool ZM = (VAR & 64) != 0;
     const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed in the epilogue only
     float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
-    // LayerNorm algebra, consumer side: the tile's rows' partial statistics (one contiguous block: 4 threads per row, coalesced) and the G' / C'
-    // slices of the tile's columns are REQUESTED here, in front of the prologue's LDS-DMA, and turned into (mu, r) / parked in LDS behind the
-    // ring by z_finish() right after the prologue's issue (one wait for everything that is in flight at kernel start); the epilogue reads
-    // them back many barriers later.  (Round 3 waited for the statistics before the first LDS-DMA went out -- one exposed fabric round trip
-    // -- and fetched G' / C' from global memory after the K loop -- a second one: +2.2 ... 2.9 us per consumer launch.)
+    // LayerNorm algebra, consumer side: the partial statistics of the tile's rows (thread t < BM: row t, part-major table) and the G' / C'
+    // slices of the tile's columns (one float4 per thread) are REQUESTED here, in front of the prologue's LDS-DMA, ride through the K loop in
+    // registers and are turned into (mu, r) / parked in LDS behind the ring by z_finish() AFTER the loop, in front of a barrier the epilogue
+    // has anyway: nothing at kernel start waits on them.
     float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only)
-    ZStatRegs<4> zst;
+    ZStatRegs zst;
     float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool z_shared_slot = a.row_slot == nullptr;
     if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-        static_assert(BM * 4 == NT, "4 threads per row");
-        static_assert(2 * (BN / 4) <= NT, "one float4 of G' or C' per thread");
-        int row = row0 + (tid >> 2);
-        row = row < a.M ? row : a.M - 1;
-        z_row_stats_load<4>(a.zstat_in + (long)row * a.zparts, a.zparts, tid & 3, zst);
-        if (z_shared_slot && tid < 2 * (BN / 4)) {
-            const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
-            int cp = col0 + 4 * t4;
-            cp = cp < a.N - 4 ? cp : a.N - 4;
-            zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + (long)slot0 * a.zt_slot_stride + cp);
+        static_assert(BM <= NT && 2 * (BN / 4) <= NT, "one row / one float4 of G' or C' per thread");
+        if (tid < BM && !((a.debug >> 8) & 1)) {
+            int row = row0 + tid;
+            row = row < a.M ? row : a.M - 1;
+            z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, zst);
         }
     }
-    auto z_finish = [&]() {
+    // G' / C' live in the table of the CURRENT modulation slot: their address needs the device step counter (slot0, a scalar load issued at
+    // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
+    // of the first tile (it did: +1 us per consumer launch); one load younger than the prologue's pieces only makes the counted waits of the
+    // first K tile marginally stricter
+    auto z_late_load = [&]() {
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            float mu, r;
-            z_row_stats_finish<4>(zst, a.zparts, a.zD, a.zw, a.zeps, tid & 3, mu, r);
-            if ((tid & 3) == 0) zrow[tid >> 2] = make_float2(mu, r);
+            if (z_shared_slot && tid < 2 * (BN / 4) && !((a.debug >> 8) & 4)) {
+                const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
+                int cp = col0 + 4 * t4;
+                cp = cp < a.N - 4 ? cp : a.N - 4;
+                zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + (long)slot0 * a.zt_slot_stride + cp);
+            }
+        }
+    };
+    auto z_finish = [&]() {   // after the K loop; the caller puts a workgroup barrier between this and the first reader
+        if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
+            if ((a.debug >> 8) & 8) return;
+            if (tid < BM) zrow[tid] = ((a.debug >> 8) & 2) ? make_float2(0.f, 1.f) : z_row_stats_finish(zst, a.zparts, a.zD, a.zeps);
             if (z_shared_slot && tid < 2 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
         }
     };
-    // EPI_RESID: the epilogue's operands (bias, residual rows, gate, LayerNorm gain) are requested NOW, in front of the prologue's LDS-DMA, and
-    // ride through the K loop in registers: after the loop nothing waits on global memory.  (Vector-memory loads complete in issue order, so
-    // the first tile's wait covers them: prologue 1842 -> 3799 cycles, epilogue 10120 -> 5668 on the D x D shape.  Requesting them BEHIND the
-    // LDS-DMA with a counted wait does not work from HIP source: beside in-flight LDS-DMA hipcc waits vmcnt(0) wherever it touches a register
-    // loaded from memory, and loads hidden in inline asm get copied by the register allocator before they land.)
-    constexpr int RFM = EPI == EPI_RESID ? FM / 2 : 1, RFN = EPI == EPI_RESID ? FN : 1;
-    float4 rb4[RFM][RFN], rr4[RFM][RFN], rg4[RFM][RFN], rz4[RFM][RFN];
-    if constexpr (EPI == EPI_RESID) pp_resid_operands<RFM, RFN, TM / 2, TN, ZM>(a, row0, col0, wm * 2 + grp, wn, lane, slot0, rb4, rr4, rg4, rz4);
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
     if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }   // [6], [7]: the 100 MHz device-wide clock (cycle counters are not comparable between workgroups)
     f32x4 acc[FM][FN];
@@ -776,12 +645,16 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
             for (int t = 0; t < PD; ++t)
                 if (t < nt) issue(t, IB{}, IE{});
-            z_finish();
+            z_late_load();
             wait_younger<PG, PD - 1>((nt < PD ? nt : PD) - 1);
             barrier();
             if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
             auto step = [&](int t, auto RF_) {
                 constexpr bool rf = decltype(RF_)::value;   // steady state: tile t + PD exists and is issued here
+                // LayerNorm algebra: (mu, r) / G' / C' -> LDS at the start of the LAST tile's step (nothing of this wave is in flight any more,
+                // so the wait the compiler puts in front of the registers' first use is free); every wave passes a barrier between here and
+                // the epilogue, which starts its math WITHOUT one (it overlaps the other group's last MFMA phase)
+                if constexpr (!rf) { if (t == nt - 1 && (a.debug & 4)) z_finish(); }   // A/B: debug bit 2 = finish inside the last K tile's step
                 // ---- LOAD(t)
                 load_phase(t, t + PD, rf, IB{}, IE{});
                 if constexpr (G == 1) {
@@ -824,7 +697,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < PD; ++u)
                 if (((u + PD) & 1) == G && u < nt) issue(u, IB{}, IE{});
-            z_finish();
+            z_late_load();
             if constexpr ((PD & 1) == G) {   // owner of tile 0
                 const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
                 wait_younger<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0);
@@ -882,6 +755,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
     if constexpr (SCHED == 2) {
+        z_finish();   // (mu, r) of the tile's rows and G' / C' of its columns -> LDS behind the ring, in front of the exchange barriers (LayerNorm algebra; no-op otherwise)
         // exchange the two groups' partial sums through the (dead) ring: group g keeps the row fragments [g * FM/2, (g + 1) * FM/2) of its
         // wave tile and parks the others for its partner wave (same wg, other group); lane-linear 16-byte accesses
         constexpr int HF = FM / 2;
@@ -917,10 +791,6 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         // from here on: 2 WM x WN waves, wave tile TM/2 x TN
         const int ewm = wm * 2 + grp;
-        if constexpr (EPI == EPI_RESID) {
-            static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "A' tile must fit the ring");
-            pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT>(a, half, smem, row0, col0, ewm, wn, lane, tid, rb4, rr4, rg4, rz4);
-        }
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
             static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");
@@ -938,6 +808,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) pp_store_direct<HF, FN, TM / 2, TN, EPI>(a, half, row0, col0, ewm, wn, lane, z);
     } else {
+        if constexpr (ZM) { if (!(a.debug & 4)) { z_finish(); __syncthreads(); } }
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {

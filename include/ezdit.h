@@ -194,9 +194,9 @@ int ezvae_sample(const float* dev_enc, const float* dev_noise, float* dev_z, int
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw,
                     const float* dev_bias, void* dev_out, int ldo, int M, int N, int K, int splitk,
                     ezdit_stream stream);
-/* unit-test hook of the un-split residual projection (LayerNorm algebra, producer side): h_out = h_in + gate * (A . W^T + bias) (fp32 [M][N];
- * gate NULL = 1, h_in NULL = 0), zu = bf16(h_out * zg) ([M][ld_zu]) and zstat ([M][ceil(N / cw)] float pairs: sum and M2 about the chunk mean of
- * each cw-column chunk, cw = the kernel's tile width: 96 for tile 70, see csrc/gemm.hip). */
+/* unit-test hook of the un-split residual projection (LayerNorm algebra, producer side; csrc/gemm_ks.h): h_out = h_in + gate * (A . W^T + bias)
+ * (fp32 [M][N]; gate NULL = 1, h_in NULL = 0), zu = bf16(h_out * zg) ([M][ld_zu]) and zstat ([ceil(N / cw)][M] float pairs, part-major: sum and
+ * sum of squares of each cw-column tile, cw = the kernel's tile width: 96 for tile 70, see csrc/gemm.hip). */
 int ezdit_test_resid(int tile, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw, const float* dev_bias, const float* dev_h_in,
                      const float* dev_gate, const float* dev_zg, float* dev_h_out, void* dev_zu_bf16, int ld_zu, void* dev_zstat,
                      int M, int N, int K, ezdit_stream stream);
