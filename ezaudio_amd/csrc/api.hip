@@ -113,19 +113,29 @@ struct ezdit_handle {
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
     int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
     int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp) at M <= 2048: bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); the residual GEMMs select it through tile_partial = 62
-    // LayerNorm algebra (common.h, GemmArgs.z*): the attention-out, cross-attention-out and (in front of an in / mid block) MLP-out
-    // projections run UN-SPLIT on the ping-pong kernel with the gated residual, partial LayerNorm statistics and the next GEMM's operand
-    // in their epilogue; the consumer (fused QKV GEMM, cross-attention q projection, GEGLU GEMM) finishes the LayerNorm in ITS epilogue:
-    // no split-K slabs and 72 of the 102 row-kernel launches of an XL step less (253 launches instead of 325), bit-for-bit the same algebra
-    // as the reference (goldens pass at the same gates).  MEASURED SLOWER on MI355X and therefore OFF: XL one prompt 4.56 ms vs 4.25 ms per
-    // step, four prompts 13.6 vs 12.3 ms.  The un-split 64x128 projection runs on 144 of 256 CUs (M = 1000; 3 rounds at M = 4000) and takes
-    // 16-20 us in situ against 9.4 (split-K 3 on 216 CUs) + 7.3 (row kernel) + one launch boundary; every consumer pays 1-3 us for its
-    // statistics / G' / C' loads.  profiles/r03_zfuse_*.txt; DESIGN.md section 4.  Needs gemm_pp bits 0 and 1 and the fused q projection.
-    int opt_zfuse = 0;
+    // LayerNorm algebra (common.h, GemmArgs.z*): the attention-out, cross-attention-out, skip_linear and (in front of an in / mid block) MLP-out
+    // projections run UN-SPLIT on the K-split-inside-the-workgroup kernel (k_gemm_ks, gemm_ks.h: 48 x 96 tiles, 252 workgroups at M = 1000) with
+    // the gated residual, per-column-tile LayerNorm statistics and the next GEMM's operand bf16(h g) in their epilogue; the consumer (fused QKV
+    // GEMM, cross-attention q projection, GEGLU GEMM) finishes the LayerNorm in ITS epilogue as r (acc - mu G') + C': no split-K slabs and 86
+    // of the 102 row-kernel launches of an XL step less (239 launches instead of 325), the same algebra as the reference (goldens pass at the
+    // same gates).  Round 3 shipped this OFF (its 64 x 128 ping-pong producer filled 144 of 256 CUs: 4.56 vs 4.25 ms); with the new producer
+    // and consumers that wait for nothing at kernel start it is ON: XL one prompt 4.066 -> 4.042 ms per step, EzAudio-L 3.194 -> 3.139 (same
+    // box, profiles/r04_experiments.txt).  Needs gemm_pp bits 0 and 1 and the fused q projection; otherwise (e.g. four prompts per GPU, M = 4000)
+    // the step falls back to split-K slabs + the row kernel.
+    int opt_zfuse = 1;
     int opt_ztile = 70;   // producer of the LayerNorm algebra: 70-75 = K-split-inside-the-workgroup kernel (gemm_ks.h; 70 = 48 x 96 tiles), 63 = ping-pong 64 x 128
     int opt_zfake = 0;   // DIAGNOSTIC: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
     int opt_zmlp = 1;     // MLP-out projection (K = 4 D) in front of an in / mid block on the un-split producer too (0: split-K slabs + row kernel)
     int opt_zskip = 1;    // skip_linear (K = 2 D) of the out-blocks on the un-split producer
+    // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
+    int qkv_mode() const {
+        return !(opt_fuse_qkv && (dh == 72 || dh == 64)) ? 0 : ((opt_gemm_pp & 2) && M <= opt_pp_max_m && D % (2 * dh) == 0) ? 2 : (D % (4 * dh) == 0 ? 1 : 0);
+    }
+    // the LayerNorm-algebra path can run for the bound shape under the current options (its tables are built by ezdit_prepare_timesteps only then)
+    bool zfuse_usable() const {
+        return opt_zfuse && opt_ztile >= 70 && (D + zwidth() - 1) / zwidth() <= Z_MAXP && M <= opt_pp_max_m && (opt_gemm_pp & 1) && geglu_tile < 0 && qkv_mode() == 2 &&
+               opt_fuse_q2 && ((long)B * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0;
+    }
     int zwidth() const { return opt_ztile == 75 ? 128 : opt_ztile == 71 || opt_ztile == 73 || opt_ztile == 77 ? 64 : 96; }   // statistics chunk = the producer's tile width
     int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
@@ -798,7 +808,7 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(EZDIT_E_HIP, "time-path launch failed: %s", hipGetErrorString(e));
     }
-    if (h->opt_zfuse) {
+    if (h->zfuse_usable()) {
         // LayerNorm algebra tables (GemmArgs.z*): G' = g W^T, C' = c W^T (+ bias) of the LayerNorm in front of the fused QKV GEMM (norm1,
         // modulated: per slot), of the GEGLU GEMM (norm3, modulated; C' carries mlp.net.0.proj.bias) and of cross-attention's to_q (norm2,
         // static).  Small bf16 GEMMs on exact hi + lo splits of the fp32 vectors; once per call.
@@ -825,7 +835,7 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
     }
     h->steps_done = 0;
     h->ts_ready = true;
-    h->z_tables_ready = h->opt_zfuse != 0;
+    h->z_tables_ready = h->zfuse_usable();
     h->n_ts = n;
     h->per_row = per_row;
     return EZDIT_OK;
@@ -922,10 +932,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     // LayerNorm algebra (opt_zfuse): un-split residual projection whose epilogue produces h_new, its partial LayerNorm statistics and
     // A' = bf16(h_new * zg) for the next GEMM; the consumer finishes the LayerNorm.  u_is_z tells the next consumer what `u` holds.
     // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
-    const int qkv_mode = !(h->opt_fuse_qkv && (h->dh == 72 || h->dh == 64)) ? 0
-                         : ((h->opt_gemm_pp & 2) && M <= h->opt_pp_max_m && D % (2 * h->dh) == 0) ? 2 : (D % (4 * h->dh) == 0 ? 1 : 0);
-    const bool zf = h->opt_zfuse && h->z_tables_ready && h->opt_ztile >= 70 && (D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP && M <= h->opt_pp_max_m && (h->opt_gemm_pp & 1) && h->geglu_tile < 0 && qkv_mode == 2 &&
-                    h->opt_fuse_q2 && ((long)h->B * h->H * ((h->L + 63) / 64) <= 512 || h->opt_fuse_q2 == 2) && h->Lcp % 128 == 0;
+    const int qkv_mode = h->qkv_mode();
+    const bool zf = h->z_tables_ready && h->zfuse_usable();
     auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
                        const float* zg, long zg_stride) {
         GemmArgs g;

@@ -308,28 +308,30 @@ def test_forward_matches_reference_golden(lib, dev, name):
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, t, r, a)
 
 
-@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'l', 'xl', 'xl_b8'])
-def test_layernorm_algebra_path_matches_reference_golden(lib, dev, name):
-    """Option zfuse (off by default: measured slower): un-split residual projections whose epilogue emits h, partial LayerNorm
-    statistics and the next GEMM's operand h * g, the consumer GEMM finishing the LayerNorm as r (acc - mu G') + C' in its epilogue.  Same
-    gates against the reference's own outputs as the default path; fewer launches (no split-K slabs, no row kernel on those edges)."""
+@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'l', 'xl'])
+def test_layernorm_algebra_and_split_k_paths_match_reference_golden(lib, dev, name):
+    """Option zfuse (default ON): un-split residual projections (k_gemm_ks) whose epilogue emits h, per-column-tile LayerNorm
+    statistics and the next GEMM's operand h * g, the consumer GEMM finishing the LayerNorm as r (acc - mu G') + C' in its epilogue -- against
+    zfuse = 0 (split-K slabs + the row kernel): both within the same gates of the reference's own outputs, and the launch counts that say
+    which path ran (no slabs and no row kernel on the attention-out / cross-out / skip / in-block MLP-out edges)."""
     cfg, sd, inp, kw, g, meta = golden_case(name)
     m = get_model(meta['size'], meta['seed_w'])
     t = meta['timesteps'][0]
     ref = g[f'pred_t{t}']
-    base = _forward(m, inp, t, kw).cpu().numpy()
-    n_base = m.last_launch_count
-    assert lib.ezdit_set_option(m._h, b'zfuse', 1) == 0
+    pred = _forward(m, inp, t, kw).cpu().numpy()
+    n_z = m.last_launch_count
+    assert lib.ezdit_set_option(m._h, b'zfuse', 0) == 0
     try:
-        pred = _forward(m, inp, t, kw).cpu().numpy()
-        n_z = m.last_launch_count
+        base = _forward(m, inp, t, kw).cpu().numpy()
+        n_base = m.last_launch_count
     finally:
-        assert lib.ezdit_set_option(m._h, b'zfuse', 0) == 0
+        assert lib.ezdit_set_option(m._h, b'zfuse', 1) == 0
     nblk = cfg['depth'] + 1
     assert n_z == n_base - (2 * nblk + cfg['depth'])      # attention-out and cross-out of every block, MLP-out in front of in / mid blocks, skip_linear of the out-blocks
-    r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
-    print(f'{name} t={t} zfuse: rel-L2 {r:.3e} max-abs {a:.3e} (default path {rel_l2(base, ref):.3e}); launches {n_base} -> {n_z}')
-    assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
+    for what, p in (('zfuse', pred), ('split-K', base)):
+        r, a = rel_l2(p, ref), float(np.abs(p - ref).max())
+        print(f'{name} t={t} {what}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {n_base} -> {n_z}')
+        assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
 @pytest.mark.parametrize('size,L', [('s', 77), ('s64', 131), ('s', 1), ('s', 1500)])
@@ -526,11 +528,11 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=0, wt=2)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
-                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (0, 1)), ('wt', (0, 1))])
+                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
