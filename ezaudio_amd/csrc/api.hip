@@ -144,6 +144,7 @@ struct ezdit_handle {
     int wt() const { return opt_wt == 2 ? (B * L <= 2048) : opt_wt; }
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
+    int opt_q2_pp = 1;                                                                    // cross-attn q projection at large grids: ping-pong GEMM with the per-head LayerNorm in its epilogue (0: fp32 GEMM + normalisation inside k_attn)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
     int opt_gemm_debug = 0;   // k_gemm2 experiments: bit 0 = s_setprio(1) over the first MFMA cluster of a K tile, bit 1 = static priority for waves 4-7
@@ -1060,6 +1061,13 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
                 at.zw = h->zwidth(); at.zstat_in = p.zstat; at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
                 at.zG = p.zt_q2 + (long)b * 2 * D; at.zC = at.zG + D;
             }
+        } else if (qkv_mode == 2 && h->opt_q2_pp) {
+            // batched prompts: the q projection on the ping-pong kernel with the fused-QKV epilogue restricted to its q part (N = D, no RoPE):
+            // per-head LayerNorm and the bf16 attention layout straight out of the GEMM -- no fp32 q round trip, no 128 x 64 tile at M = 4000
+            // (k_gemm<128,64> + normalisation inside k_attn: 30 us; this: one round of 256 workgroups).  LayerNorm-algebra capable (zt_q2 is static)
+            c.hn = &hn;
+            if (u_is_z) { c.zG = p.zt_q2 + (long)b * 2 * D; c.zC = c.zG + D; c.zt_stride = 0; }
+            gemm(c, u, h->ldD, w.wq2, nullptr, nullptr, 0, M, D, EPI_QKV, 61);
         } else {
             gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
             if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
@@ -1466,6 +1474,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "xcd_map")) h->opt_xcd_map = value;
     else if (!strcmp(name, "slab_bf16")) h->opt_slab_bf16 = value;
     else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
+    else if (!strcmp(name, "q2_pp")) h->opt_q2_pp = value;
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "attn_xcd")) h->opt_attn_xcd = value;

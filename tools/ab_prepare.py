@@ -52,7 +52,7 @@ def measure(combo):
     if combo != 'base':
         for kv in combo.split('+'):
             k, v = kv.split('=')
-            touched.setdefault(k, DEFAULTS.get(k, 0))
+            touched.setdefault(k, DEFAULTS[k])   # an option missing here would be 'restored' to a wrong value
             setopt(k, v)
     smp = LatentSampler(unet, DDIMScheduler(**params['diff']))
     smp.prepare(text, mask, utext, um, init, noise, 5.0, 0.75, n, 1.0)
@@ -72,7 +72,7 @@ def measure(combo):
 
 # defaults of the options this script may touch (csrc/api.hip)
 DEFAULTS = dict(zfuse=1, ztile=70, zmlp=1, zskip=1, gemm_pp=3, tile_partial=9, wt=2, fuse_q2=1, attn_xk2=1, gemm_panel=3, row_affine=1,
-                split18=3, split36=3, split72=3, pp_max_m=1 << 30, attn_nkh=0, xproj=1, gemm_debug=0)
+                split18=3, split36=3, split72=3, pp_max_m=1 << 30, attn_nkh=0, gemm_debug=0, q2_pp=1, zfake=0, tile_partial_big=40, split_big=0, zbig=1)
 for r in range(rounds):
     for combo in combos:
         try:
