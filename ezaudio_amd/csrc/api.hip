@@ -124,6 +124,7 @@ struct ezdit_handle {
     // the step falls back to split-K slabs + the row kernel.
     int opt_zfuse = 1;
     int opt_ztile = 70;   // producer of the LayerNorm algebra: 70-75 = K-split-inside-the-workgroup kernel (gemm_ks.h; 70 = 48 x 96 tiles), 63 = ping-pong 64 x 128
+    int opt_zbig = 1;     // M > 2048 (batched prompts): the un-split producer is the ping-pong kernel's 128 x 144 tile (one round of 256 workgroups at M = 4000) instead of k_gemm_ks
     int opt_zfake = 0;   // DIAGNOSTIC: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
     int opt_zmlp = 1;     // MLP-out projection (K = 4 D) in front of an in / mid block on the un-split producer too (0: split-K slabs + row kernel)
     int opt_zskip = 1;    // skip_linear (K = 2 D) of the out-blocks on the un-split producer
@@ -133,10 +134,13 @@ struct ezdit_handle {
     }
     // the LayerNorm-algebra path can run for the bound shape under the current options (its tables are built by ezdit_prepare_timesteps only then)
     bool zfuse_usable() const {
+        // the cross-attention q projection must be one of the two LayerNorm-algebra consumers: fused into k_attn (small grids) or the ping-pong GEMM with the q epilogue
+        const bool q_fused = opt_fuse_q2 && ((long)B * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0;
         return opt_zfuse && opt_ztile >= 70 && (D + zwidth() - 1) / zwidth() <= Z_MAXP && M <= opt_pp_max_m && (opt_gemm_pp & 1) && geglu_tile < 0 && qkv_mode() == 2 &&
-               opt_fuse_q2 && ((long)B * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0;
+               (q_fused || opt_q2_pp);
     }
-    int zwidth() const { return opt_ztile == 75 ? 128 : opt_ztile == 71 || opt_ztile == 73 || opt_ztile == 77 ? 64 : 96; }   // statistics chunk = the producer's tile width
+    int ztile() const { return (M > 2048 && opt_zbig && !per_row) ? 61 : opt_ztile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
+    int zwidth() const { const int t = ztile(); return t == 61 ? 144 : t == 75 ? 128 : t == 71 || t == 73 || t == 77 ? 64 : 96; }   // statistics part = the producer's tile width
     int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 2;   // write-through (sc1) output stores: 0 off, 1 on, 2 = on while B L <= 2048.  The end-of-kernel write-back then has nothing left to flush: -3.5 % step time
@@ -768,6 +772,7 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
     if (per_row && n != h->B) return fail(EZDIT_E_INVALID, "per_row needs n == B (%d != %d)", n, h->B);
     hipStream_t st = (hipStream_t)stream;
     const int D = h->D, nblk = h->nblk;
+    h->per_row = per_row;   // (the producer choice of the LayerNorm algebra depends on it: ztile())
     int* ints = h->buf<int>("ints");
     HIPCHK(hipMemcpyAsync(h->buf<int>("ts"), ts, (size_t)n * 4, hipMemcpyHostToDevice, st));
     std::vector<int> rs(240, 0);
@@ -940,7 +945,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         GemmArgs g;
         memset(&g, 0, sizeof g);
         g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
-        g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->opt_ztile;
+        g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->ztile();
         g.xcd_map = h->opt_xcd_map; g.wt = h->wt(); g.debug = h->opt_gemm_debug;
         g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
@@ -1493,6 +1498,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "ztile")) h->opt_ztile = value;
     else if (!strcmp(name, "zmlp")) h->opt_zmlp = value;
     else if (!strcmp(name, "zfake")) h->opt_zfake = value;
+    else if (!strcmp(name, "zbig")) h->opt_zbig = value;
     else if (!strcmp(name, "zskip")) h->opt_zskip = value;
     else if (!strcmp(name, "pp_max_m")) h->opt_pp_max_m = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;

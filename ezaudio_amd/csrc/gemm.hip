@@ -713,7 +713,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
     if (EPI == EPI_PARTIAL && a.xcd_panel && BM == 128) grid.x = 8 * ((a.N + BN - 1) / BN) * a.splitk * (((a.M + BM - 1) / BM + 7) / 8);   // M tile tm -> XCD tm % 8 (gemm_pp.h)
     else a.xcd_panel = 0;
-    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + 2 * BN * 4;   // ring + (mu, r) of the tile's rows + G' / C' of its columns (LayerNorm algebra)
+    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 3 : 2) * BN * 4;   // ring + (mu, r) of the tile's rows + G' / C' (EPI_RESID: bias / gate / gain) of its columns (LayerNorm algebra)
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     static std::atomic<bool> attr_set[32];   // per (kernel, device); two host threads may race here on first use (harmless double set)
     int dev = 0;
@@ -897,7 +897,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         if (a.resid || a.conv_cpb) return 1;
         return launch_ks_tile<EPI_F32, false, false>(a, st);
     }
-    if (a.epi == EPI_RESID) return 1;   // the K-split kernel is the only producer
+    if (a.epi == EPI_RESID && a.tile == 61) {   // batched prompts: un-split residual projection on the ping-pong kernel, 128 x 144 tiles (k-split schedule, ring 4)
+        if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.out || !a.bias || a.splitk != 1 || (a.gate && !a.resid) || a.row_slot) return 1;
+        if (a.gate) return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 64 + 128>(a, st);
+        if (a.resid) return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 128>(a, st);
+        return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 0>(a, st);
+    }
+    if (a.epi == EPI_RESID) return 1;
     if (a.epi == EPI_GEGLU && a.zstat_in) {   // GEGLU GEMM that finishes the LayerNorm of its operand (LayerNorm algebra): ping-pong kernel only
         if (a.tile != 60 || !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
         return launch_pp<128, 288, 4, 2, 3, EPI_GEGLU, 1, 64>(a, st);

@@ -269,6 +269,65 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
     copy_out_bf16<NT>(tile, PITCH, BM, OC, out, a.ldo, row0, EPI == EPI_GEGLU ? col0 / 2 : col0, a.M, EPI == EPI_GEGLU ? a.N / 2 : a.N, a.wt, tid);
 }
 
+// EPI_RESID of the k-split schedule (batched prompts, M > 2048: 128 x 144 tiles fill the 256 CUs in one round at M = 4000; at M = 1000 the
+// K-split-inside-the-workgroup kernel k_gemm_ks is the producer): the un-split residual projection.  h_new = resid + gate * (acc + bias) (fp32,
+// stored), its (sum, sum of squares) over the tile's BN columns (part-major table, GemmArgs.zstat_out) and A' = bf16(h_new * zg), the operand
+// of the NEXT GEMM, whose epilogue finishes the LayerNorm (GemmArgs.z*).  After the k-split exchange a wave holds 16 rows x ALL BN columns
+// of the tile (WN == 1): a row's statistics are an in-lane sum over FN fragments plus two xor-shuffles.  The per-column vectors (bias, gate,
+// LayerNorm gain) were parked in LDS behind the ring (`vec`: [3][BN]); the residual rows `r4` were requested right after the K loop.
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, bool GATE, bool RES>
+__device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int lane, int tid,
+                                               const float* vec, const float4 (&r4)[FM][FN]) {
+    static_assert(TN == BN, "one wave holds whole tile rows");
+    constexpr int PITCH = BN + 8;
+    static_assert(BN % 8 == 0, "16-byte row chunks");
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem);
+    const int m_in = lane & 15, cg = lane >> 4;
+    const int tn = col0 / BN;
+    float* out = reinterpret_cast<float*>(a.out);
+    uint2 pk[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int row = row0 + wm * TM + i * 16 + m_in;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int cl = j * 16 + 4 * cg, col = col0 + cl;
+            const bool ok = col < a.N;
+            const float4 b4 = *reinterpret_cast<const float4*>(vec + cl);
+            // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
+            float4 x = make_float4(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
+            if constexpr (GATE) {
+                const float4 g4 = *reinterpret_cast<const float4*>(vec + BN + cl);
+                x.x *= g4.x; x.y *= g4.y; x.z *= g4.z; x.w *= g4.w;
+            }
+            if constexpr (RES) { x.x += r4[i][j].x; x.y += r4[i][j].y; x.z += r4[i][j].z; x.w += r4[i][j].w; }
+            if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+            s1 += (x.x + x.y) + (x.z + x.w);
+            s2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, s2))));
+            if (ok && row < a.M) {
+                float* dst = out + (long)row * a.ldo + col;
+                if (a.wt) st16_wt(dst, x); else *reinterpret_cast<float4*>(dst) = x;
+            }
+            const float4 z4 = *reinterpret_cast<const float4*>(vec + 2 * BN + cl);
+            pk[i][j].x = pack_bf2(x.x * z4.x, x.y * z4.y);
+            pk[i][j].y = pack_bf2(x.z * z4.z, x.w * z4.w);
+        }
+        // the 4 lanes (cg) of a row sit 16 lanes apart
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (cg == 0 && row < a.M) a.zstat_out[(long)tn * a.zs_stride + row] = make_float2(s1, s2);
+    }
+    __syncthreads();   // the exchange area of the k-split schedule is dead: park A'
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<uint2*>(tile + (wm * TM + i * 16 + m_in) * PITCH + j * 16 + 4 * cg) = pk[i][j];
+    __syncthreads();
+    copy_out_bf16<NT>(tile, PITCH, BM, BN, a.zu, a.ld_zu, row0, col0, a.M, a.N, a.wt, tid);
+}
+
 // fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile
 // holds NH = BN / head_dim WHOLE heads of q, of k or of v (D is a multiple of BN), parked in LDS as fp32 so that head boundaries need not
 // coincide with MFMA fragments; per-head LayerNorm + RoPE of q / k -> [B][H][Lp][DQK], V -> V^T [B][H][DV][Lp].
@@ -437,7 +496,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr int STAGE = NP * 4096;
     constexpr int PD = NS - 1;                 // prefetch distance in K tiles
     static_assert(NS >= 3 && NS <= 6, "ring depth");
-    static_assert(NS * STAGE + BM * 8 + 2 * BN * 4 <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics + G' / C' of the tile's columns)");
+    static_assert(NS * STAGE + BM * 8 + (EPI == EPI_RESID ? 3 : 2) * BN * 4 <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics + G' / C' (or bias / gate / gain) of the tile's columns)");
     constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -475,7 +534,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // slices of the tile's columns (one float4 per thread) are REQUESTED here, in front of the prologue's LDS-DMA, ride through the K loop in
     // registers and are turned into (mu, r) / parked in LDS behind the ring by z_finish() AFTER the loop, in front of a barrier the epilogue
     // has anyway: nothing at kernel start waits on them.
-    float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only)
+    float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only); EPI_RESID: [3][BN] bias | gate | LayerNorm gain
     ZStatRegs zst;
     float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool z_shared_slot = a.row_slot == nullptr;
@@ -491,7 +550,18 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
     // of the first tile (it did: +1 us per consumer launch); one load younger than the prologue's pieces only makes the counted waits of the
     // first K tile marginally stricter
+    constexpr bool RGATE = EPI == EPI_RESID && (VAR & 64) != 0, RRES = EPI == EPI_RESID && (VAR & 128) != 0;
     auto z_late_load = [&]() {
+        if constexpr (EPI == EPI_RESID) {   // producer side: bias | gate | gain of the tile's columns, one float4 per thread (the modulation slot is shared: launch_gemm checks)
+            static_assert(3 * (BN / 4) <= NT, "one float4 per thread");
+            if (tid < 3 * (BN / 4)) {
+                const int which = tid / (BN / 4), t4 = tid - which * (BN / 4);
+                int cp = col0 + 4 * t4;
+                cp = cp < a.N - 4 ? cp : a.N - 4;
+                const float* src = which == 0 ? a.bias : which == 1 ? (RGATE ? a.gate + (long)slot0 * a.gate_slot_stride : a.bias) : a.zg + (long)slot0 * a.zg_slot_stride;
+                zgc_reg = *reinterpret_cast<const float4*>(src + cp);
+            }
+        }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
             if (z_shared_slot && tid < 2 * (BN / 4) && !((a.debug >> 8) & 4)) {
                 const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
@@ -502,6 +572,9 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
     };
     auto z_finish = [&]() {   // after the K loop; the caller puts a workgroup barrier between this and the first reader
+        if constexpr (EPI == EPI_RESID) {
+            if (tid < 3 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
+        }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
             if ((a.debug >> 8) & 8) return;
             if (tid < BM) zrow[tid] = ((a.debug >> 8) & 2) ? make_float2(0.f, 1.f) : z_row_stats_finish(zst, a.zparts, a.zD, a.zeps);
@@ -756,6 +829,23 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
     if constexpr (SCHED == 2) {
         z_finish();   // (mu, r) of the tile's rows and G' / C' of its columns -> LDS behind the ring, in front of the exchange barriers (LayerNorm algebra; no-op otherwise)
+        // EPI_RESID: the residual rows this wave finishes after the exchange (16 rows x the tile's columns) are requested NOW and land under the exchange
+        constexpr int RF = EPI == EPI_RESID ? FM / 2 : 1, RN = EPI == EPI_RESID ? FN : 1;
+        float4 rres[RF][RN];
+        if constexpr (RRES) {
+            const int m_in = lane & 15, cg = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < RF; ++i) {
+                int row = row0 + (wm * 2 + grp) * (TM / 2) + i * 16 + m_in;
+                row = row < a.M ? row : a.M - 1;
+#pragma unroll
+                for (int j = 0; j < RN; ++j) {
+                    int col = col0 + wn * TN + j * 16 + 4 * cg;
+                    col = col < a.N - 4 ? col : a.N - 4;
+                    rres[i][j] = *reinterpret_cast<const float4*>(a.resid + (long)row * a.ldr + col);
+                }
+            }
+        }
         // exchange the two groups' partial sums through the (dead) ring: group g keeps the row fragments [g * FM/2, (g + 1) * FM/2) of its
         // wave tile and parks the others for its partner wave (same wg, other group); lane-linear 16-byte accesses
         constexpr int HF = FM / 2;
@@ -791,6 +881,11 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         // from here on: 2 WM x WN waves, wave tile TM/2 x TN
         const int ewm = wm * 2 + grp;
+        if constexpr (EPI == EPI_RESID) {
+            static_assert(WN == 1, "EPI_RESID: a wave holds whole tile rows after the exchange");
+            static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "A' tile must fit the ring");
+            pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres);
+        }
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
             static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");

@@ -163,13 +163,14 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-ZW = {70: 96, 71: 64, 72: 96, 73: 64, 75: 128, 76: 96, 77: 64}   # statistics part width = the producer's tile width
+ZW = {61: 144, 70: 96, 71: 64, 72: 96, 73: 64, 75: 128, 76: 96, 77: 64}   # statistics part width = the producer's tile width
 
 
-@pytest.mark.parametrize('tile,mode', [(70, 'gr'), (70, 'r'), (70, ''), (71, 'gr'), (72, 'gr'), (73, 'r'), (75, 'gr'), (75, ''), (76, 'gr'), (76, ''), (77, 'r')])
+@pytest.mark.parametrize('tile,mode', [(61, 'gr'), (61, 'r'), (61, ''), (70, 'gr'), (70, 'r'), (70, ''), (71, 'gr'), (72, 'gr'), (73, 'r'), (75, 'gr'), (75, ''), (76, 'gr'), (76, ''), (77, 'r')])
 @pytest.mark.parametrize('M,N,K', [(1000, 1152, 1152), (1000, 1152, 4608), (192, 144, 192), (192, 128, 128), (77, 576, 64), (500, 1024, 320), (1000, 1152, 2304)])
 def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K, tile, mode):
-    """Producer side of the LayerNorm algebra (EPI_RESID of the K-split-inside-the-workgroup kernel k_gemm_ks):
+    """Producer side of the LayerNorm algebra (EPI_RESID of the K-split-inside-the-workgroup kernel k_gemm_ks, tiles 70+, and of the ping-pong
+    kernel's 128 x 144 tile, 61, the producer for batched prompts):
     h_new = h + gate * (A W^T + b) in fp32 (mode 'gr'; 'r': no gate; '': no residual either -- skip_linear), its per-column-tile
     (sum, sum of squares) statistics (part-major: [N tiles][M]) -- merged here and compared with the row's true mean / variance --
     and A' = bf16(h_new * g)."""
@@ -308,7 +309,7 @@ def test_forward_matches_reference_golden(lib, dev, name):
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, t, r, a)
 
 
-@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'l', 'xl'])
+@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 's', 's64', 'l', 'xl', 'xl_b8'])
 def test_layernorm_algebra_and_split_k_paths_match_reference_golden(lib, dev, name):
     """Option zfuse (default ON): un-split residual projections (k_gemm_ks) whose epilogue emits h, per-column-tile LayerNorm
     statistics and the next GEMM's operand h * g, the consumer GEMM finishing the LayerNorm as r (acc - mu G') + C' in its epilogue -- against
