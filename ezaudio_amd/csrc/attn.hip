@@ -122,10 +122,10 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             ZStatRegs zst;
             float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (ZQ) {
-                if (tid < 64) {
-                    int qr = qt * 64 + tid;
+                if (tid < 256) {   // four threads per row
+                    int qr = qt * 64 + (tid >> 2);
                     qr = qr < a.Lq ? qr : a.Lq - 1;
-                    z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, zst);
+                    z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, tid & 3, zst);
                 }
                 if (tid < 2 * (DH / 4)) {
                     const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
@@ -210,7 +210,10 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[j]));
             if constexpr (ZQ) {   // behind the two barriers below: read in phase 1b
-                if (tid < 64) zrow_l[tid] = z_row_stats_finish(zst, a.zparts, a.zD, a.zeps);
+                if (tid < 256) {
+                    const float2 mr = z_row_stats_finish(zst, a.zparts, tid & 3, a.zD, a.zeps);
+                    if ((tid & 3) == 0) zrow_l[tid >> 2] = mr;
+                }
                 if (tid < 2 * (DH / 4)) {
                     const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
                     *reinterpret_cast<float4*>(zgc_l + which * DQK + 4 * t4) = zgc_reg;

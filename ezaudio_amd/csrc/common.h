@@ -73,28 +73,37 @@ constexpr int Z_MAXP = 12;   // LayerNorm algebra: column tiles (partial statist
 // (the textbook one-pass form: its relative error on var is eps_fp32 (1 + mu^2 / var) -- harmless while a row's mean is not orders of
 // magnitude above its spread, which holds for the residual stream; the (sum, M2-about-the-tile-mean) form of round 3 needed a 12-term Chan
 // merge with a data-dependent correction per part: 130 instructions on the one wave every other wave of the workgroup waits for).
-// The statistics are stored PART-MAJOR ([part][row], GemmArgs.zs_stride rows apart): ONE thread per row loads the row's parts (consecutive
-// lanes = consecutive rows: every load instruction is one contiguous 512-byte run) at kernel start and merges them after the K loop --
-// nothing at kernel start waits on them (round 3 let four threads per row gather 8-byte pieces of a row-major table and wait for them
-// before the first LDS-DMA went out).
-struct ZStatRegs { float2 v[Z_MAXP]; };
+// The statistics are stored PART-MAJOR ([part][row], GemmArgs.zs_stride rows apart): FOUR neighbouring threads per row load its parts (thread
+// pg of a row takes the parts pg, pg + 4, pg + 8: a wave's load instruction covers 16 rows x 4 parts = four contiguous 128-byte runs) at
+// kernel start -- 6 registers per thread ride through the K loop -- and merge them after it with two xor-shuffles: nothing at kernel start
+// waits on them (round 3 let four threads per row gather 8-byte pieces of a row-major table and wait for them before the first LDS-DMA).
+constexpr int Z_PT = Z_MAXP / 4;   // parts per thread
+static_assert(Z_PT * 4 == Z_MAXP, "four threads per row");
+struct ZStatRegs { float2 v[Z_PT]; };
 // The loads are UNCONDITIONAL (part index clamped) and their results are not touched here: a select on a loaded value made hipcc wait for
 // the loads at kernel start, in front of the first LDS-DMA (k_attn: +1.7 us per launch); the unused parts are masked in z_row_stats_finish
-__device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st /* + row */, long stride, int parts, ZStatRegs& z) {
+__device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st /* + row */, long stride, int parts, int pg, ZStatRegs& z) {
 #pragma unroll
-    for (int k = 0; k < Z_MAXP; ++k) z.v[k] = st[(k < parts ? k : parts - 1) * stride];
+    for (int k = 0; k < Z_PT; ++k) {
+        const int p = pg + 4 * k;
+        z.v[k] = st[(p < parts ? p : parts - 1) * stride];
+    }
 }
-__device__ __forceinline__ float2 z_row_stats_finish(ZStatRegs& z, int parts, int D, float eps) {
+// all four threads of the row (lanes pg = 0 .. 3, neighbours) return (mu, r)
+__device__ __forceinline__ float2 z_row_stats_finish(ZStatRegs& z, int parts, int pg, int D, float eps) {
     // nothing below may be hoisted above this point (hipcc moved the first addition up to the loads and waited for them at kernel start)
 #pragma unroll
-    for (int k = 0; k < Z_MAXP; ++k) asm volatile("" : "+v"(z.v[k].x), "+v"(z.v[k].y));
+    for (int k = 0; k < Z_PT; ++k) asm volatile("" : "+v"(z.v[k].x), "+v"(z.v[k].y));
     const float inv_d = __builtin_amdgcn_rcpf((float)D);
     float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int k = 0; k < Z_MAXP; ++k) {   // fixed order: bit-reproducible
-        s += k < parts ? z.v[k].x : 0.f;
-        q += k < parts ? z.v[k].y : 0.f;
+    for (int k = 0; k < Z_PT; ++k) {   // fixed order: bit-reproducible
+        const bool on = pg + 4 * k < parts;
+        s += on ? z.v[k].x : 0.f;
+        q += on ? z.v[k].y : 0.f;
     }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
     const float mu = s * inv_d;
     const float var = fmaxf(fmaf(q, inv_d, -mu * mu), 0.f);
     return make_float2(mu, rsqrtf(var + eps));

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr bool ZM = (VAR & 64) != 0;
     const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed in the epilogue only
     float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
-    // LayerNorm algebra, consumer side: the partial statistics of the tile's rows (thread t < BM: row t, part-major table) and the G' / C'
+    // LayerNorm algebra, consumer side: the partial statistics of the tile's rows (four threads per row, part-major table) and the G' / C'
     // slices of the tile's columns (one float4 per thread) are REQUESTED here, in front of the prologue's LDS-DMA, ride through the K loop in
     // registers and are turned into (mu, r) / parked in LDS behind the ring by z_finish() AFTER the loop, in front of a barrier the epilogue
     // has anyway: nothing at kernel start waits on them.
@@ -539,11 +539,11 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool z_shared_slot = a.row_slot == nullptr;
     if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-        static_assert(BM <= NT && 2 * (BN / 4) <= NT, "one row / one float4 of G' or C' per thread");
-        if (tid < BM && !((a.debug >> 8) & 1)) {
-            int row = row0 + tid;
+        static_assert(4 * BM <= NT && 2 * (BN / 4) <= NT, "four threads per row / one float4 of G' or C' per thread");
+        if (tid < 4 * BM) {
+            int row = row0 + (tid >> 2);
             row = row < a.M ? row : a.M - 1;
-            z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, zst);
+            z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, tid & 3, zst);
         }
     }
     // G' / C' live in the table of the CURRENT modulation slot: their address needs the device step counter (slot0, a scalar load issued at
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             }
         }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            if (z_shared_slot && tid < 2 * (BN / 4) && !((a.debug >> 8) & 4)) {
+            if (z_shared_slot && tid < 2 * (BN / 4)) {
                 const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
                 cp = cp < a.N - 4 ? cp : a.N - 4;
@@ -576,8 +576,10 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             if (tid < 3 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
         }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            if ((a.debug >> 8) & 8) return;
-            if (tid < BM) zrow[tid] = ((a.debug >> 8) & 2) ? make_float2(0.f, 1.f) : z_row_stats_finish(zst, a.zparts, a.zD, a.zeps);
+            if (tid < 4 * BM) {
+                const float2 mr = z_row_stats_finish(zst, a.zparts, tid & 3, a.zD, a.zeps);
+                if ((tid & 3) == 0) zrow[tid >> 2] = mr;
+            }
             if (z_shared_slot && tid < 2 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
         }
     };
@@ -724,10 +726,6 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
             auto step = [&](int t, auto RF_) {
                 constexpr bool rf = decltype(RF_)::value;   // steady state: tile t + PD exists and is issued here
-                // LayerNorm algebra: (mu, r) / G' / C' -> LDS at the start of the LAST tile's step (nothing of this wave is in flight any more,
-                // so the wait the compiler puts in front of the registers' first use is free); every wave passes a barrier between here and
-                // the epilogue, which starts its math WITHOUT one (it overlaps the other group's last MFMA phase)
-                if constexpr (!rf) { if (t == nt - 1 && (a.debug & 4)) z_finish(); }   // A/B: debug bit 2 = finish inside the last K tile's step
                 // ---- LOAD(t)
                 load_phase(t, t + PD, rf, IB{}, IE{});
                 if constexpr (G == 1) {
@@ -903,7 +901,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) pp_store_direct<HF, FN, TM / 2, TN, EPI>(a, half, row0, col0, ewm, wn, lane, z);
     } else {
-        if constexpr (ZM) { if (!(a.debug & 4)) { z_finish(); __syncthreads(); } }
+        if constexpr (ZM) { z_finish(); __syncthreads(); }   // (inside the last K tile's step instead -- no barrier, GELU math still under the other group's last MFMAs -- measured the same: 27.10 vs 27.29 us)
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
