@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libezaudio_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class EzditConfig(C.Structure):
@@ -69,7 +69,7 @@ PROTOTYPES = {
     'ezvae_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_test_gemm': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'ezdit_debug_gemm_timestamps': (C.c_int, [C.c_void_p]),
+    'ezdit_debug_gemm_timestamps': (C.c_int, [C.c_void_p, C.c_long]),
     'ezdit_test_resid': (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_test_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

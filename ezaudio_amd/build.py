@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libezaudio_hip.so')
 SOURCES = ['gemm.hip', 'attn.hip', 'rowops.hip', 'api.hip', 'vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
-if os.environ.get('EZAUDIO_ABLATE'):   # timing-only variants of the GEMM K loop (tools/ablate_gemm.py); never in the shipped build
+if os.environ.get('EZAUDIO_ABLATE'):   # timing-only variants of the ping-pong K loop (VAR bits 8 / 16 / 32 of k_gemm_pp, tools/microbench/gemm_bench.cpp); never in the shipped build
     FLAGS.append('-DEZ_ABLATE')
 
 

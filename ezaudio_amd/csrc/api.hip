@@ -58,7 +58,8 @@ struct WsPtrs {  // workspace regions used on the per-step path, resolved once a
     float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
 };
 
-static unsigned long long* g_gemm_ts = nullptr;   // ezdit_debug_gemm_timestamps: device buffer for in-kernel cycle stamps (gemm_pp.h, attn.hip)
+static unsigned long long* g_gemm_ts = nullptr;   // ezdit_debug_gemm_timestamps: device buffer for in-kernel cycle stamps (gemm_pp.h, gemm_ks.h, attn.hip)
+static long g_gemm_ts_cap = 0;                    // ... and the workgroups it has room for ([workgroup][8] uint64): a launch with a larger grid gets no stamps
 
 struct ezdit_handle {
     ezdit_config cfg;
@@ -141,7 +142,7 @@ struct ezdit_handle {
     }
     int ztile() const { return (M > 2048 && opt_zbig && !per_row) ? 61 : opt_ztile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
     int zwidth() const { const int t = ztile(); return t == 61 ? 144 : t == 75 ? 128 : t == 71 || t == 73 || t == 77 ? 64 : 96; }   // statistics part = the producer's tile width
-    int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels are used at.  Four prompts (M = 4000): 12.27 vs 12.95 ms per step with the large-tile k_gemm2 / lockstep QKV path
+    int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels (and with them the LayerNorm algebra) are used at; default: no limit.  Round 3, four prompts (M = 4000): ping-pong GEGLU / QKV 12.27 ms per step, large-tile k_gemm2 GEGLU + lockstep QKV (pp_max_m = 2048) 12.95 ms
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
     int opt_wt = 2;   // write-through (sc1) output stores: 0 off, 1 on, 2 = on while B L <= 2048.  The end-of-kernel write-back then has nothing left to flush: -3.5 % step time
                       // for one prompt (4.19 -> 4.04 ms), +1.4 % for four (the step is throughput-bound there and the stores compete with the loads)
@@ -494,7 +495,7 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
         g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
         c.fuse = nullptr;
     }
-    g.ts = c.stamps();
+    g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
     c.launched(epi == EPI_GEGLU ? "k_gemm (GEGLU)" : epi == EPI_QKV ? "k_gemm (QKV)" : epi == EPI_PARTIAL ? "k_gemm (split-K slabs)" : "k_gemm", launch_gemm(g, c.st));
 }
 
@@ -950,7 +951,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
         g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat; g.zs_stride = h->Mp;
-        g.ts = c.stamps();
+        g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
         c.launched("k_gemm (un-split residual)", launch_gemm(g, st));
         u_is_z = true;
     };
@@ -1026,7 +1027,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
         STOPCHK();
-        at.ts = c.stamps();
+        at.ts = c.stamps(); at.ts_cap = g_gemm_ts_cap;
         c.launched("k_attn (self)", launch_attention(at, st));
         STOPCHK();
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
@@ -1089,7 +1090,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         at.kmask = p.kmask;
         at.Lk = h->Lc; at.Lkp = h->Lcp;
         STOPCHK();
-        at.ts = c.stamps();
+        at.ts = c.stamps(); at.ts_cap = g_gemm_ts_cap;
         c.launched("k_attn (cross)", launch_attention(at, st));
         STOPCHK();
         if (fuse_res) {
@@ -1286,6 +1287,9 @@ static int sampler_step(ezdit_handle* h, hipStream_t st) {
         ezdit_handle* cn = h->cn;
         if (cn->B != h->B || cn->L != h->L || cn->nhalf != h->nhalf || cn->D != h->D || !cn->ctx_ready || !cn->ts_ready || !cn->cond_ready)
             return fail(EZDIT_E_STATE, "attached ControlNet is not prepared for this shape (bind/context/timesteps/condition)");
+        // the ControlNet indexes ITS modulation tables with the backbone's device step counter: its prepared schedule must cover the backbone's
+        if (cn->n_ts < h->n_steps || cn->n_slots < h->n_steps || cn->per_row != h->per_row)
+            return fail(EZDIT_E_STATE, "attached ControlNet was prepared for %d timesteps (per_row %d), the sampler runs %d (per_row %d)", cn->n_ts, cn->per_row, h->n_steps, h->per_row);
         cn->ext_mask_embed = h->w_mask_embed;
         hipStream_t cst = st;
         if (h->opt_cn_overlap && h->debug_stop == 0) {   // fork: the ControlNet chain runs next to the backbone's first half
@@ -1371,7 +1375,11 @@ int ezdit_sampler_run(ezdit_handle* h, int n, int use_graph, ezdit_stream stream
 }
 
 // ------------------------------------------------------------------------------------------------------
-int ezdit_debug_gemm_timestamps(void* dev_buf) { g_gemm_ts = static_cast<unsigned long long*>(dev_buf); return EZDIT_OK; }
+int ezdit_debug_gemm_timestamps(void* dev_buf, long capacity_workgroups) {
+    g_gemm_ts = static_cast<unsigned long long*>(dev_buf);
+    g_gemm_ts_cap = dev_buf ? capacity_workgroups : 0;
+    return EZDIT_OK;
+}
 
 int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const void* W, int ldw, const float* bias, void* out,
                     int ldo, int M, int N, int K, int splitk, ezdit_stream stream) {
@@ -1386,7 +1394,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: bits 0-1 k_gemm2 experiment bits (GemmArgs.debug), bit 3 LDS-staged bf16 epilogue, bit 4 bf16 slabs, bits 8.. k_gemm_pp ablation variant
     if (g.debug & 8) g.epi_lds = 1;
     if (g.debug & 16) g.part_bf16 = 1;   // 16000 + v: bf16 split-K slabs
-    g.ts = g_gemm_ts;
+    g.ts = g_gemm_ts; g.ts_cap = g_gemm_ts_cap;
     g.epi = variant % 4; g.tile = variant / 4;   // variant = tile_config * 4 + epilogue
     if (g.debug & 64) {
         // 64000 + v: run the consumer side of the LayerNorm algebra on neutral tables (statistics of a zero-mean, unit-variance row, G' = 0,
@@ -1419,7 +1427,7 @@ int ezdit_test_resid(int tile, const void* A, int lda, const void* W, int ldw, c
     g.out = h_out; g.ldo = N; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_RESID; g.tile = tile; g.xcd_map = 1;
     g.resid = h_in; g.ldr = N; g.gate = gate; g.rows_per_b = 1;
     g.zu = (bf16_t*)zu; g.ld_zu = ld_zu; g.zg = zg; g.zstat_out = (float2*)zstat; g.zs_stride = M;   // zstat [N tiles][M]
-    g.ts = g_gemm_ts;
+    g.ts = g_gemm_ts; g.ts_cap = g_gemm_ts_cap;
     (void)hipGetLastError();
     if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "residual GEMM configuration not supported");
     const hipError_t e = hipGetLastError();
@@ -1436,7 +1444,7 @@ int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const vo
     a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
-    a.ts = g_gemm_ts;
+    a.ts = g_gemm_ts; a.ts_cap = g_gemm_ts_cap;
     (void)hipGetLastError();
     if (launch_attention(a, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "attention configuration not supported");
     const hipError_t e = hipGetLastError();

@@ -577,6 +577,7 @@ int launch_attention(const AttnArgs& a0, hipStream_t st) {
     if (a.Lkp % 128) nkh = 2;
     if (a.xu && nkh != 4) return 1;   // the fused projection exists in the 8-wave form only (needs Lkp % 128 == 0)
     if (a.dh != 64 && a.dh != 72) return 1;
+    if (a.ts && (long)grid.x * grid.y * grid.z > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
     const bool zq = a.xu && a.zstat_in;
     if (zq && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
     if (a.dh == 64) {

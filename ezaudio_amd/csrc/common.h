@@ -212,7 +212,8 @@ struct GemmArgs {
     const float2* zstat_in; int zparts; int zD; int zw; // [zparts][zs_stride] partial statistics of the operand's rows: zparts = ceil(zD / zw) <= Z_MAXP parts of zw columns (the last one ragged; zw = the producer's tile width)
     const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]
     float zeps;
-    unsigned long long* ts;   // test hook (k_gemm_pp): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
+    unsigned long long* ts;   // test hook (k_gemm_pp, k_gemm_ks): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
+    long ts_cap;              // workgroups `ts` has room for: the launcher drops `ts` for a larger grid
     int epi_lds;   // k_gemm bf16 epilogues (GEGLU output, bf16 slabs): park the tile in the dead ring and write whole rows, 16 bytes per lane
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
@@ -242,6 +243,7 @@ struct AttnArgs {
     // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)
     const float2* zstat_in; long zs_stride; int zparts; int zD; int zw; const float* zG; const float* zC; float zeps;   // zstat_in [zparts][zs_stride], part-major
     unsigned long long* ts;     // test hook: [workgroup][8] shader-clock stamps (start, operands staged, tile loop end, merge end, end), nullable
+    long ts_cap;                // workgroups `ts` has room for: the launcher drops `ts` for a larger grid
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 

@@ -724,6 +724,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
         attr_set[dev].store(true, std::memory_order_release);
     }
+    if (a.ts && (long)grid.x > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
     hipLaunchKernelGGL((k_gemm_pp<BM, BN, WM, WN, NS, EPI, SCHED, VAR>), grid, dim3(512), SMEM, st, a);
     return 0;
 }
@@ -749,6 +750,7 @@ int launch_ks(const GemmArgs& a0, hipStream_t st) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
         attr_set[dev].store(true, std::memory_order_release);
     }
+    if (a.ts && (long)grid.x > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
     hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES, CK>), grid, dim3(512), SMEM, st, a);
     return 0;
 }

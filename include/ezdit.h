@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EZDIT_ABI_VERSION 1
+#define EZDIT_ABI_VERSION 2
 
 typedef struct ezdit_handle ezdit_handle;
 typedef void* ezdit_stream; /* hipStream_t */
@@ -200,9 +200,10 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int ld
 int ezdit_test_resid(int tile, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw, const float* dev_bias, const float* dev_h_in,
                      const float* dev_gate, const float* dev_zg, float* dev_h_out, void* dev_zu_bf16, int ld_zu, void* dev_zstat,
                      int M, int N, int K, ezdit_stream stream);
-/* test hook: ezdit_test_gemm launches of the ping-pong kernel record, per workgroup, eight 64-bit shader-clock stamps (kernel start, K-loop
- * start, K-loop end, kernel end, then epilogue internals) into dev_buf ([workgroups][8] uint64; NULL switches it off). */
-int ezdit_debug_gemm_timestamps(void* dev_buf);
+/* test hook: launches of k_gemm_pp / k_gemm_ks / k_attn record, per workgroup, eight 64-bit shader-clock stamps (kernel start, K-loop
+ * start, K-loop end, kernel end, then epilogue internals) into dev_buf ([capacity_workgroups][8] uint64; NULL switches it off).  A launch
+ * whose grid exceeds capacity_workgroups writes no stamps.  Un-register (NULL) before freeing the buffer. */
+int ezdit_debug_gemm_timestamps(void* dev_buf, long capacity_workgroups);
 int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, const void* dev_vt,
                          const uint8_t* dev_kmask, void* dev_out, int B, int Lq, int Lk, int Lqp, int Lkp,
                          ezdit_stream stream);
@@ -215,7 +216,7 @@ int ezdit_device_status(ezdit_handle* h, ezdit_stream stream);
 int ezdit_last_launch_count(const ezdit_handle* h);
 /* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
 int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
-/* Tuning / A-B knobs (tools/ab_sweep.py flips them on a live sampler; a captured graph is dropped and re-captured).  Defaults
+/* Tuning / A-B knobs (tools/ab_sweep.py flips them on a live sampler, tools/ab_prepare.py re-prepares per option set; a captured graph is dropped and re-captured).  Defaults
  * are the measured best on MI355X; none changes results beyond fp rounding.  Unknown names return EZDIT_E_INVALID.
  *   GEMM tile ids (csrc/gemm.hip table): tile_partial, tile_f32, tile_qkv, tile_p18 / tile_p36 / tile_p72 (per K depth),
  *     geglu_tile, and for > 2048 rows tile_partial_big, tile_f32_big, geglu_big; split-K: split18 / split36 / split72, split_big
@@ -225,12 +226,16 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
  *     wave per row)
  *   cn_overlap 0/1 (fused sampler: ControlNet branch on a side stream next to the backbone's in-blocks)
- *   gemm_pp (ping-pong kernel k_gemm_pp at M <= 2048: bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; the residual GEMMs select it with
- *     tile_partial = 62)
- *   zfuse 0/1 (LayerNorm algebra: attention-out / cross-attention-out / MLP-out projections un-split with the residual, partial LayerNorm
- *     statistics and the next GEMM's operand in their epilogue; the consumer GEMM finishes the LayerNorm in its epilogue -- no split-K slabs,
- *     no row kernel on those edges; needs gemm_pp = 3 and fuse_q2), pp_max_m (largest number of token rows the ping-pong kernels and the
- *     LayerNorm algebra are used at; above it the large-tile k_gemm2 path)
+ *   gemm_pp (ping-pong kernel k_gemm_pp at M <= pp_max_m rows (default: unlimited): bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; the split-K
+ *     residual GEMMs select it with tile_partial = 62), pp_max_m (above it the large-tile k_gemm2 / lockstep-QKV path and no LayerNorm algebra)
+ *   zfuse 0/1, default 1 (LayerNorm algebra: attention-out / cross-attention-out / skip_linear / in-block MLP-out projections UN-SPLIT with the
+ *     residual, per-column-tile LayerNorm statistics and the next GEMM's operand in their epilogue -- k_gemm_ks (csrc/gemm_ks.h) up to 2048 rows,
+ *     the ping-pong kernel's 128 x 144 tile above (zbig 0/1) -- the consumer GEMM finishing the LayerNorm in its epilogue: no split-K slabs, no row
+ *     kernel on those edges; needs gemm_pp = 3 and a LayerNorm-algebra q projection (fuse_q2 at small grids, q2_pp above)); ztile (70 ... 77:
+ *     k_gemm_ks tile, csrc/gemm.hip), zmlp 0/1 and zskip 0/1 (MLP-out / skip_linear on the un-split producer too)
+ *   q2_pp 0/1 (cross-attention q projection at grids too large for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue)
+ *   zfake 0/1 (DIAGNOSTIC, default 0: the consumers run their LayerNorm-algebra variant on a finished LayerNorm with neutral tables -- what
+ *     the consumer side costs by itself; results change by the factor rsqrt(1 + 1e-5))
  *   gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
  *     row_affine 0/1 (the row kernel processes row panel p on XCD p % 8): a panel's slabs / residual stream / LayerNorm output stay in
  *     one XCD's L2 across the kernel boundary.  Placement only.

@@ -404,6 +404,8 @@ JOBS = {
     'cn_l':      (mint_controlnet, dict(size='l', L=500, Lc=100, t=[979, 499], seed_w=1234, seed_in=34, scale=1.0, row_stride=25)),
     # ... and its sampler: the reference's unmodified src/inference_controlnet.py::inference, 50 steps, guidance 3.5, no rescale, eta 1
     'smp_cn_l':  (mint_cn_sampler, dict(size='l', L=500, Lc=100, steps=50, seed_w=1234, seed_in=23, guidance_scale=3.5, guidance_rescale=0.0, eta=1.0, scale=1.0)),
+    # BASELINE config #5 as benchmarked: XL width + the energy ControlNet through the reference's unmodified ControlNet sampler
+    'smp_cn_xl': (mint_cn_sampler, dict(size='xl', L=500, Lc=100, steps=50, seed_w=1234, seed_in=25, guidance_scale=3.5, guidance_rescale=0.0, eta=1.0, scale=1.0)),
     # editing above toy size (conditioners.py:151-176, inference.py:79-86,103-104): forward with gt + mask and the full loop, L = 300
     'l_edit':    (mint_forward, dict(size='l', L=300, Lc=100, timesteps=[499], seed_w=1234, seed_in=12, with_gt=True)),
     'smp_l_edit': (mint_sampler, dict(size='l', L=300, Lc=100, steps=50, seed_w=1234, seed_in=24, guidance_scale=5.0, guidance_rescale=0.75, eta=1.0, with_gt=True)),

@@ -95,16 +95,18 @@ def test_energy_extractor_matches_the_reference_file_golden():
 
 
 @pytest.mark.gpu
-def test_controlnet_sampler_matches_the_reference_controlnet_loop_golden(lib):
+@pytest.mark.parametrize('gname', ['smp_cn_l', 'smp_cn_xl'])
+def test_controlnet_sampler_matches_the_reference_controlnet_loop_golden(lib, gname):
     """sampler_smp_cn_l: the reference's UNMODIFIED src/inference_controlnet.py::inference (50 steps, guidance 3.5, no rescale, eta 1) on the
     configuration it ships -- EzAudio-L + the energy ControlNet of ckpts/controlnet/energy_l.yml -- against the fused HIP sampler with the
-    ControlNet attached (one captured graph per step: ControlNet on a side stream + backbone + CFG / DDIM)."""
+    ControlNet attached (one captured graph per step: ControlNet on a side stream + backbone + CFG / DDIM).
+    sampler_smp_cn_xl: the same loop at XL width = BASELINE config #5 as benchmarked (the reference ships no XL ControlNet: synthetic weights)."""
     import ast
     import torch
     from ezaudio_amd.sampler import LatentSampler
     from ezaudio_amd.scheduler import DDIMScheduler
     from tests.util import DIFF
-    g = np.load(os.path.join(GOLDEN, 'sampler_smp_cn_l.npz'))
+    g = np.load(os.path.join(GOLDEN, f'sampler_{gname}.npz'))
     meta = ast.literal_eval(str(g['meta']))
     cfg = model_config(meta['size'])
     sd = make_state_dict(cfg, meta['seed_w'])
@@ -125,7 +127,7 @@ def test_controlnet_sampler_matches_the_reference_controlnet_loop_golden(lib):
     lat = smp.finish()
     torch.cuda.synchronize()
     r = rel_l2(lat.cpu().numpy(), g['latent'])
-    print(f'smp_cn_l: final-latent rel-L2 {r:.3e}')
+    print(f'{gname}: final-latent rel-L2 {r:.3e}')
     assert torch.isfinite(lat).all() and r < 2e-2
 
 

@@ -30,7 +30,7 @@ def test_library_exports_every_symbol_the_header_declares(lib):
     exported = set(re.findall(r' T (ez(?:dit|vae)_[a-z_0-9]+)', out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     assert set(declared) == set(_lib.PROTOTYPES), sorted(set(declared) ^ set(_lib.PROTOTYPES))
-    assert lib.ezdit_abi_version() == 1
+    assert lib.ezdit_abi_version() == 2
 
 
 def test_no_oracle_import_in_product():
@@ -181,7 +181,8 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
     names = ['tile_partial', 'tile_f32', 'tile_qkv', 'tile_p18', 'tile_p36', 'tile_p72', 'geglu_tile', 'tile_partial_big', 'tile_f32_big',
              'geglu_big', 'split18', 'split36', 'split72', 'split_big', 'xcd_map', 'slab_bf16', 'wt', 'fuse_qkv', 'qkv_waves9', 'fuse_q2',
              'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'cn_overlap', 'gemm_pp', 'zfuse', 'pp_max_m',
-             'gemm_panel', 'row_affine', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2', 'stamp_launch', 'trace_launches']
+             'gemm_panel', 'row_affine', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2', 'stamp_launch', 'trace_launches', 'ztile', 'zmlp', 'zskip', 'zbig',
+             'q2_pp', 'zfake']
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
     for n in names:
         assert n in src, n
@@ -386,3 +387,47 @@ def test_bench_line_extras_are_wired():
     # the XL step's algorithmic work the roofline fraction is computed from: 1.541 TFLOP for B = 2, L = 500, Lc = 100
     cfg = bench.model_section('xl')['model']
     assert abs(bench.flops_per_step(cfg, 2, 500, 100) / 1e12 - 1.541) < 1e-3
+
+
+def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
+    """k_gemm_pp, k_gemm_ks and k_attn issue their MFMAs from inline asm, so hipcc's hazard recogniser neither sees them nor pads behind them
+    (round-3 ADVICE): the wait states between the LAST MFMA of an accumulation chain and the first non-MFMA read of its accumulator are
+    hand-placed `s_nop`s.  This test disassembles the gfx950 code hipcc generates for those sources and checks, per kernel, that every
+    instruction which reads an accumulator register (AGPR operand of a v_accvgpr_read / ds_write / global_store / VALU instruction, or the
+    VGPR accumulators of k_attn) sits at least 18 issue slots (s_nop N counts N + 1) behind the textually preceding MFMA -- a refactor or a
+    compiler upgrade that moves a reader up fails here instead of corrupting tiles silently."""
+    import re
+    import subprocess
+    import tempfile
+    from ezaudio_amd import build
+    src_dir = os.path.join(ROOT, 'ezaudio_amd', 'csrc')
+    with tempfile.TemporaryDirectory() as td:
+        for src, kernels in (('gemm.hip', ('k_gemm_pp', 'k_gemm_ks')),):
+            out = os.path.join(td, src + '.s')
+            subprocess.check_call([build._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+                                   os.path.join(src_dir, src), '-o', out], stderr=subprocess.DEVNULL)
+            text = open(out).read()
+            funcs = re.split(r'\n(?=_Z\w+:)', text)
+            checked = 0
+            for f in funcs:
+                name = f.split(':', 1)[0]
+                if not any(k in name for k in kernels) or 'v_mfma' not in f:
+                    continue
+                lines = [l.strip() for l in f.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
+                dist = None          # issue slots since the last MFMA
+                for ins in lines:
+                    op = ins.split()[0]
+                    if op.startswith('v_mfma'):
+                        dist = 0
+                        continue
+                    if dist is None:
+                        continue
+                    reads_acc = (op == 'v_accvgpr_read_b32') or (op.startswith(('ds_write', 'global_store', 'v_')) and re.search(r'\ba\[?\d', ins.split(None, 1)[1] if ' ' in ins else ''))
+                    if reads_acc and not op.startswith('v_accvgpr_write'):
+                        assert dist >= 18, (name, ins, dist)
+                        dist = None          # chain consumed; the next MFMA re-arms the check
+                        checked += 1
+                        continue
+                    m = re.match(r's_nop (\d+)', ins)
+                    dist += int(m.group(1)) + 1 if m else 1
+            assert checked >= 10, checked

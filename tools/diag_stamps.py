@@ -81,11 +81,11 @@ def main(size='xl'):
         reps = 6
         for _ in range(reps):
             ts.zero_()
-            m.lib.ezdit_debug_gemm_timestamps(C.c_void_p(ts.data_ptr()))
+            m.lib.ezdit_debug_gemm_timestamps(C.c_void_p(ts.data_ptr()), NWG)
             assert m.lib.ezdit_set_option(m._h, b'stamp_launch', i) == 0
             fwd()
             torch.cuda.synchronize()
-            m.lib.ezdit_debug_gemm_timestamps(None)
+            m.lib.ezdit_debug_gemm_timestamps(None, 0)
             raw = ts.cpu().numpy().reshape(NWG, 8)
             okr = (raw[:, 0] > 0) & (raw[:, 3] > 0)
             if not okr.any():

@@ -33,7 +33,7 @@ int main() {
         CHECK(hipEventRecord(e0, st)); for (int i = 0; i < 50; ++i) run(); CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
         const int NWG = 4096; unsigned long long* dts; CHECK(hipMalloc(&dts, NWG * 64)); CHECK(hipMemsetAsync(dts, 0, NWG * 64, st));
-        ezdit_debug_gemm_timestamps(dts); run(); ezdit_debug_gemm_timestamps(nullptr); CHECK(hipStreamSynchronize(st));
+        ezdit_debug_gemm_timestamps(dts, NWG); run(); ezdit_debug_gemm_timestamps(nullptr, 0); CHECK(hipStreamSynchronize(st));
         std::vector<unsigned long long> t(NWG * 8); CHECK(hipMemcpy(t.data(), dts, NWG * 64, hipMemcpyDeviceToHost));
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0; int n = 0;
         for (int w = 0; w < NWG; ++w) { const unsigned long long* s = &t[8 * w]; if (!s[0] || !s[3] || !s[4]) continue; ++n; a0 += s[1] - s[0]; a1 += s[2] - s[1]; a2 += s[4] - s[2]; a3 += s[3] - s[4]; }
@@ -54,7 +54,7 @@ int main() {
                     CHECK(hipMemsetAsync(dts, 0, NWG * 64, st));
                     others();
                     if (mode == 2) CHECK(hipMemsetAsync(big, rep, (size_t)1 << 30, st));
-                    ezdit_debug_gemm_timestamps(dts); run(); ezdit_debug_gemm_timestamps(nullptr); CHECK(hipStreamSynchronize(st));
+                    ezdit_debug_gemm_timestamps(dts, NWG); run(); ezdit_debug_gemm_timestamps(nullptr, 0); CHECK(hipStreamSynchronize(st));
                     CHECK(hipMemcpy(t.data(), dts, NWG * 64, hipMemcpyDeviceToHost));
                     for (int w = 0; w < NWG; ++w) { const unsigned long long* s = &t[8 * w]; if (!s[0] || !s[3] || !s[4]) continue; ++m; b0 += s[1] - s[0]; b1 += s[2] - s[1]; b2 += s[4] - s[2]; b3 += s[3] - s[4]; }
                 }

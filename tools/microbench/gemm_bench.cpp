@@ -161,9 +161,9 @@ int main(int argc, char** argv) {
                 static unsigned long long* dts = nullptr;
                 if (!dts) CHECK(hipMalloc(&dts, NWG * 8 * 8));
                 CHECK(hipMemsetAsync(dts, 0, NWG * 8 * 8, st));
-                ezdit_debug_gemm_timestamps(dts);
+                ezdit_debug_gemm_timestamps(dts, NWG);
                 ezdit_test_gemm(nullptr, variant, dA, K, dW, K, c.epi == 1 ? nullptr : db, dout, ldo, M, N, K, c.splitk, st);
-                ezdit_debug_gemm_timestamps(nullptr);
+                ezdit_debug_gemm_timestamps(nullptr, 0);
                 CHECK(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hts(NWG * 8);
                 CHECK(hipMemcpy(hts.data(), dts, NWG * 8 * 8, hipMemcpyDeviceToHost));
@@ -243,7 +243,7 @@ int main(int argc, char** argv) {
                 printf("   %-34s %8.2f us warm  %8.2f us cold (event pair around one launch)  %7.1f TF warm\n", name, warm_us, cold_us, 2.0 * M * N * K / warm_us * 1e-6);
                 const int NWG = 8192;
                 unsigned long long* dts; CHECK(hipMalloc(&dts, NWG * 8 * 8)); CHECK(hipMemsetAsync(dts, 0, NWG * 8 * 8, st));
-                ezdit_debug_gemm_timestamps(dts); run(); ezdit_debug_gemm_timestamps(nullptr);
+                ezdit_debug_gemm_timestamps(dts, NWG); run(); ezdit_debug_gemm_timestamps(nullptr, 0);
                 CHECK(hipStreamSynchronize(st));
                 std::vector<unsigned long long> hts(NWG * 8);
                 CHECK(hipMemcpy(hts.data(), dts, NWG * 8 * 8, hipMemcpyDeviceToHost));
