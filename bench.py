@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # gfx950 dense bf16 MFMA peak (MI355X_MICROARCH.md)
-GEGLU_VARIANT = 60 * 4 + 2  # ezdit_test_gemm: tile config 60 (ping-pong kernel k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1>: what the step launches for mlp.net.0.proj), GEGLU epilogue
+GEGLU_VARIANT = 72000 + 60 * 4 + 2  # ezdit_test_gemm: tile config 60 (ping-pong kernel k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1,64>: what the step launches for mlp.net.0.proj),
+                                    # GEGLU epilogue that also finishes the LayerNorm of its operand (LayerNorm algebra, the default path; + 72000: that variant, on neutral statistics)
 
 
 def load_yaml(path):
@@ -77,7 +78,7 @@ def dominant_kernel_probe(unet, cfg, M, stream, iters=20):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     fl = 2.0 * M * D * 2 * inner
-    return dict(name='k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1> (mlp.net.0.proj + GEGLU epilogue)', launches_per_step=cfg['depth'] + 1,
+    return dict(name='k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1,64> (mlp.net.0.proj + LayerNorm-finishing GEGLU epilogue)', launches_per_step=cfg['depth'] + 1,
                 flops_per_launch=fl, avg_us=us, tflops=fl / us / 1e6, frac=fl / us / 1e6 / PEAK_BF16_TFLOPS,
                 note='back-to-back launches, includes launch gaps')
 

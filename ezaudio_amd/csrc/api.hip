@@ -126,6 +126,7 @@ struct ezdit_handle {
     int opt_zfuse = 1;
     int opt_ztile = 70;   // producer of the LayerNorm algebra: 70-75 = K-split-inside-the-workgroup kernel (gemm_ks.h; 70 = 48 x 96 tiles), 63 = ping-pong 64 x 128
     int opt_zbig = 1;     // M > 2048 (batched prompts): the un-split producer is the ping-pong kernel's 128 x 144 tile (one round of 256 workgroups at M = 4000) instead of k_gemm_ks
+    int opt_zbig_m = 2048;   // rows above which the 128 x 144 producer takes over (zbig)
     int opt_zfake = 0;   // DIAGNOSTIC: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
     int opt_zmlp = 1;     // MLP-out projection (K = 4 D) in front of an in / mid block on the un-split producer too (0: split-K slabs + row kernel)
     int opt_zskip = 1;    // skip_linear (K = 2 D) of the out-blocks on the un-split producer
@@ -140,7 +141,7 @@ struct ezdit_handle {
         return opt_zfuse && opt_ztile >= 70 && (D + zwidth() - 1) / zwidth() <= Z_MAXP && M <= opt_pp_max_m && (opt_gemm_pp & 1) && geglu_tile < 0 && qkv_mode() == 2 &&
                (q_fused || opt_q2_pp);
     }
-    int ztile() const { return (M > 2048 && opt_zbig && !per_row) ? 61 : opt_ztile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
+    int ztile() const { return (M > opt_zbig_m && opt_zbig && !per_row) ? 61 : opt_ztile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
     int zwidth() const { const int t = ztile(); return t == 61 ? 144 : t == 75 ? 128 : t == 71 || t == 73 || t == 77 ? 64 : 96; }   // statistics part = the producer's tile width
     int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels (and with them the LayerNorm algebra) are used at; default: no limit.  Round 3, four prompts (M = 4000): ping-pong GEGLU / QKV 12.27 ms per step, large-tile k_gemm2 GEGLU + lockstep QKV (pp_max_m = 2048) 12.95 ms
     int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
@@ -1507,6 +1508,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "zmlp")) h->opt_zmlp = value;
     else if (!strcmp(name, "zfake")) h->opt_zfake = value;
     else if (!strcmp(name, "zbig")) h->opt_zbig = value;
+    else if (!strcmp(name, "zbig_m")) h->opt_zbig_m = value;
     else if (!strcmp(name, "zskip")) h->opt_zskip = value;
     else if (!strcmp(name, "pp_max_m")) h->opt_pp_max_m = value;
     else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;
