@@ -377,13 +377,13 @@ def test_pmc_step_summary_folds_the_lds_and_l2_passes(tmp_path):
 def test_bench_line_extras_are_wired():
     """The keys and flags round 3 added to bench.py: the config-#4 shard measurement, the placement-test dump flags and the traffic label."""
     src = open(os.path.join(ROOT, 'bench.py')).read()
-    for needle in ("'config4_shard'", '--no-shard4', '--dump-latents', '--as-rank', 'L2<->fabric bytes per step', 'k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1>'):
+    for needle in ("'config4_shard'", '--no-shard4', '--dump-latents', '--as-rank', 'L2<->fabric bytes per step', 'k_gemm_pp<128,288,4,2,3,EPI_GEGLU,1,64>'):
         assert needle in src, needle
     import importlib.util
     spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(ROOT, 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench.GEGLU_VARIANT == 60 * 4 + 2 and callable(bench.shard4_measure)
+    assert bench.GEGLU_VARIANT == 72000 + 60 * 4 + 2 and callable(bench.shard4_measure)   # tile 60, GEGLU epilogue, LayerNorm-algebra variant (the default path)
     # the XL step's algorithmic work the roofline fraction is computed from: 1.541 TFLOP for B = 2, L = 500, Lc = 100
     cfg = bench.model_section('xl')['model']
     assert abs(bench.flops_per_step(cfg, 2, 500, 100) / 1e12 - 1.541) < 1e-3
