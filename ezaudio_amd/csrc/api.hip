@@ -150,6 +150,9 @@ struct ezdit_handle {
     int wt() const { return opt_wt == 2 ? (B * L <= 2048) : opt_wt; }
     int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
+    // the two small fp32 GEMMs of a step at M <= 2048 on the K-split kernel (k_gemm_ks): patch embed (K = 320: 252 workgroups instead of 144) and the
+    // final Linear (N = 128: 42 workgroups of 48 x 64 instead of 16 of 128 x 64); -1 = tile_f32
+    int opt_tile_pe = 70, opt_tile_fin = 73;
     int opt_q2_pp = 1;                                                                    // cross-attn q projection at large grids: ping-pong GEMM with the per-head LayerNorm in its epilogue (0: fp32 GEMM + normalisation inside k_attn)
     int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
@@ -896,7 +899,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     launch_assemble(as, st);
     c.launched("k_assemble");
     STOPCHK();
-    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, tile_for(h, M, false));
+    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, (M <= 2048 && h->opt_tile_pe >= 0) ? h->opt_tile_pe : tile_for(h, M, false));
 
     const float* part_src = part;
     bool u_is_z = false;   // `u` holds A' = bf16(h g) + partial statistics (LayerNorm algebra) instead of a finished LayerNorm
@@ -1144,7 +1147,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     }
     // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
     STOPCHK();
-    gemm(c, u, h->ldD, h->w_fin, h->b_fin, p.y, h->C, M, h->C, EPI_F32, tile_for(h, M, false));
+    gemm(c, u, h->ldD, h->w_fin, h->b_fin, p.y, h->C, M, h->C, EPI_F32, (M <= 2048 && h->opt_tile_fin >= 0) ? h->opt_tile_fin : tile_for(h, M, false));
     FinalConvArgs fc;
     fc.y = p.y; fc.ldy = h->C;
     fc.w = h->w_fin_cw; fc.b = h->w_fin_cb;
@@ -1521,6 +1524,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "tile_p36")) h->opt_tile_p36 = value;
     else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;
     else if (!strcmp(name, "tile_qkv")) h->opt_tile_qkv = value;
+    else if (!strcmp(name, "tile_pe")) h->opt_tile_pe = value;
+    else if (!strcmp(name, "tile_fin")) h->opt_tile_fin = value;
     else if (!strcmp(name, "stamp_launch")) h->opt_stamp_launch = value;
     else if (!strcmp(name, "trace_launches")) h->opt_trace_launches = value;
     else return fail(EZDIT_E_INVALID, "unknown option %s", name);

@@ -43,16 +43,17 @@ __device__ __forceinline__ int ks_slot_of(int q, int j) {
 // 21 x 12 tiles on 2 x 4 boxes are 33 / 30 tiles per XCD, i.e. a SECOND ROUND on the 32 CUs of four XCDs; the runs are 32 / 31
 __device__ __forceinline__ bool ks_tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn) {
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
-    const int xm = xcd % a.pm, gn = xcd / a.pm;
+    const int lpm = __builtin_ctz(a.pm);           // a.pm is 1, 2, 4 or 8 (pick_boxes)
+    const int xm = xcd & (a.pm - 1), gn = xcd >> lpm;
     const int n0 = gn * a.bn;
     int gw = tilesN - n0;                          // N tiles of this group
     gw = gw < a.bn ? gw : a.bn;
     if (gw <= 0) return false;
-    const int T = tilesM * gw, run = (T + a.pm - 1) / a.pm;
+    const int T = tilesM * gw, run = (T + a.pm - 1) >> lpm;
     const int t = xm * run + l;
     if (l >= run || t >= T) return false;
-    tm = t / gw;
-    tn = n0 + t % gw;
+    tm = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)gw));   // t / gw for the small integers of a tile grid, without the 40-instruction integer division
+    tn = n0 + (t - tm * gw);
     return true;
 }
 
@@ -100,6 +101,12 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     const int ncl = a.N - 4;                       // N is a multiple of 4 for every caller
 
     // ---- loop-invariant addressing: byte offset of this lane's 16 bytes of piece p (K offset excluded)
+    // The pieces of this wave's FIRST chunk go out as soon as their offsets are known, not behind all NPC offset computations: the time to the
+    // first byte is what the whole (latency-bound) kernel is shifted by
+    const char* gA = reinterpret_cast<const char*>(a.A);
+    const char* gW = reinterpret_cast<const char*>(a.W);
+    char* slot = smem + wave * SLOT;               // wave-uniform
+    const int nmine = wave < nk ? (nk - wave + 7) / 8 : 0;   // chunks of this wave: wave, wave + 8, ...; chunk number i lives in slot i % NSL
     uint32_t poff[NPC];
 #pragma unroll
     for (int p = 0; p < NPC; ++p) {
@@ -116,10 +123,10 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             gr = gr < a.wrows ? gr : a.wrows - 1;
             poff[p] = (uint32_t)(gr * a.ldw + (gc << 3)) * 2u;
         }
+        if (nmine > 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((p < PA ? gA : gW) + (long)wave * (CK * 2) + poff[p]),
+                                             (__attribute__((address_space(3))) void*)(slot + p * 1024), 16, 0, 0);
     }
-    const char* gA = reinterpret_cast<const char*>(a.A);
-    const char* gW = reinterpret_cast<const char*>(a.W);
-    char* slot = smem + wave * SLOT;               // wave-uniform
     auto issue = [&](int c, char* dst) {           // chunk c (K columns [c CK, (c + 1) CK)) -> LDS at dst
         const long koff = (long)c * (CK * 2);
 #pragma unroll
@@ -143,10 +150,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // chunks of this wave: wave, wave + 8, ...; chunk number i lives in slot i % NSL
-    const int nmine = wave < nk ? (nk - wave + 7) / 8 : 0;
 #pragma unroll
-    for (int i = 0; i < NSL; ++i)
+    for (int i = 1; i < NSL; ++i)                  // (chunk 0 went out with the offsets above)
         if (i < nmine) issue(wave + 8 * i, slot + i * CHUNK);
     // ---- epilogue operands (bias, residual rows, gate, LayerNorm gain), requested BEHIND the first chunks -- their addresses need the device
     // step counter, a scalar round trip that sat in front of the first LDS-DMA (2.6 us from kernel start to the first piece in situ) -- and
