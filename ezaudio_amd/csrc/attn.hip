@@ -115,23 +115,12 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             const int mh = wave & 1, kq = wave >> 1;
             const int rowb = b * a.Lq;
             // LayerNorm algebra: the partial statistics of the 64 operand rows of this tile (wave 0: one row per lane, part-major table: every
-            // load is one contiguous 512-byte run) and G' | C' of this head's columns (one float4 per thread of wave 1) are requested NOW, land
-            // under the projection's K loop, and are merged / parked in LDS behind the loop's last barrier; used in phase 1b
+            // load is one contiguous 512-byte run) and G' | C' of this head's columns (one float4 per thread of wave 1) are requested right behind
+            // the first two K tiles, land under the projection's K loop, and are merged / parked in LDS behind the loop's last barrier; used in phase 1b
             float2* zrow_l = reinterpret_cast<float2*>(smem + SMEM);            // [64] (mu, r)
             float* zgc_l = reinterpret_cast<float*>(smem + SMEM + 64 * 8);      // [2][DQK] G' | C'
             ZStatRegs zst;
             float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (ZQ) {
-                if (tid < 256) {   // four threads per row
-                    int qr = qt * 64 + (tid >> 2);
-                    qr = qr < a.Lq ? qr : a.Lq - 1;
-                    z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, tid & 3, zst);
-                }
-                if (tid < 2 * (DH / 4)) {
-                    const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
-                    zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + h * DH + 4 * t4);
-                }
-            }
             uint32_t aoff[1], boff[(DW * 8 + NT - 1) / NT];
             stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
             stage_offsets<DW, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
@@ -148,6 +137,18 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             const bool two = (DW * 8 > NT) && (wave_u * 64 + NT < DW * 8);
             stage(0);
             if (nt > 1) stage(1);
+            // (behind the first two tiles: the requests overlap the first tile's wait; they only make the first counted wait below marginally stricter)
+            if constexpr (ZQ) {
+                if (tid < 256) {   // four threads per row
+                    int qr = qt * 64 + (tid >> 2);
+                    qr = qr < a.Lq ? qr : a.Lq - 1;
+                    z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, tid & 3, zst);
+                }
+                if (tid < 2 * (DH / 4)) {
+                    const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
+                    zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + h * DH + 4 * t4);
+                }
+            }
             f32x16 acc[FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j)

@@ -80,6 +80,9 @@ constexpr int Z_MAXP = 12;   // LayerNorm algebra: column tiles (partial statist
 constexpr int Z_PT = Z_MAXP / 4;   // parts per thread
 static_assert(Z_PT * 4 == Z_MAXP, "four threads per row");
 struct ZStatRegs { float2 v[Z_PT]; };
+// xor-shuffles inside a quad by DPP (hipcc lowers __shfl_xor to ds_bpermute: an LDS-pipe round trip)
+__device__ __forceinline__ float quad_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float quad_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }
 // The loads are UNCONDITIONAL (part index clamped) and their results are not touched here: a select on a loaded value made hipcc wait for
 // the loads at kernel start, in front of the first LDS-DMA (k_attn: +1.7 us per launch); the unused parts are masked in z_row_stats_finish
 __device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st /* + row */, long stride, int parts, int pg, ZStatRegs& z) {
@@ -102,8 +105,8 @@ __device__ __forceinline__ float2 z_row_stats_finish(ZStatRegs& z, int parts, in
         s += on ? z.v[k].x : 0.f;
         q += on ? z.v[k].y : 0.f;
     }
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+    s += quad_xor1(s); s += quad_xor2(s);   // the four threads of a row are one quad
+    q += quad_xor1(q); q += quad_xor2(q);
     const float mu = s * inv_d;
     const float var = fmaxf(fmaf(q, inv_d, -mu * mu), 0.f);
     return make_float2(mu, rsqrtf(var + eps));

@@ -531,25 +531,18 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed in the epilogue only
     float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
     // LayerNorm algebra, consumer side: the partial statistics of the tile's rows (four threads per row, part-major table) and the G' / C'
-    // slices of the tile's columns (one float4 per thread) are REQUESTED here, in front of the prologue's LDS-DMA, ride through the K loop in
-    // registers and are turned into (mu, r) / parked in LDS behind the ring by z_finish() AFTER the loop, in front of a barrier the epilogue
-    // has anyway: nothing at kernel start waits on them.
+    // slices of the tile's columns (one float4 per thread) are requested right BEHIND the first K tile's LDS-DMA (z_late_load), waited for together
+    // with that tile (the counted wait that leaves only the YOUNGER tiles in flight) and turned into (mu, r) / parked in LDS behind the ring
+    // (z_finish) in front of the barrier that opens the K loop: the first tile's wait is needed anyway, the requests overlap it, no register
+    // rides through the loop and the epilogue needs no extra barrier (so the GEGLU math still overlaps the other group's last MFMA phase).  Ledger of the alternatives: profiles/r04_experiments.txt.
     float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only); EPI_RESID: [3][BN] bias | gate | LayerNorm gain
     ZStatRegs zst;
     float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool z_shared_slot = a.row_slot == nullptr;
-    if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-        static_assert(4 * BM <= NT && 2 * (BN / 4) <= NT, "four threads per row / one float4 of G' or C' per thread");
-        if (tid < 4 * BM) {
-            int row = row0 + (tid >> 2);
-            row = row < a.M ? row : a.M - 1;
-            z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, tid & 3, zst);
-        }
-    }
+    constexpr bool ZP = (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) || EPI == EPI_RESID;   // this instantiation parks per-row / per-column vectors behind the ring
     // G' / C' live in the table of the CURRENT modulation slot: their address needs the device step counter (slot0, a scalar load issued at
     // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
-    // of the first tile (it did: +1 us per consumer launch); one load younger than the prologue's pieces only makes the counted waits of the
-    // first K tile marginally stricter
+    // of the first tile (it did: +1 us per consumer launch)
     constexpr bool RGATE = EPI == EPI_RESID && (VAR & 64) != 0, RRES = EPI == EPI_RESID && (VAR & 128) != 0;
     auto z_late_load = [&]() {
         if constexpr (EPI == EPI_RESID) {   // producer side: bias | gate | gain of the tile's columns, one float4 per thread (the modulation slot is shared: launch_gemm checks)
@@ -563,6 +556,12 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             }
         }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
+            static_assert(4 * BM <= NT && 2 * (BN / 4) <= NT, "four threads per row / one float4 of G' or C' per thread");
+            if (tid < 4 * BM) {
+                int row = row0 + (tid >> 2);
+                row = row < a.M ? row : a.M - 1;
+                z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, tid & 3, zst);
+            }
             if (z_shared_slot && tid < 2 * (BN / 4)) {
                 const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
@@ -571,7 +570,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             }
         }
     };
-    auto z_finish = [&]() {   // after the K loop; the caller puts a workgroup barrier between this and the first reader
+    auto z_finish = [&]() {   // behind a wait for the loads of z_late_load; the caller puts a workgroup barrier between this and the first reader
         if constexpr (EPI == EPI_RESID) {
             if (tid < 3 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
         }
@@ -718,10 +717,12 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             using IE = std::integral_constant<int, PE>;
             // prologue: tiles 0 .. PD-1; tile 0 must be complete (every wave's share) before interval 0
 #pragma unroll
-            for (int t = 0; t < PD; ++t)
+            for (int t = 0; t < PD; ++t) {
                 if (t < nt) issue(t, IB{}, IE{});
-            z_late_load();
+                if (t == 0) z_late_load();   // right behind tile 0: the wait for tile 0 below (everything but the YOUNGER tiles' pieces) covers these loads too
+            }
             wait_younger<PG, PD - 1>((nt < PD ? nt : PD) - 1);
+            z_finish();
             barrier();
             if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
             auto step = [&](int t, auto RF_) {
@@ -765,14 +766,20 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         };
         auto run = [&](auto G_) {
             constexpr int G = decltype(G_)::value;
+            // the z loads go out right behind tile 0 in the group that owns it, in front of its first tile in the other group: in both, the
+            // counted wait for "everything but my younger tiles" covers them
+            if constexpr ((PD & 1) != G) z_late_load();
 #pragma unroll
-            for (int u = 0; u < PD; ++u)
+            for (int u = 0; u < PD; ++u) {
                 if (((u + PD) & 1) == G && u < nt) issue(u, IB{}, IE{});
-            z_late_load();
-            if constexpr ((PD & 1) == G) {   // owner of tile 0
-                const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
-                wait_younger<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0);
+                if (u == 0 && (PD & 1) == G) z_late_load();
             }
+            {
+                const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
+                if constexpr ((PD & 1) == G) wait_younger<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0);      // owner of tile 0: own younger tiles 2, 4, ...
+                else if constexpr (ZP) wait_younger<NP, PD / 2>((last + 1) / 2);                            // the other group: own tiles 1, 3, ... stay in flight
+            }
+            z_finish();
             barrier();
             // end of interval i: the owner of tile i + 1 -- group (i + 1 + PD) & 1 -- makes sure it has landed.  Group G's LOAD intervals are
             // i = G mod 2, so it owns tile i + 1 at the end of its LOAD intervals iff PD is odd, at the end of its MFMA (and idle) intervals
@@ -826,7 +833,6 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
     if constexpr (SCHED == 2) {
-        z_finish();   // (mu, r) of the tile's rows and G' / C' of its columns -> LDS behind the ring, in front of the exchange barriers (LayerNorm algebra; no-op otherwise)
         // EPI_RESID: the residual rows this wave finishes after the exchange (16 rows x the tile's columns) are requested NOW and land under the exchange
         constexpr int RF = EPI == EPI_RESID ? FM / 2 : 1, RN = EPI == EPI_RESID ? FN : 1;
         float4 rres[RF][RN];
@@ -901,7 +907,6 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) pp_store_direct<HF, FN, TM / 2, TN, EPI>(a, half, row0, col0, ewm, wn, lane, z);
     } else {
-        if constexpr (ZM) { z_finish(); __syncthreads(); }   // (inside the last K tile's step instead -- no barrier, GELU math still under the other group's last MFMAs -- measured the same: 27.10 vs 27.29 us)
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {

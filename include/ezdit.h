@@ -233,7 +233,9 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *     the ping-pong kernel's 128 x 144 tile above (zbig 0/1) -- the consumer GEMM finishing the LayerNorm in its epilogue: no split-K slabs, no row
  *     kernel on those edges; needs gemm_pp = 3 and a LayerNorm-algebra q projection (fuse_q2 at small grids, q2_pp above)); ztile (70 ... 77:
  *     k_gemm_ks tile, csrc/gemm.hip), zmlp 0/1 and zskip 0/1 (MLP-out / skip_linear on the un-split producer too)
- *   q2_pp 0/1 (cross-attention q projection at grids too large for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue)
+ *   q2_pp 0/1 (cross-attention q projection at grids too large for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue),
+ *     zbig_m (rows above which the 128 x 144 producer replaces k_gemm_ks, default 2048), tile_pe / tile_fin (patch-embed / final-Linear GEMM at
+ *     M <= 2048: a k_gemm_ks tile id, -1 = tile_f32)
  *   zfake 0/1 (DIAGNOSTIC, default 0: the consumers run their LayerNorm-algebra variant on a finished LayerNorm with neutral tables -- what
  *     the consumer side costs by itself; results change by the factor rsqrt(1 + 1e-5))
  *   gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and

@@ -182,7 +182,7 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
              'geglu_big', 'split18', 'split36', 'split72', 'split_big', 'xcd_map', 'slab_bf16', 'wt', 'fuse_qkv', 'qkv_waves9', 'fuse_q2',
              'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'cn_overlap', 'gemm_pp', 'zfuse', 'pp_max_m',
              'gemm_panel', 'row_affine', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2', 'stamp_launch', 'trace_launches', 'ztile', 'zmlp', 'zskip', 'zbig',
-             'q2_pp', 'zfake']
+             'q2_pp', 'zfake', 'zbig_m', 'tile_pe', 'tile_fin']
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
     for n in names:
         assert n in src, n
