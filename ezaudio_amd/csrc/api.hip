@@ -110,7 +110,9 @@ struct ezdit_handle {
     int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
     // M > 2048 rows (batched prompts): the large-tile kernel (k_gemm2, 256x256) for the residual and GEGLU GEMMs; split_big 0 = as
     // many K splits as keep the grid within one round of the 256 CUs (measured on MI355X at M = 4000: -2.6 % per step vs round 1's tiles)
-    int opt_tile_partial_big = 40, opt_tile_f32_big = 25, opt_geglu_big = 40, opt_split_big = 0;
+    // round 4: the split-K residual GEMMs that remain at M > 2048 (the MLP-outs in front of the out-blocks; every residual GEMM when zfuse is off) on the ping-pong
+    // kernel's 128 x 288 tile with split-K 2 -- 32 x 4 x 2 = 256 workgroups at M = 4000, no N padding: 10.70 -> 10.46 ms per step of 4 against k_gemm2 (id 40)
+    int opt_tile_partial_big = 60, opt_tile_f32_big = 25, opt_geglu_big = 40, opt_split_big = 2;
     int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
     int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
     int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp) at M <= 2048: bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); the residual GEMMs select it through tile_partial = 62

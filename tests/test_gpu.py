@@ -85,6 +85,8 @@ def t_(a, dev='cuda:0'):
     (130, 128, 64, 62 * 4 + 0, 1),
     (1000, 1152, 2304, 16000 + 62 * 4 + 1, 3), # bf16 slabs
     (300, 200, 192, 16000 + 62 * 4 + 1, 2),
+    (4000, 1152, 4608, 16000 + 8000 + 60 * 4 + 1, 2),   # the batched-prompt MLP-out configuration: 128x288, split-K 2, bf16 slabs through LDS
+    (4000, 1152, 1152, 16000 + 8000 + 60 * 4 + 1, 2),
     (1000, 3456, 1152, 61 * 4 + 0, 1),
     (130, 144, 64, 61 * 4 + 0, 1),
     (200, 288, 128, 61 * 4 + 0, 1),
