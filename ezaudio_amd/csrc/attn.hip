@@ -250,12 +250,12 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                     if constexpr (ZQ) v[e] = fmaf(zr, v[e], fmaf(-zr * zmu, zgc_l[col], zgc_l[DQK + col]));
                     s1 += v[e];
                 }
-                s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+                s1 = oct_sum(s1);   // the 8 threads of a row are an aligned octet (DPP, common.h)
                 const float mean = s1 * (1.f / DH);
                 float s2 = 0.f;
 #pragma unroll
                 for (int e = 0; e < CP; ++e) { const float d = v[e] - mean; s2 += d * d; }
-                s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+                s2 = oct_sum(s2);
                 const float rstd = rsqrtf(s2 * (1.f / DH) + 1e-5f);
 #pragma unroll
                 for (int e = 0; e < CP; ++e) {

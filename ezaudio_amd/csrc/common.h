@@ -83,6 +83,15 @@ struct ZStatRegs { float2 v[Z_PT]; };
 // xor-shuffles inside a quad by DPP (hipcc lowers __shfl_xor to ds_bpermute: an LDS-pipe round trip)
 __device__ __forceinline__ float quad_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
 __device__ __forceinline__ float quad_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }
+// sum over the 8 neighbouring lanes of an aligned octet, in every lane, in the order of  s += xor 1; s += xor 2; s += xor 4  (bit-identical to the
+// __shfl_xor form): after the two quad steps all four lanes of a quad hold the quad's sum, and row_half_mirror (lane i <- lane 7 - i) hands every
+// lane the OTHER quad's
+__device__ __forceinline__ float oct_sum(float s) {
+    s += quad_xor1(s);
+    s += quad_xor2(s);
+    return s + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));
+}
+__device__ __forceinline__ uint32_t quad_xor1_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true); }
 // The loads are UNCONDITIONAL (part index clamped) and their results are not touched here: a select on a loaded value made hipcc wait for
 // the loads at kernel start, in front of the first LDS-DMA (k_attn: +1.7 us per launch); the unused parts are masked in z_row_stats_finish
 __device__ __forceinline__ void z_row_stats_load(const float2* __restrict__ st /* + row */, long stride, int parts, int pg, ZStatRegs& z) {

@@ -713,7 +713,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
     if (EPI == EPI_PARTIAL && a.xcd_panel && BM == 128) grid.x = 8 * ((a.N + BN - 1) / BN) * a.splitk * (((a.M + BM - 1) / BM + 7) / 8);   // M tile tm -> XCD tm % 8 (gemm_pp.h)
     else a.xcd_panel = 0;
-    constexpr int SMEM = NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 3 : 2) * BN * 4;   // ring + (mu, r) of the tile's rows + G' / C' (EPI_RESID: bias / gate / gain) of its columns (LayerNorm algebra)
+    constexpr int SMEM = pp_smem_bytes<BM, BN, NS, EPI>();   // ring + (mu, r) of the tile's rows + G' / C' (EPI_RESID: bias / gate / gain) of its columns (LayerNorm algebra) [+ EPI_QKV: warm-up sink]
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     static std::atomic<bool> attr_set[32];   // per (kernel, device); two host threads may race here on first use (harmless double set)
     int dev = 0;

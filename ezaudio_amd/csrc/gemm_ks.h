@@ -288,8 +288,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         float s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < SL; ++q) s2 = fmaf(v[q].x, v[q].x, fmaf(v[q].y, v[q].y, fmaf(v[q].z, v[q].z, fmaf(v[q].w, v[q].w, s2))));
-        s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
-        s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+        s1 = oct_sum(s1);   // DPP: three VALU moves instead of three dependent LDS-pipe round trips (ds_bpermute) per sum
+        s2 = oct_sum(s2);
         if (ej == 0 && row_ok) a.zstat_out[(long)tn * a.zs_stride + erow] = make_float2(s1, s2);   // part-major: the consumer's loads are contiguous over rows
         // A' = bf16(h_new * zg) as whole 16-byte chunks (8 columns)
         uint2 pk[SL];
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             // the single slot: lanes (2 i, 2 i + 1) hold the two halves of one 8-column chunk; the even lane stores it
             const uint2 mine = pk[SL - 1];
             uint2 other;
-            other.x = __shfl_xor(mine.x, 1, 64);
-            other.y = __shfl_xor(mine.y, 1, 64);
+            other.x = quad_xor1_u32(mine.x);
+            other.y = quad_xor1_u32(mine.y);
             if ((ej & 1) == 0) store8(col0 + 4 * ks_slot_of<SL>(SL - 1, ej), mine, other);
         }
     }

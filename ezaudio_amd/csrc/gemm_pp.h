@@ -379,28 +379,68 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
             }
         }
     }
-    __syncthreads();                                                      // every wave is done with the ring
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-            *reinterpret_cast<f32x4*>(tile + (wm * TM + i * 16 + m_in) * PITCH + wn * TN + j * 16 + 4 * cg) = acc[i][j];
-    __syncthreads();
     const HeadNormArgs& hn = a.hn;
     const int D = hn.H * DH;
     const int part = col0 / D;                 // 0 q, 1 k, 2 v
     const int head0 = (col0 % D) / DH;         // first head of this tile
+    // q / k tiles: 4 lanes per (row, head), each owns E = DH / 4 contiguous channels; a thread's items are it = tid + NT k (same sub-lane every time).
+    // Its LayerNorm weights and the RoPE rows of its first item are requested HERE, in front of the two barriers and the fp32 park, the other items'
+    // rows right behind the park -- not inside the item loop behind the LayerNorm arithmetic: there every item waited a full L2 round trip for 2 E table values (in-situ stamps: the q / k
+    // tiles' epilogue took 17K cycles against 10K of the v tiles, and the kernel ends with its slowest workgroup)
+    constexpr int E = DH / 4, ITEMS = BM * NH * 4 / NT;
+    static_assert(ITEMS * NT == BM * NH * 4 && E % 2 == 0, "whole items per thread, float2 pieces");
+    const int sub = tid & 3;
+    const bool rope = part < 2 && hn.rope_cos != nullptr;
+    float2 wv[E / 2], bv[E / 2], csv[ITEMS][E / 2], snv[ITEMS][E / 2];
+    // behind the LayerNorm-algebra arithmetic above, not in front of it: with per-row timesteps that arithmetic waits for its own global loads, and
+    // the (static) vmcnt in front of it would drain these requests too on every path.  hipcc sinks the arithmetic towards the park below (past a
+    // sched_barrier as well): the empty asm "modifies" the accumulators here, and its memory clobber keeps the loads below it
+    if constexpr (ZC) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]) : : "memory");
+    }
+    auto park = [&]() {   // fp32 tile -> LDS (the ring is dead behind the barrier)
+        __syncthreads();                                                  // every wave is done with the ring
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4*>(tile + (wm * TM + i * 16 + m_in) * PITCH + wn * TN + j * 16 + 4 * cg) = acc[i][j];
+    };
+    // ONE region for the q / k tiles (barriers and park duplicated in the v branch, `part` is uniform over the workgroup): hipcc's vmcnt bookkeeping is
+    // path-insensitive -- with the requests and their uses in separate `if (part < 2)` blocks it assumed the later requests might not have been
+    // issued and drained all of them at the first use
     if (part < 2) {
-        // 4 lanes per (row, head): each owns DH / 4 contiguous channels; LN via two xor-shuffles, RoPE partner (i +- DH/2) in lane ^ 2
-        constexpr int E = DH / 4;
-        const float* w = part == 0 ? hn.qn_w : hn.kn_w;
-        const float* bb = part == 0 ? hn.qn_b : hn.kn_b;
+        const float2* w2 = reinterpret_cast<const float2*>((part == 0 ? hn.qn_w : hn.kn_w) + sub * E);
+        const float2* b2 = reinterpret_cast<const float2*>((part == 0 ? hn.qn_b : hn.kn_b) + sub * E);
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) { wv[i] = w2[i]; bv[i] = b2[i]; }
+        // item k's cos / sin pieces.  Without RoPE (the cross-attention q projection) the same loads read the LayerNorm weight instead and go unused
+        // (a conditional load between a request and its use has the same effect on the vmcnt bookkeeping)
+        auto rope_rows = [&](int k) {
+            const int m = row0 + ((tid + k * NT) >> 2) / NH;
+            const int l = (m < a.M ? m : a.M - 1) % hn.L;
+            const float* w = part == 0 ? hn.qn_w : hn.kn_w;
+            const float2* c2 = reinterpret_cast<const float2*>((rope ? hn.rope_cos + (long)l * (DH / 2) : w) + (sub & 1) * E);
+            const float2* s2 = reinterpret_cast<const float2*>((rope ? hn.rope_sin + (long)l * (DH / 2) : w) + (sub & 1) * E);
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) { csv[k][i] = c2[i]; snv[k][i] = s2[i]; }
+        };
+        rope_rows(0);
+        park();
+        // the accumulators are parked: their registers take the later items' rows (all of them up front did not fit: scratch spills)
+#pragma unroll
+        for (int k = 1; k < ITEMS; ++k) rope_rows(k);
+        __syncthreads();
+        // LN via two xor-shuffles inside the quad, RoPE partner (i +- DH/2) in lane ^ 2: DPP, not __shfl_xor (ds_bpermute: 22 LDS-pipe round trips per item)
         bf16_t* dstbase = part == 0 ? hn.q : hn.k;
-        for (int it = tid; it < BM * NH * 4; it += NT) {
-            const int sub = it & 3, hh = (it >> 2) % NH, r = (it >> 2) / NH;
-            const int m = row0 + r;
-            const int mm = m < a.M ? m : a.M - 1;
-            const int l = mm % hn.L;
+        const float sign = (sub & 2) ? 1.f : -1.f;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int it = tid + k * NT;
+            const int hh = (it >> 2) % NH, r = (it >> 2) / NH;
             const float* src = tile + r * PITCH + hh * DH + sub * E;
             float v[E];
 #pragma unroll
@@ -411,25 +451,26 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
             float s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < E; ++i) s1 += v[i];
-            s1 += __shfl_xor(s1, 1, 64);
-            s1 += __shfl_xor(s1, 2, 64);
+            s1 += quad_xor1(s1);
+            s1 += quad_xor2(s1);
             const float mean = s1 * (1.f / DH);
             float q2 = 0.f;
 #pragma unroll
             for (int i = 0; i < E; ++i) { const float d = v[i] - mean; q2 += d * d; }
-            q2 += __shfl_xor(q2, 1, 64);
-            q2 += __shfl_xor(q2, 2, 64);
+            q2 += quad_xor1(q2);
+            q2 += quad_xor2(q2);
             const float rstd = rsqrtf(q2 * (1.f / DH) + 1e-5f);
 #pragma unroll
-            for (int i = 0; i < E; ++i) v[i] = (v[i] - mean) * rstd * w[sub * E + i] + bb[sub * E + i];
-            if (hn.rope_cos) {
-                const float* cs = hn.rope_cos + (long)l * (DH / 2) + (sub & 1) * E;
-                const float* sn = hn.rope_sin + (long)l * (DH / 2) + (sub & 1) * E;
-                const float sign = (sub & 2) ? 1.f : -1.f;
+            for (int i = 0; i < E / 2; ++i) {
+                v[2 * i] = (v[2 * i] - mean) * rstd * wv[i].x + bv[i].x;
+                v[2 * i + 1] = (v[2 * i + 1] - mean) * rstd * wv[i].y + bv[i].y;
+            }
+            if (rope) {
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const float other = __shfl_xor(v[i], 2, 64);
-                    v[i] = v[i] * cs[i] + sign * other * sn[i];
+                for (int i = 0; i < E / 2; ++i) {
+                    const float o0 = quad_xor2(v[2 * i]), o1 = quad_xor2(v[2 * i + 1]);
+                    v[2 * i] = v[2 * i] * csv[k][i].x + sign * o0 * snv[k][i].x;
+                    v[2 * i + 1] = v[2 * i + 1] * csv[k][i].y + sign * o1 * snv[k][i].y;
                 }
             }
             bf16_t* dst = qk_st + (r * NH + hh) * DH + sub * E;   // written out below as whole 16-byte chunks (a head is 9 or 8 of them)
@@ -450,6 +491,8 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
             }
         }
     } else {
+        park();
+        __syncthreads();
         // V^T[b][h][d][l]: consecutive lanes take consecutive ROW PAIRS (l, l + 1) of one channel d -> contiguous 4-byte stores
         // (row0, L and Lp are even, so a pair never straddles a batch element and is 4-byte aligned)
         if ((hn.L & 1) == 0) {
@@ -483,6 +526,12 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
 // timing ablations (results are garbage; EZ_ABLATE builds): 8 = no MFMAs, 16 = no fragment reads, 32 = no LDS-DMA refill inside the loop.  Measured and dropped (MI355X, 128x288 tile, cycles per K tile): s_setprio(1) over the MFMA phase 1809 vs 1793,
 // over the LOAD phase 1806, static priority for group 1 1819 -- priorities do not move this loop.
 // GemmArgs.ts (test hook, nullable): wave 0 of every workgroup records s_memtime at kernel start, loop start, loop end, kernel end
+// dynamic LDS of k_gemm_pp: ring | (mu, r) per row | per-column vectors | EPI_QKV: 256 bytes per wave that the RoPE-table warm-up DMA lands in
+template <int BM, int BN, int NS, int EPI>
+constexpr int pp_smem_bytes() {
+    return NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 3 : 2) * BN * 4 + (EPI == EPI_QKV ? 8 * 256 : 0);
+}
+
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR>
 __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     static_assert(SCHED == 1 || SCHED == 2, "schedule");
@@ -496,7 +545,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr int STAGE = NP * 4096;
     constexpr int PD = NS - 1;                 // prefetch distance in K tiles
     static_assert(NS >= 3 && NS <= 6, "ring depth");
-    static_assert(NS * STAGE + BM * 8 + (EPI == EPI_RESID ? 3 : 2) * BN * 4 <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics + G' / C' (or bias / gate / gain) of the tile's columns)");
+    static_assert(pp_smem_bytes<BM, BN, NS, EPI>() <= 160 * 1024, "LDS budget of a CU (ring + per-row LayerNorm statistics + G' / C' (or bias / gate / gain) of the tile's columns [+ EPI_QKV: sink of the table warm-up])");
     constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -545,6 +594,20 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // of the first tile (it did: +1 us per consumer launch)
     constexpr bool RGATE = EPI == EPI_RESID && (VAR & 64) != 0, RRES = EPI == EPI_RESID && (VAR & 128) != 0;
     auto z_late_load = [&]() {
+        if constexpr (EPI == EPI_QKV) {
+            // q / k tiles: the RoPE rows of the tile's 128 tokens (2 x 18 KB of the cos / sin tables) are read in the epilogue, by every workgroup
+            // at the same time, and no longer in the L2 by then (the kernels in between stream through it): each thread pulls one end of one row
+            // of one table towards its L2 now -- a 4-byte LDS-DMA into a sink, nothing waits for it, no register is held
+            const HeadNormArgs& hn = a.hn;
+            if (hn.rope_cos && col0 < 2 * hn.H * hn.dh) {
+                const int r = tid >> 2, which = tid & 3;
+                int m = row0 + r;
+                m = m < a.M ? m : a.M - 1;
+                const char* src = reinterpret_cast<const char*>((which & 2) ? hn.rope_sin : hn.rope_cos) + ((long)(m % hn.L) * (hn.dh / 2) + ((which & 1) ? hn.dh / 2 - 1 : 0)) * 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(smem + NS * STAGE + BM * 8 + 2 * BN * 4 + wave * 256), 4, 0, 0);
+            }
+        }
         if constexpr (EPI == EPI_RESID) {   // producer side: bias | gate | gain of the tile's columns, one float4 per thread (the modulation slot is shared: launch_gemm checks)
             static_assert(3 * (BN / 4) <= NT, "one float4 per thread");
             if (tid < 3 * (BN / 4)) {
