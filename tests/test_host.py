@@ -389,6 +389,58 @@ def test_bench_line_extras_are_wired():
     assert abs(bench.flops_per_step(cfg, 2, 500, 100) / 1e12 - 1.541) < 1e-3
 
 
+_ISA_CACHE = {}
+
+
+def _gfx950_isa(src):
+    """{mangled kernel name: its gfx950 assembly} of one translation unit of csrc/, compiled with the flags of the shipped build (cached per test session)."""
+    if src not in _ISA_CACHE:
+        import re
+        import subprocess
+        import tempfile
+        from ezaudio_amd import build
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, src + '.s')
+            subprocess.check_call([build._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
+                                   os.path.join(ROOT, 'ezaudio_amd', 'csrc', src), '-o', out], stderr=subprocess.DEVNULL)
+            text = open(out).read()
+        _ISA_CACHE[src] = {f.split(':', 1)[0]: f for f in re.split(r'\n(?=_Z\w+:)', text) if f.startswith('_Z')}
+    return _ISA_CACHE[src]
+
+
+def test_kernels_of_the_default_step_neither_spill_nor_shuffle_through_the_lds():
+    """Structural facts the round-4 epilogue work rests on, checked on the code hipcc generates today: (1) no kernel of the default step (one or four
+    prompts) uses scratch memory -- the fused-QKV epilogue's table prefetch spilled when all of it was requested up front, and a spilling kernel
+    pays a scratch set-up per launch; (2) the fused-QKV and K-split kernels contain no ds_bpermute (their quad / octet shuffles are DPP: a
+    __shfl_xor that creeps back in is 100+ cycles of LDS pipe inside a dependency chain); (3) the fused-QKV kernels wait for their epilogue
+    tables with COUNTED vmcnt (>= 10 younger loads left in flight somewhere), not with a drain at the first use."""
+    import re
+    funcs = _gfx950_isa('gemm.hip')
+
+    def tmpl(name):   # '..k_gemm_ppILi128ELi144E..' -> ('k_gemm_pp', [128, 144, ...]); Lb1E / Lb0E are booleans
+        m = re.search(r'(k_gemm_pp|k_gemm_ks|k_gemm2|k_gemm)I((?:L[ib]\d+E)+)', name)
+        return (m.group(1), [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(2))]) if m else (None, [])
+
+    default_step = {   # launch_gemm's instantiations on the default path (profiles/r04b_kernel_trace*.txt)
+        ('k_gemm_pp', (128, 288, 4, 2, 3)), ('k_gemm_pp', (128, 144, 4, 1, 4)), ('k_gemm_ks', (3, 6)), ('k_gemm_ks', (3, 4)),
+        ('k_gemm', (128, 128, 4, 2, 3)), ('k_gemm', (128, 64, 4, 2, 4)),
+    }
+    seen = set()
+    for name, f in funcs.items():
+        kind, args = tmpl(name)
+        key = next((k for k in default_step if k[0] == kind and tuple(args[:len(k[1])]) == k[1]), None)
+        if key is None:
+            continue
+        seen.add(key)
+        assert 'scratch_' not in f, f'{name} spills to scratch'
+        if kind == 'k_gemm_ks' or (kind == 'k_gemm_pp' and args[5] == 3):   # EPI_QKV = 3
+            assert 'ds_bpermute' not in f, f'{name} shuffles through the LDS pipe'
+        if kind == 'k_gemm_pp' and args[5] == 3:
+            waits = [int(x) for x in re.findall(r's_waitcnt vmcnt\((\d+)\)', f)]
+            assert max(waits) >= 20, (name, sorted(set(waits)))   # weights behind 2 x 10 younger table loads
+    assert seen == default_step, default_step - seen
+
+
 def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     """k_gemm_pp, k_gemm_ks and k_attn issue their MFMAs from inline asm, so hipcc's hazard recogniser neither sees them nor pads behind them
     (round-3 ADVICE): the wait states between the LAST MFMA of an accumulation chain and the first non-MFMA read of its accumulator are
@@ -397,37 +449,27 @@ def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     VGPR accumulators of k_attn) sits at least 18 issue slots (s_nop N counts N + 1) behind the textually preceding MFMA -- a refactor or a
     compiler upgrade that moves a reader up fails here instead of corrupting tiles silently."""
     import re
-    import subprocess
-    import tempfile
-    from ezaudio_amd import build
-    src_dir = os.path.join(ROOT, 'ezaudio_amd', 'csrc')
-    with tempfile.TemporaryDirectory() as td:
-        for src, kernels in (('gemm.hip', ('k_gemm_pp', 'k_gemm_ks')),):
-            out = os.path.join(td, src + '.s')
-            subprocess.check_call([build._hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '--cuda-device-only', '-S',
-                                   os.path.join(src_dir, src), '-o', out], stderr=subprocess.DEVNULL)
-            text = open(out).read()
-            funcs = re.split(r'\n(?=_Z\w+:)', text)
-            checked = 0
-            for f in funcs:
-                name = f.split(':', 1)[0]
-                if not any(k in name for k in kernels) or 'v_mfma' not in f:
+    for src, kernels in (('gemm.hip', ('k_gemm_pp', 'k_gemm_ks')),):
+        funcs = _gfx950_isa(src)
+        checked = 0
+        for name, f in funcs.items():
+            if not any(k in name for k in kernels) or 'v_mfma' not in f:
+                continue
+            lines = [l.strip() for l in f.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
+            dist = None          # issue slots since the last MFMA
+            for ins in lines:
+                op = ins.split()[0]
+                if op.startswith('v_mfma'):
+                    dist = 0
                     continue
-                lines = [l.strip() for l in f.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
-                dist = None          # issue slots since the last MFMA
-                for ins in lines:
-                    op = ins.split()[0]
-                    if op.startswith('v_mfma'):
-                        dist = 0
-                        continue
-                    if dist is None:
-                        continue
-                    reads_acc = (op == 'v_accvgpr_read_b32') or (op.startswith(('ds_write', 'global_store', 'v_')) and re.search(r'\ba\[?\d', ins.split(None, 1)[1] if ' ' in ins else ''))
-                    if reads_acc and not op.startswith('v_accvgpr_write'):
-                        assert dist >= 18, (name, ins, dist)
-                        dist = None          # chain consumed; the next MFMA re-arms the check
-                        checked += 1
-                        continue
-                    m = re.match(r's_nop (\d+)', ins)
-                    dist += int(m.group(1)) + 1 if m else 1
-            assert checked >= 10, checked
+                if dist is None:
+                    continue
+                reads_acc = (op == 'v_accvgpr_read_b32') or (op.startswith(('ds_write', 'global_store', 'v_')) and re.search(r'\ba\[?\d', ins.split(None, 1)[1] if ' ' in ins else ''))
+                if reads_acc and not op.startswith('v_accvgpr_write'):
+                    assert dist >= 18, (name, ins, dist)
+                    dist = None          # chain consumed; the next MFMA re-arms the check
+                    checked += 1
+                    continue
+                m = re.match(r's_nop (\d+)', ins)
+                dist += int(m.group(1)) + 1 if m else 1
+        assert checked >= 10, checked
