@@ -35,6 +35,23 @@ __global__ void k_ref(const uint16_t* A, int lda, const uint16_t* W, int ldw, fl
     C[(long)m * N + n] = s;
 }
 
+// ---- L2-residency experiment (resid section, "l2" lines): what would a launch gain if the PREVIOUS kernel had pulled its weights into every
+// XCD's L2?  k_stream evicts the L2s (not the Infinity Cache) by streaming a buffer larger than 8 x 4 MB through all XCDs; k_touch makes every
+// XCD (workgroup b runs on XCD b % 8) read every 128-byte line of [p, p + bytes): afterwards each of the eight L2s holds the whole range.
+__global__ void k_stream(const uint4* p, size_t n16, unsigned* sink) {
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    if (acc == 0x12345678u) *sink = acc;   // never true for the buffers used here: keeps the loads
+}
+__global__ void k_touch(const char* p, size_t bytes, unsigned* sink) {
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    (void)xcd;
+    unsigned acc = 0;
+    const size_t lines = (bytes + 127) / 128;
+    for (size_t i = (size_t)l * blockDim.x + threadIdx.x; i < lines; i += (size_t)per_xcd * blockDim.x) acc ^= *reinterpret_cast<const unsigned*>(p + i * 128);
+    if (acc == 0x12345678u) *sink = acc;
+}
+
 struct Shape { const char* name; int M, N, K; };
 struct Cfg { const char* name; int tile, epi, splitk, var, lds; };
 
@@ -241,6 +258,37 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < citers; ++i) { float m1 = 0; CHECK(hipEventElapsedTime(&m1, ev[2 * i], ev[2 * i + 1])); cold_us += m1 * 1e3 / citers; }
                 for (auto& e : ev) CHECK(hipEventDestroy(e));
                 printf("   %-34s %8.2f us warm  %8.2f us cold (event pair around one launch)  %7.1f TF warm\n", name, warm_us, cold_us, 2.0 * M * N * K / warm_us * 1e-6);
+                {
+                    // "as inside the step": weights and activations in the Infinity Cache, nothing in the L2s -- then the same with the weights
+                    // (and, for scale, also the activations) pulled into every XCD's L2 right in front of the launch.  The difference is the
+                    // most a next-kernel weight prefetch issued by the previous kernel could buy this launch.
+                    static unsigned* dsink = nullptr;
+                    if (!dsink) CHECK(hipMalloc(&dsink, 4));
+                    const size_t EVICT = (size_t)96 << 20;   // > 8 x 4 MB of L2, < 256 MB of Infinity Cache
+                    const size_t wbytes = (size_t)N * K * 2, abytes = (size_t)M * K * 2;
+                    auto timed = [&](int mode) {   // 0: L2-cold, 1: + weights in every L2, 2: + weights and activations in every L2
+                        double us = 0;
+                        std::vector<hipEvent_t> ev2(2 * citers);
+                        for (auto& e : ev2) CHECK(hipEventCreate(&e));
+                        for (int i = 0; i < citers; ++i) {
+                            k_touch<<<256, 512, 0, st>>>(reinterpret_cast<const char*>(dW), wbytes, dsink);          // into the Infinity Cache (and some L2s)
+                            k_touch<<<256, 512, 0, st>>>(reinterpret_cast<const char*>(dA), abytes, dsink);
+                            k_stream<<<1024, 256, 0, st>>>(reinterpret_cast<const uint4*>(dflush) + (size_t)(i & 3) * (EVICT / 16), EVICT / 16, dsink);   // out of the L2s
+                            if (mode >= 1) k_touch<<<256, 512, 0, st>>>(reinterpret_cast<const char*>(dW), wbytes, dsink);
+                            if (mode >= 2) k_touch<<<256, 512, 0, st>>>(reinterpret_cast<const char*>(dA), abytes, dsink);
+                            CHECK(hipEventRecord(ev2[2 * i], st));
+                            run();
+                            CHECK(hipEventRecord(ev2[2 * i + 1], st));
+                        }
+                        CHECK(hipStreamSynchronize(st));
+                        for (int i = 0; i < citers; ++i) { float m1 = 0; CHECK(hipEventElapsedTime(&m1, ev2[2 * i], ev2[2 * i + 1])); us += m1 * 1e3 / citers; }
+                        for (auto& e : ev2) CHECK(hipEventDestroy(e));
+                        return us;
+                    };
+                    const double c0 = timed(0), c1 = timed(1), c2 = timed(2);
+                    printf("      l2: operands in the Infinity Cache only %8.2f us | + weights (%.1f MB) in every L2 %8.2f us | + activations too %8.2f us   (warm back-to-back %.2f)\n",
+                           c0, wbytes / 1048576.0, c1, c2, warm_us);
+                }
                 const int NWG = 8192;
                 unsigned long long* dts; CHECK(hipMalloc(&dts, NWG * 8 * 8)); CHECK(hipMemsetAsync(dts, 0, NWG * 8 * 8, st));
                 ezdit_debug_gemm_timestamps(dts, NWG); run(); ezdit_debug_gemm_timestamps(nullptr, 0);
