@@ -263,10 +263,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true', help='skip the dominant-kernel probe (profiling passes)')
-    ap.add_argument('--no-prefetch', action='store_true', help='A/B: disable the Infinity-Cache weight prefetcher')
-    ap.add_argument('--geglu-tile', type=int, default=-1)
     ap.add_argument('--opt', action='append', default=[], help='name=value tuning knob passed to ezdit_set_option')
-    ap.add_argument('--prefetch', action='store_true')
     ap.add_argument('--controlnet', action='store_true', help='BASELINE config #5: add an energy ControlNet of the same width')
     ap.add_argument('--dist-backend', default='nccl', help="torch.distributed backend: 'nccl' (= RCCL over xGMI, the real thing) or 'gloo' "
                                                            '(test mode: latents are gathered through host memory)')
@@ -318,12 +315,6 @@ def main():
     sd = random_state_dict(cfg, seed=1234)
     unet = MaskDiT(device=dev, **cfg)
     unet.load_state_dict(sd)
-    if a.no_prefetch:
-        unet.lib.ezdit_set_option(unet._h, b'prefetch', 0)
-    if a.geglu_tile >= 0:
-        unet.lib.ezdit_set_option(unet._h, b'geglu_tile', a.geglu_tile)
-    if a.prefetch:
-        unet.lib.ezdit_set_option(unet._h, b'prefetch', 1)
     for kv in a.opt:
         k, v = kv.split('=')
         assert unet.lib.ezdit_set_option(unet._h, k.encode(), int(v)) == 0, kv

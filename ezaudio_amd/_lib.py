@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libezaudio_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class EzditConfig(C.Structure):
@@ -75,7 +75,6 @@ PROTOTYPES = {
     'ezdit_test_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'ezdit_debug_buffer': (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
-    'ezdit_device_status': (C.c_int, [C.c_void_p, C.c_void_p]),
     'ezdit_last_launch_count': (C.c_int, [C.c_void_p]),
     'ezdit_debug_stop_after': (C.c_int, [C.c_void_p, C.c_int]),
     'ezdit_set_option': (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

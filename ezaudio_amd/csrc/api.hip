@@ -56,6 +56,7 @@ struct WsPtrs {  // workspace regions used on the per-step path, resolved once a
     uint8_t* kmask; bf16_t *kc, *vct; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
     float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
+    float* zd;   // [nblk][B][D] constant cross-attention-out vectors of the single-key batch elements (opt_xkey1)
 };
 
 static unsigned long long* g_gemm_ts = nullptr;   // ezdit_debug_gemm_timestamps: device buffer for in-kernel cycle stamps (gemm_pp.h, gemm_ks.h, attn.hip)
@@ -100,65 +101,58 @@ struct ezdit_handle {
     float fwd_cn_scale = 1.0f;   // scale ezdit_forward applies to caller-provided residuals (ezdit_set_cn_scale; default 1)
     std::vector<ezdit_handle*> cn_users;  // backbones whose sampler has this ControlNet attached (cleared on destroy)
     const float* ext_mask_embed = nullptr;
-    int geglu_tile = -1;  // tuning override (tests/bench)
-    size_t step_weights_end = 0;
-    hipStream_t pf_stream = nullptr;   // side stream of the weight prefetcher
-    std::vector<hipEvent_t> pf_events;  // fork/join events (one pair per use so capture sees distinct nodes)
-    int prefetch = 0;      // measured -12 % on MI355X (profiles/): the side stream disturbs the GEMMs more than warm weights help
-    // tuning knobs (M <= 2048 rows); defaults from tools/bench_cold.py + tools/ab_sweep.py on MI355X: 128x128 8-wave tiles with a
-    // 3-deep ring and split-K 3 (216 workgroups, 3 slabs) for the residual GEMMs, 128x64 8-wave ring 4 for the small fp32 ones
-    int opt_split18 = 3, opt_split36 = 3, opt_split72 = 3, opt_tile_partial = 9, opt_tile_f32 = 25, opt_xcd_map = 1;
-    // M > 2048 rows (batched prompts): the large-tile kernel (k_gemm2, 256x256) for the residual and GEGLU GEMMs; split_big 0 = as
-    // many K splits as keep the grid within one round of the 256 CUs (measured on MI355X at M = 4000: -2.6 % per step vs round 1's tiles)
-    // round 4: the split-K residual GEMMs that remain at M > 2048 (the MLP-outs in front of the out-blocks; every residual GEMM when zfuse is off) on the ping-pong
-    // kernel's 128 x 288 tile with split-K 2 -- 32 x 4 x 2 = 256 workgroups at M = 4000, no N padding: 10.70 -> 10.46 ms per step of 4 against k_gemm2 (id 40)
-    int opt_tile_partial_big = 60, opt_tile_f32_big = 25, opt_geglu_big = 40, opt_split_big = 2;
-    int opt_fuse_resid = 0;                                                               // D x D projections: residual in the GEMM epilogue
-    int opt_qkv_waves9 = 1;                                                               // fused QKV (dh 72): 1x9 waves instead of 2x3
-    int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp) at M <= 2048: bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); the residual GEMMs select it through tile_partial = 62
+    // ---- fixed tile / split-K choices (measured on MI355X in rounds 1-4; the per-shape override options they used to be
+    // were deleted in round 5: nothing but the experiments that settled them ever set a non-default value) ----
+    // M <= 2048 rows: 128 x 128 8-wave tiles with a 3-deep ring and split-K 3 (216 workgroups, 3 bf16 slabs) for the residual GEMMs that still run
+    // split-K, 128 x 64 8-wave ring 4 for the small fp32 ones; patch embed and final Linear on the K-split kernel (k_gemm_ks: 252 / 42 workgroups)
+    static constexpr int kSplitK = 3, kTileF32 = 25, kTilePE = 70, kTileFin = 73;
+    // M > 2048 rows (batched prompts): the split-K residual GEMMs that remain on the ping-pong kernel's 128 x 288 tile with split-K 2 (32 x 4 x 2 =
+    // 256 workgroups at M = 4000, no N padding); the un-split LayerNorm-algebra producer is the ping-pong kernel's 128 x 144 tile above kZBigM rows
+    // (one round of 256 workgroups at M = 4000) and k_gemm_ks's 48 x 96 tile (id 70) up to there
+    static constexpr int kTilePartialBig = 60, kSplitBig = 2, kZTile = 70, kZBigM = 2048;
+    int opt_tile_partial = 9;   // split-K residual GEMMs at M <= 2048: 9 = lockstep 128 x 128 (k_gemm), 62 = the same tile on the ping-pong kernel
+    int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp): bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); 0 = the round-1/2 lockstep kernels
     // LayerNorm algebra (common.h, GemmArgs.z*): the attention-out, cross-attention-out, skip_linear and (in front of an in / mid block) MLP-out
-    // projections run UN-SPLIT on the K-split-inside-the-workgroup kernel (k_gemm_ks, gemm_ks.h: 48 x 96 tiles, 252 workgroups at M = 1000) with
+    // projections run UN-SPLIT (k_gemm_ks, gemm_ks.h: 48 x 96 tiles, 252 workgroups at M = 1000; the ping-pong kernel's 128 x 144 tile above 2048 rows) with
     // the gated residual, per-column-tile LayerNorm statistics and the next GEMM's operand bf16(h g) in their epilogue; the consumer (fused QKV
     // GEMM, cross-attention q projection, GEGLU GEMM) finishes the LayerNorm in ITS epilogue as r (acc - mu G') + C': no split-K slabs and 86
     // of the 102 row-kernel launches of an XL step less (239 launches instead of 325), the same algebra as the reference (goldens pass at the
-    // same gates).  Round 3 shipped this OFF (its 64 x 128 ping-pong producer filled 144 of 256 CUs: 4.56 vs 4.25 ms); with the new producer
-    // and consumers that wait for nothing at kernel start it is ON: XL one prompt 4.066 -> 4.042 ms per step, EzAudio-L 3.194 -> 3.139 (same
-    // box, profiles/r04_experiments.txt).  Needs gemm_pp bits 0 and 1 and the fused q projection; otherwise (e.g. four prompts per GPU, M = 4000)
-    // the step falls back to split-K slabs + the row kernel.
+    // same gates).  Needs gemm_pp bits 0 and 1 and a LayerNorm-algebra q projection; otherwise the step falls back to split-K slabs + the row kernel.
     int opt_zfuse = 1;
-    int opt_ztile = 70;   // producer of the LayerNorm algebra: 70-75 = K-split-inside-the-workgroup kernel (gemm_ks.h; 70 = 48 x 96 tiles), 63 = ping-pong 64 x 128
-    int opt_zbig = 1;     // M > 2048 (batched prompts): the un-split producer is the ping-pong kernel's 128 x 144 tile (one round of 256 workgroups at M = 4000) instead of k_gemm_ks
-    int opt_zbig_m = 2048;   // rows above which the 128 x 144 producer takes over (zbig)
-    int opt_zfake = 0;   // DIAGNOSTIC: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
-    int opt_zmlp = 1;     // MLP-out projection (K = 4 D) in front of an in / mid block on the un-split producer too (0: split-K slabs + row kernel)
-    int opt_zskip = 1;    // skip_linear (K = 2 D) of the out-blocks on the un-split producer
+    // Single-key cross-attention shortcut (needs the LayerNorm-algebra path).  Softmax over ONE valid key is exactly 1, so for a batch element whose
+    // context mask has a single valid key -- every unconditional row of classifier-free guidance: the T5 encoding of "" is one EOS token
+    // (src/inference.py:44-50, attention.py:131-135) -- cross-attention returns v_key for every query and the cross-attention block adds the
+    // step-invariant vector  d = W_o v_key + b_o  (blocks.py:147-151).  ezdit_prepare_context finds those batch elements and computes d per block
+    // (zd); the attention-out projection adds it for their rows and emits the GEGLU GEMM's operand for them (k_gemm_ks DUAL / the ping-pong
+    // producer), and cross-attention + its out-projection run over the remaining batch elements only -- which must be one contiguous range
+    // [act_b0, act_b1), as in the CFG layout [cond.. | uncond..]; otherwise the general path runs.  Exact; the FLOP count of the bench line is NOT reduced for it.
+    int opt_xkey1 = 1;
+    bool xkey1 = false;          // set by ezdit_prepare_context: the bound context qualifies
+    int act_b0 = 0, act_b1 = 0;  // batch elements that still run cross-attention
+#ifdef EZ_DIAG
+    int opt_zfake = 0;   // DIAGNOSTIC build only: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
+#endif
     // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
+    // (odd head counts: fp32 projection + k_headnorm)
     int qkv_mode() const {
-        return !(opt_fuse_qkv && (dh == 72 || dh == 64)) ? 0 : ((opt_gemm_pp & 2) && M <= opt_pp_max_m && D % (2 * dh) == 0) ? 2 : (D % (4 * dh) == 0 ? 1 : 0);
+        return ((opt_gemm_pp & 2) && D % (2 * dh) == 0) ? 2 : (D % (4 * dh) == 0 ? 1 : 0);
     }
+    // the cross-attention kernel computes its own q projection (8-wave form: small grids, or forced by fuse_q2 = 2)
+    bool q2_fused() const { return opt_fuse_q2 && ((long)B * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0; }
     // the LayerNorm-algebra path can run for the bound shape under the current options (its tables are built by ezdit_prepare_timesteps only then)
     bool zfuse_usable() const {
         // the cross-attention q projection must be one of the two LayerNorm-algebra consumers: fused into k_attn (small grids) or the ping-pong GEMM with the q epilogue
-        const bool q_fused = opt_fuse_q2 && ((long)B * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0;
-        return opt_zfuse && opt_ztile >= 70 && (D + zwidth() - 1) / zwidth() <= Z_MAXP && M <= opt_pp_max_m && (opt_gemm_pp & 1) && geglu_tile < 0 && qkv_mode() == 2 &&
-               (q_fused || opt_q2_pp);
+        return opt_zfuse && (D + zwidth() - 1) / zwidth() <= Z_MAXP && (opt_gemm_pp & 1) && qkv_mode() == 2 && (q2_fused() || opt_q2_pp);
     }
-    int ztile() const { return (M > opt_zbig_m && opt_zbig && !per_row) ? 61 : opt_ztile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
-    int zwidth() const { const int t = ztile(); return t == 61 ? 144 : t == 75 ? 128 : t == 71 || t == 73 || t == 77 ? 64 : 96; }   // statistics part = the producer's tile width
-    int opt_pp_max_m = 1 << 30;   // largest M (token rows) the ping-pong kernels (and with them the LayerNorm algebra) are used at; default: no limit.  Round 3, four prompts (M = 4000): ping-pong GEGLU / QKV 12.27 ms per step, large-tile k_gemm2 GEGLU + lockstep QKV (pp_max_m = 2048) 12.95 ms
-    int opt_fuse_qkv = 1;                                                                 // head-norm / RoPE / V^T in the QKV GEMM epilogue (dh 72)
+    int ztile() const { return (M > kZBigM && !per_row) ? 61 : kZTile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
+    int zwidth() const { return ztile() == 61 ? 144 : 96; }   // statistics part = the producer's tile width
     int opt_wt = 2;   // write-through (sc1) output stores: 0 off, 1 on, 2 = on while B L <= 2048.  The end-of-kernel write-back then has nothing left to flush: -3.5 % step time
                       // for one prompt (4.19 -> 4.04 ms), +1.4 % for four (the step is throughput-bound there and the stores compete with the loads)
     int wt() const { return opt_wt == 2 ? (B * L <= 2048) : opt_wt; }
-    int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt)
+    int opt_fuse_q2 = 1;                                                                  // cross-attn q projection inside k_attn (one prompt); 2 = at every grid size
     int opt_attn_nkh = 0;                                                                 // attention key sub-blocks per tile (0 = auto)
-    // the two small fp32 GEMMs of a step at M <= 2048 on the K-split kernel (k_gemm_ks): patch embed (K = 320: 252 workgroups instead of 144) and the
-    // final Linear (N = 128: 42 workgroups of 48 x 64 instead of 16 of 128 x 64); -1 = tile_f32
-    int opt_tile_pe = 70, opt_tile_fin = 73;
     int opt_q2_pp = 1;                                                                    // cross-attn q projection at large grids: ping-pong GEMM with the per-head LayerNorm in its epilogue (0: fp32 GEMM + normalisation inside k_attn)
-    int opt_fuse_qnorm = 1;                                                               // cross-attn q LayerNorm inside k_attn
     int opt_attn_xcd = 1;                                                                 // attention: all query tiles of a (batch, head) on one XCD
-    int opt_gemm_debug = 0;   // k_gemm2 experiments: bit 0 = s_setprio(1) over the first MFMA cluster of a K tile, bit 1 = static priority for waves 4-7
     // XCD affinity of the residual path at M <= 1024 (placement only, results bit-identical): gemm_panel = shapes (1 D x D, 2 skip, 4 MLP-out)
     // whose split-K GEMM puts ALL workgroups of an M tile on XCD tm % 8; row_affine = the row kernel processes row panel p on XCD p % 8, so
     // a panel's slabs, residual stream and LayerNorm output stay in one XCD's L2 (the L2 keeps its lines across kernel boundaries: a
@@ -177,8 +171,6 @@ struct ezdit_handle {
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
     int opt_row_variant = 1;                                                              // row kernel: 0 = one workgroup per row, 1 = one wave per row
-    int opt_slab_bf16 = 1;                                                                // split-K slabs in bf16
-    int opt_tile_p18 = -1, opt_tile_p36 = -1, opt_tile_p72 = -1, opt_tile_qkv = 9;       // per-shape overrides (-1: use the above)
     int debug_stop = 0;  // > 0: ezdit_forward returns after this many launches (unit-test hook)
     int opt_stamp_launch = -1;   // in-situ cycle stamps: the launch with this index of a forward writes them (ezdit_debug_gemm_timestamps buffer; eager launches only)
     int opt_trace_launches = 0;  // print 'index name' of every launch of a forward to stderr
@@ -314,7 +306,7 @@ void build_params(ezdit_handle* h) {
     };
     for (const V& v : vecs)
         for (int b = 0; b < h->nblk; ++b) add_param(h, bn(b, v.name), {blk_prefix(h, b) + "." + v.key}, F, 1, v.n);
-    // per-STEP matrices of one block are contiguous (one prefetch range per block, see forward_impl)
+    // per-STEP matrices of one block are contiguous
     for (int b = 0; b < h->nblk; ++b) {
         const std::string p = blk_prefix(h, b);
         add_param(h, bn(b, "b1"), {p + ".mlp.net.0.proj.bias"}, F, 1, 2 * I, EZDIT_T_GEGLU8);
@@ -331,7 +323,6 @@ void build_params(ezdit_handle* h) {
         add_param(h, bn(b, "w1"), {p + ".mlp.net.0.proj.weight"}, Bf, 2 * I, D, EZDIT_T_GEGLU8);
         add_param(h, bn(b, "w2"), {p + ".mlp.net.2.weight"}, Bf, D, I);
     }
-    h->step_weights_end = h->param_bytes;
     // used once per CALL only (context K/V projection, AdaLN-SOLA low-rank factors)
     for (int b = 0; b < h->nblk; ++b) {
         const std::string p = blk_prefix(h, b);
@@ -415,10 +406,13 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         add("zt_qkv", (size_t)ns * nblk * 2 * N3 * 4);
         add("zt_geglu", (size_t)ns * nblk * 2 * I2 * 4);
         add("zt_q2", (size_t)nblk * 2 * D * 4);
+        add("zd", (size_t)nblk * B * D * 4);
         add("zA", (size_t)rup(4 * ns, 128) * h->ldD * 2);
         add("ztmp", (size_t)rup(4 * ns, 128) * nmax * 4);
+#ifdef EZ_DIAG
         add("zneutral", (size_t)Z_MAXP * Mp * 8);
         add("zzeros", (size_t)nmax * 4);
+#endif
     }
     return off;
 }
@@ -426,16 +420,13 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
 // ------------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------------
-struct FuseResid {   // out = resid + gate * (A . W^T + bias) in the GEMM epilogue
-    const float* resid; int ldr; const float* gate; long gate_stride; const int* cur_step; const int* row_slot; int rows_per_b;
-};
 struct Ctx {
     ezdit_handle* h;
     hipStream_t st;
-    const FuseResid* fuse = nullptr;
     const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
     bool panel = false;                 // one-shot: panel placement of a split-K GEMM (GemmArgs.xcd_panel)
     const float* zG = nullptr; const float* zC = nullptr; long zt_stride = 0;   // one-shot: LayerNorm algebra in the consumer's epilogue
+    int zrow0 = 0, zb0 = 0;   // one-shot: the launch covers a row sub-range that starts at row zrow0 = batch element zb0 (statistics table / per-row slot offsets)
     const int* cur = nullptr; const int* row_slot = nullptr;   // modulation slot of this forward (a ControlNet attached to the fused sampler reads the BACKBONE's step counter)
     // first launch failure of this call (hipGetLastError after EVERY launch: a rejected launch -- LDS limit, bad grid,
     // unsupported fused configuration -- must surface as an error code, never as stale numbers)
@@ -479,55 +470,42 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.splitk = splitk;
     g.epi = epi;
     g.tile = tile;
-    g.xcd_map = h->opt_xcd_map;
-    g.part_bf16 = (epi == EPI_PARTIAL) ? h->opt_slab_bf16 : 0;
+    g.xcd_map = 1;
+    g.part_bf16 = (epi == EPI_PARTIAL) ? 1 : 0;   // split-K slabs in bf16
     g.wt = h->wt();
-    g.debug = h->opt_gemm_debug;
     g.epi_lds = h->opt_epi_lds;
     g.rows_per_b = 1;
     if (c.hn) { g.hn = *c.hn; c.hn = nullptr; g.xcd_qkv = h->opt_qkv_affine && h->opt_attn_xcd; }
     if (c.panel) { g.xcd_panel = 1; c.panel = false; }
+#ifdef EZ_DIAG
     if (!c.zG && h->opt_zfake && (epi == EPI_QKV || epi == EPI_GEGLU) && (tile == 60 || tile == 61) && (h->D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
         g.zw = h->zwidth(); g.zstat_in = h->buf<float2>("zneutral"); g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D;
         g.zG = h->buf<float>("zzeros"); g.zC = bias ? bias : g.zG; g.zt_slot_stride = 0; g.zeps = 1e-5f; g.rows_per_b = h->L;
     }
+#endif
     if (c.zG) {
-        g.zw = h->zwidth(); g.zstat_in = h->p.zstat; g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
+        g.zw = h->zwidth(); g.zstat_in = h->p.zstat + c.zrow0; g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
         g.cur_step = c.cur ? c.cur : h->p.ints; g.row_slot = c.cur ? c.row_slot : (h->per_row ? h->p.ints + 16 : nullptr); g.rows_per_b = h->L;
+        if (g.row_slot) g.row_slot += c.zb0;
         c.zG = nullptr;
     }
-    if (c.fuse) {   // one-shot residual epilogue request (gemm_resid)
-        g.resid = c.fuse->resid; g.ldr = c.fuse->ldr; g.gate = c.fuse->gate; g.gate_slot_stride = c.fuse->gate_stride;
-        g.cur_step = c.fuse->cur_step; g.row_slot = c.fuse->row_slot; g.rows_per_b = c.fuse->rows_per_b;
-        c.fuse = nullptr;
-    }
+    c.zrow0 = 0; c.zb0 = 0;
     g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
     c.launched(epi == EPI_GEGLU ? "k_gemm (GEGLU)" : epi == EPI_QKV ? "k_gemm (QKV)" : epi == EPI_PARTIAL ? "k_gemm (split-K slabs)" : "k_gemm", launch_gemm(g, c.st));
 }
 
-// Tile / split-K heuristics: measured in situ on MI355X with tools/ab_sweep.py (one knob flipped on the live sampler) and
-// tools/bench_cold.py (cold weights, freshly written activations); DESIGN.md section 4 has the numbers.  Every choice can be
-// overridden through ezdit_set_option, which is what those harnesses do.
+// Tile / split-K choices: measured in situ on MI355X (DESIGN.md section 4 has the numbers); fixed since round 5 except tile_partial.
 int tile_for(const ezdit_handle* h, int M, bool partial) {
-    if (M <= 2048) return partial ? h->opt_tile_partial : h->opt_tile_f32;
-    return partial ? h->opt_tile_partial_big : h->opt_tile_f32_big;
+    if (M <= 2048) return partial ? h->opt_tile_partial : ezdit_handle::kTileF32;
+    return partial ? ezdit_handle::kTilePartialBig : ezdit_handle::kTileF32;
 }
 
 int pick_splitk(const ezdit_handle* h, int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 63) / 64);
     const int nk = K / 64;
-    if (M > 2048 && h->opt_split_big > 0) return h->opt_split_big < nk ? h->opt_split_big : nk;
-    if (M > 2048 && h->opt_tile_partial_big == 40) {   // 256 x 256 tiles: fill one round of CUs, at most 4 slabs
-        const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
-        int s = 256 / t256;
-        s = s < 1 ? 1 : s > 4 ? 4 : s;
-        return s < nk ? s : nk;
-    }
+    if (M > 2048) return ezdit_handle::kSplitBig < nk ? ezdit_handle::kSplitBig : nk;
     if (tiles >= 256) return 1;
-    int s = nk >= 72 ? h->opt_split72 : nk >= 36 ? h->opt_split36 : h->opt_split18;  // fewer slabs = less row-kernel traffic
-    if (s > nk) s = nk;
-    if (s < 1) s = 1;
-    return s;
+    return ezdit_handle::kSplitK < nk ? ezdit_handle::kSplitK : nk;  // fewer slabs = less row-kernel traffic
 }
 
 // residual GEMM: part = A . W^T as split-K slabs (reduced by the row kernel that follows)
@@ -535,15 +513,9 @@ int gemm_partial(Ctx& c, const bf16_t* A, int lda, const WRef& w, int M, int N) 
     ezdit_handle* h = c.h;
     const int K = w.ld;
     const int s = pick_splitk(h, M, N, K);
-    int tile = tile_for(h, M, true);
-    if (M <= 2048) {
-        const int nk = K / 64;
-        const int o = nk >= 72 ? h->opt_tile_p72 : nk >= 36 ? h->opt_tile_p36 : h->opt_tile_p18;
-        if (o >= 0) tile = o;
-    }
     const int shape_bit = K >= 4 * N ? 4 : K >= 2 * N ? 2 : 1;
     c.panel = (h->opt_gemm_panel & shape_bit) && M <= 1024;
-    gemm(c, A, lda, w, nullptr, h->p.part, h->D, M, N, EPI_PARTIAL, tile, s, (long)h->Mp * h->D);
+    gemm(c, A, lda, w, nullptr, h->p.part, h->D, M, N, EPI_PARTIAL, tile_for(h, M, true), s, (long)h->Mp * h->D);
     return s;
 }
 
@@ -583,6 +555,7 @@ void resolve_workspace(ezdit_handle* h) {
     p.ao = h->buf<bf16_t>("ao"); p.act = h->buf<bf16_t>("act"); p.part = h->buf<float>("part"); p.y = h->buf<float>("y");
     p.pred = h->buf<float>("pred"); p.kmask = h->buf<uint8_t>("kmask"); p.kc = h->buf<bf16_t>("kc"); p.vct = h->buf<bf16_t>("vct");
     p.mod = h->buf<float>("mod"); p.modf = h->buf<float>("modf");
+    p.zd = h->buf<float>("zd");
     p.zstat = h->buf<float2>("zstat"); p.zt_qkv = h->buf<float>("zt_qkv"); p.zt_geglu = h->buf<float>("zt_geglu"); p.zt_q2 = h->buf<float>("zt_q2");
     if (h->is_cn) { p.cembed = h->buf<float>("cembed"); p.cnres = h->buf<float>("cnres"); p.skipbf = h->buf<bf16_t>("skipbf"); }
 }
@@ -658,11 +631,9 @@ int ezdit_destroy(ezdit_handle* h) {
     }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
-    for (auto& e : h->pf_events) (void)hipEventDestroy(e);
     if (h->cn_fork) (void)hipEventDestroy(h->cn_fork);
     if (h->cn_join) (void)hipEventDestroy(h->cn_join);
     if (h->cn_stream) (void)hipStreamDestroy(h->cn_stream);
-    if (h->pf_stream) (void)hipStreamDestroy(h->pf_stream);
     delete h;
     return EZDIT_OK;
 }
@@ -708,14 +679,10 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
     h->ctx_ready = h->ts_ready = h->cond_ready = false;
     drop_graph(h);
     for (ezdit_handle* u : h->cn_users) drop_graph(u);   // a graph captured with this ControlNet attached points at its old buffers
-    if (!h->pf_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&h->pf_stream, hipStreamNonBlocking));
-        h->pf_events.resize(2 * (h->nblk + 2));
-        for (auto& e : h->pf_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     // zero everything once: all padding rows / columns / keys stay zero for the lifetime of the binding
     HIPCHK(hipMemsetAsync(ws, 0, need, st));
     launch_rope_table(h->buf<float>("rope_cos"), h->buf<float>("rope_sin"), h->cfg.max_len, h->dh, st);
+#ifdef EZ_DIAG
     {   // zfake diagnostic: statistics of a zero-mean, unit-variance row in parts of zwidth() columns
         const int zw = h->zwidth(), parts = (h->D + zw - 1) / zw;
         if (parts <= Z_MAXP) {
@@ -726,6 +693,7 @@ int ezdit_bind_workspace(ezdit_handle* h, void* ws, size_t bytes, int B, int L, 
             HIPCHK(hipStreamSynchronize(st));
         }
     }
+#endif
     return EZDIT_OK;
 }
 
@@ -738,6 +706,28 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
     uint8_t* km = h->buf<uint8_t>("kmask");
     if (mask) HIPCHK(hipMemcpyAsync(km, mask, Mc, hipMemcpyDeviceToDevice, c.st));
     else HIPCHK(hipMemsetAsync(km, 1, Mc, c.st));
+    // single-key batch elements (opt_xkey1): their cross-attention output is a constant.  The mask is read back once per call (B Lc bytes)
+    std::vector<int> key1(h->B, -1);   // the valid key of a single-key batch element, -1 otherwise
+    h->xkey1 = false; h->act_b0 = 0; h->act_b1 = h->B;
+    if (mask) {
+        std::vector<uint8_t> hm((size_t)Mc);
+        HIPCHK(hipMemcpyAsync(hm.data(), mask, Mc, hipMemcpyDeviceToHost, c.st));
+        HIPCHK(hipStreamSynchronize(c.st));
+        int first = -1, last = -1, n1 = 0;
+        for (int b = 0; b < h->B; ++b) {
+            int cnt = 0, at = -1;
+            for (int j = 0; j < h->Lc; ++j) if (hm[(size_t)b * h->Lc + j]) { ++cnt; at = j; }
+            if (cnt == 1) { key1[b] = at; ++n1; }
+            else { if (first < 0) first = b; last = b; }
+        }
+        bool contiguous = true;
+        for (int b = first; first >= 0 && b <= last; ++b) if (key1[b] >= 0) contiguous = false;
+        if (n1 > 0 && contiguous) {
+            h->xkey1 = true;
+            h->act_b0 = first < 0 ? 0 : first;
+            h->act_b1 = first < 0 ? 0 : last + 1;
+        }
+    }
     // context_embed: Linear -> SiLU -> Linear  (udit.py:94-97)
     launch_cast_bf16(ctx, h->Cctx, h->buf<bf16_t>("ctx_bf"), h->ldCtx, Mc, h->Cctx, 0, c.st);
     gemm(c, h->buf<bf16_t>("ctx_bf"), h->ldCtx, h->wref("ce.w1"), h->w<float>("ce.b1"), h->buf<float>("c1"), D, Mc, D, EPI_F32, tile_for(h, Mc, false));
@@ -766,6 +756,17 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
         hn.B = h->B; hn.H = h->H; hn.L = h->Lc; hn.Lp = h->Lcp; hn.dh = h->dh;
         launch_headnorm(hn, c.st);
         c.launched("k_headnorm");
+        if (h->xkey1) {
+            // d[b] = W_o v_key + b_o for the single-key batch elements: v_key is row (b Lc + key) of the fp32 value projection above, rounded to bf16
+            // as the attention kernel's V^T operand and output would be (P = 1 exactly), W_o the bf16 out-projection the step uses
+            const WRef wo2 = h->wref(bn(b, "wo2"));
+            for (int e = 0; e < h->B; ++e) {
+                if (key1[e] < 0) continue;
+                launch_gemv_bf16w(h->buf<float>("ckv") + ((size_t)e * h->Lc + key1[e]) * 2 * D + D, 1, wo2.W, wo2.ld, h->w<float>(bn(b, "bo2")),
+                                  h->p.zd + ((size_t)b * h->B + e) * D, D, D, c.st);
+                c.launched("k_gemv_bf16w");
+            }
+        }
     }
     if (c.bad()) return c.result();
     h->ctx_ready = true;
@@ -901,7 +902,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     launch_assemble(as, st);
     c.launched("k_assemble");
     STOPCHK();
-    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, (M <= 2048 && h->opt_tile_pe >= 0) ? h->opt_tile_pe : tile_for(h, M, false));
+    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, M <= 2048 ? ezdit_handle::kTilePE : tile_for(h, M, false));
 
     const float* part_src = part;
     bool u_is_z = false;   // `u` holds A' = bf16(h g) + partial statistics (LayerNorm algebra) instead of a finished LayerNorm
@@ -913,7 +914,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         memset(&r, 0, sizeof r);
         r.h_in = h_in; r.h_out = h_out;
         r.part = part_src; r.nsplit = nsplit; r.part_stride = (long)Mp * D; r.ld_part = D;
-        r.part_bf16 = (part_src == part) ? h->opt_slab_bf16 : 0;
+        r.part_bf16 = (part_src == part) ? 1 : 0;   // the split-K slabs are bf16
         r.cn_scale = cn_scale;
         r.bias = bias; r.gate = gate; r.gate_slot_stride = gate_stride; r.mode = mode;
         r.ln_g = lg; r.ln_c = lc; r.ln_slot_stride = ln_stride;
@@ -947,20 +948,31 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
     const int qkv_mode = h->qkv_mode();
     const bool zf = h->z_tables_ready && h->zfuse_usable();
+    // eb0 / enb: the launch covers the batch elements [eb0, eb0 + enb) only (enb < 0: all); dual_blk >= 0: DUAL form for block dual_blk (GemmArgs.zd)
     auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
-                       const float* zg, long zg_stride) {
+                       const float* zg, long zg_stride, int eb0 = 0, int enb = -1, int dual_blk = -1) {
+        const long r0 = (long)eb0 * h->L;
+        const int Ms = enb < 0 ? M : enb * h->L;
         GemmArgs g;
         memset(&g, 0, sizeof g);
-        g.A = A; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
-        g.out = h_out; g.ldo = D; g.M = M; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->ztile();
-        g.xcd_map = h->opt_xcd_map; g.wt = h->wt(); g.debug = h->opt_gemm_debug;
-        g.resid = h_in; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
-        g.cur_step = cur; g.row_slot = row_slot; g.rows_per_b = h->L;
-        g.zu = u; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat; g.zs_stride = h->Mp;
+        g.A = A + r0 * lda; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
+        g.out = h_out + r0 * D; g.ldo = D; g.M = Ms; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->ztile();
+        g.xcd_map = 1; g.wt = h->wt();
+        g.resid = h_in ? h_in + r0 * D : nullptr; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
+        g.cur_step = cur; g.row_slot = row_slot ? row_slot + eb0 : nullptr; g.rows_per_b = h->L;
+        g.zu = u + r0 * h->ldD; g.ld_zu = h->ldD; g.zg = zg; g.zg_slot_stride = zg_stride; g.zstat_out = p.zstat + r0; g.zs_stride = h->Mp;
+        if (dual_blk >= 0) {
+            g.zd = p.zd + (size_t)dual_blk * h->B * D; g.zd_stride = D;
+            g.zg2 = modv(dual_blk, 3); g.zg2_slot_stride = mod_slot;
+            g.act_row0 = h->act_b0 * h->L; g.act_row1 = h->act_b1 * h->L;
+        }
         g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
         c.launched("k_gemm (un-split residual)", launch_gemm(g, st));
         u_is_z = true;
     };
+    // single-key shortcut (opt_xkey1): cross-attention + its out-projection cover the batch elements [xb0, xb0 + xnb) only
+    const bool x1 = zf && h->opt_xkey1 && h->xkey1 && h->ztile() == ezdit_handle::kZTile;
+    const int xb0 = x1 ? h->act_b0 : 0, xnb = x1 ? h->act_b1 - h->act_b0 : h->B;
 
     // LN1 of block 0 on the patch embedding (ControlNet: x = patch_embed(x) + controlnet_pre(condition) first, :263-266)
     STOPCHK();
@@ -973,33 +985,13 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     }
     const float* hcur = hA;
 
-    // weight prefetch: while block b computes, a side stream pulls block b+1's per-step matrices into the Infinity Cache
-    const bool use_pf = h->prefetch && h->pf_stream && h->debug_stop == 0;
-    int n_fork = 0;
-    auto prefetch_block = [&](int blk) {
-        if (!use_pf || blk >= nblk) return;
-        const size_t beg = (size_t)h->params[h->pidx.at(bn(blk, "b1"))].offset;
-        const size_t end = blk + 1 < nblk ? (size_t)h->params[h->pidx.at(bn(blk + 1, "b1"))].offset : h->step_weights_end;
-        hipEvent_t ev = h->pf_events[n_fork++];
-        (void)hipEventRecord(ev, st);
-        (void)hipStreamWaitEvent(h->pf_stream, ev, 0);
-        launch_prefetch(h->wblob + beg, end - beg, reinterpret_cast<unsigned*>(h->buf<unsigned>("sink")), h->pf_stream);
-    };
-    auto join_prefetch = [&]() {   // mandatory inside a capture (an unjoined side stream invalidates it); cheap otherwise
-        if (!use_pf || n_fork == 0) return;
-        hipEvent_t ev = h->pf_events[n_fork++];
-        (void)hipEventRecord(ev, h->pf_stream);
-        (void)hipStreamWaitEvent(st, ev, 0);
-    };
-    prefetch_block(0);
     for (int b = 0; b < nblk; ++b) {
         const BlkW& w = h->blk[b];
         const bool is_in = b < nhalf, is_out = b > nhalf;
-        prefetch_block(b + 1);
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            if (zf && h->opt_zskip) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot);
+            if (zf) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot);
             else resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
@@ -1018,10 +1010,9 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
             c.hn = &hn;
             if (u_is_z) { c.zG = p.zt_qkv + (long)b * 2 * 3 * D; c.zC = c.zG + 3 * D; c.zt_stride = (long)nblk * 2 * 3 * D; }
-            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, qkv_mode == 2 ? 61 : h->opt_qkv_waves9);
+            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, qkv_mode == 2 ? 61 : 1);   // lockstep form: 1 x 9 waves (head_dim 72)
         } else {
-            gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32,
-                 (M <= 2048 && h->opt_tile_qkv >= 0) ? h->opt_tile_qkv : tile_for(h, M, false));
+            gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32, tile_for(h, M, false));
             STOPCHK();
             launch_headnorm(hn, st);
             c.launched("k_headnorm");
@@ -1037,15 +1028,8 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         c.launched("k_attn (self)", launch_attention(at, st));
         STOPCHK();
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
-        const bool fuse_res = h->opt_fuse_resid && M <= 2048;   // non-split GEMM with the gated residual in its epilogue
-        if (fuse_res) {
-            const FuseResid fr{hcur, D, modv(b, 2), mod_slot, cur, row_slot, h->L};
-            c.fuse = &fr;
-            gemm(c, at.out, h->ldD, w.wo, w.bo, hA, D, M, D, EPI_F32, tile_for(h, M, false));
-            STOPCHK();
-            row(0, hA, nullptr, 0, nullptr, nullptr, 0, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
-        } else if (zf) {
-            resid_z(at.out, h->ldD, w.wo, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, 0);
+        if (zf) {
+            resid_z(at.out, h->ldD, w.wo, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, 0, 0, -1, x1 ? b : -1);
         } else {
             resid(at.out, h->ldD, w.wo, 1, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         }
@@ -1053,69 +1037,67 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // ---- cross attention (blocks.py:147-151) ----
         STOPCHK();
         // one prompt: the cross-attention kernel also computes its own q = LN_head(u . Wq^T) (8-wave form, Lcp % 128 == 0)
-        const bool fuse_q2 = h->opt_fuse_q2 && ((long)h->B * h->H * ((h->L + 63) / 64) <= 512 || h->opt_fuse_q2 == 2) && h->Lcp % 128 == 0;
-        memset(&hn, 0, sizeof hn);
-        hn.x = p.qkv; hn.ldx = D;
-        hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
-        hn.qn_w = w.cqnw; hn.qn_b = w.cqnb;
-        hn.q = p.q;
-        hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
-        at.xu = nullptr; at.nkh = h->opt_attn_nkh;
-        if (fuse_q2) {
-            at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
-            at.xw_rows = w.wq2.rows; at.xK = at.ldw;
-            at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
-            if (!u_is_z && h->opt_zfake && (D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
-                at.zw = h->zwidth(); at.zstat_in = h->buf<float2>("zneutral"); at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
-                at.zG = h->buf<float>("zzeros"); at.zC = at.zG;
-            }
-            if (u_is_z) {
-                at.zw = h->zwidth(); at.zstat_in = p.zstat; at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
-                at.zG = p.zt_q2 + (long)b * 2 * D; at.zC = at.zG + D;
-            }
-        } else if (qkv_mode == 2 && h->opt_q2_pp) {
-            // batched prompts: the q projection on the ping-pong kernel with the fused-QKV epilogue restricted to its q part (N = D, no RoPE):
-            // per-head LayerNorm and the bf16 attention layout straight out of the GEMM -- no fp32 q round trip, no 128 x 64 tile at M = 4000
-            // (k_gemm<128,64> + normalisation inside k_attn: 30 us; this: one round of 256 workgroups).  LayerNorm-algebra capable (zt_q2 is static)
-            c.hn = &hn;
-            if (u_is_z) { c.zG = p.zt_q2 + (long)b * 2 * D; c.zC = c.zG + D; c.zt_stride = 0; }
-            gemm(c, u, h->ldD, w.wq2, nullptr, nullptr, 0, M, D, EPI_QKV, 61);
-        } else {
-            gemm(c, u, h->ldD, w.wq2, nullptr, p.qkv, D, M, D, EPI_F32, tile_for(h, M, false));
-            if (h->opt_fuse_qnorm) {   // the cross-attention kernel normalises q itself (one launch and one q round trip less)
-                at.q_raw = hn.x; at.ld_qraw = D; at.qn_w = hn.qn_w; at.qn_b = hn.qn_b;
+        // (x1: over the batch elements [xb0, xb0 + xnb) only -- the others are single-key rows served by the attention-out projection above)
+        const bool fuse_q2 = h->q2_fused();
+        const long xr0 = (long)xb0 * h->L;          // first row of the sub-range
+        const int xM = xnb * h->L;
+        if (xnb > 0) {
+            memset(&hn, 0, sizeof hn);
+            hn.x = p.qkv; hn.ldx = D;
+            hn.q_col = 0; hn.k_col = -1; hn.v_col = -1;
+            hn.qn_w = w.cqnw; hn.qn_b = w.cqnb;
+            hn.q = p.q + (size_t)xb0 * h->H * h->Lp * h->DQK;
+            hn.B = xnb; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
+            at.xu = nullptr; at.nkh = h->opt_attn_nkh;
+            at.B = xnb; at.b0 = xb0;
+            if (fuse_q2) {
+                at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
+                at.xw_rows = w.wq2.rows; at.xK = at.ldw;
+                at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
+#ifdef EZ_DIAG
+                if (!u_is_z && h->opt_zfake && (D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
+                    at.zw = h->zwidth(); at.zstat_in = h->buf<float2>("zneutral"); at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
+                    at.zG = h->buf<float>("zzeros"); at.zC = at.zG;
+                }
+#endif
+                if (u_is_z) {
+                    at.zw = h->zwidth(); at.zstat_in = p.zstat; at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
+                    at.zG = p.zt_q2 + (long)b * 2 * D; at.zC = at.zG + D;
+                }
+            } else if (qkv_mode == 2 && h->opt_q2_pp) {
+                // batched prompts: the q projection on the ping-pong kernel with the fused-QKV epilogue restricted to its q part (N = D, no RoPE):
+                // per-head LayerNorm and the bf16 attention layout straight out of the GEMM -- no fp32 q round trip, no 128 x 64 tile at M = 4000
+                // (k_gemm<128,64> + normalisation inside k_attn: 30 us; this: one round of 256 workgroups).  LayerNorm-algebra capable (zt_q2 is static)
+                c.hn = &hn;
+                if (u_is_z) { c.zG = p.zt_q2 + (long)b * 2 * D; c.zC = c.zG + D; c.zt_stride = 0; c.zrow0 = (int)xr0; c.zb0 = xb0; }
+                gemm(c, u + xr0 * h->ldD, h->ldD, w.wq2, nullptr, nullptr, 0, xM, D, EPI_QKV, 61);
+                at.q = p.q;   // (launch_attention advances it by b0)
             } else {
-                STOPCHK();
-                launch_headnorm(hn, st);
-                c.launched("k_headnorm");
+                gemm(c, u + xr0 * h->ldD, h->ldD, w.wq2, nullptr, p.qkv + xr0 * D, D, xM, D, EPI_F32, tile_for(h, xM, false));
+                at.q_raw = p.qkv; at.ld_qraw = D; at.qn_w = hn.qn_w; at.qn_b = hn.qn_b;   // the cross-attention kernel normalises q itself
             }
-        }
-        at.q = hn.q;
-        at.k = p.kc + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
-        at.vt = p.vct + (size_t)b * h->B * h->H * h->DV * h->Lcp;
-        at.kmask = p.kmask;
-        at.Lk = h->Lc; at.Lkp = h->Lcp;
-        STOPCHK();
-        at.ts = c.stamps(); at.ts_cap = g_gemm_ts_cap;
-        c.launched("k_attn (cross)", launch_attention(at, st));
-        STOPCHK();
-        if (fuse_res) {
-            const FuseResid fr{hA, D, nullptr, 0, nullptr, nullptr, h->L};
-            c.fuse = &fr;
-            gemm(c, at.out, h->ldD, w.wo2, w.bo2, hA, D, M, D, EPI_F32, tile_for(h, M, false));
+            at.q = p.q;
+            at.k = p.kc + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
+            at.vt = p.vct + (size_t)b * h->B * h->H * h->DV * h->Lcp;
+            at.kmask = p.kmask;
+            at.Lk = h->Lc; at.Lkp = h->Lcp;
             STOPCHK();
-            row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
-        } else if (zf) {
-            at.zstat_in = nullptr;
-            resid_z(at.out, h->ldD, w.wo2, hA, hA, w.bo2, nullptr, 0, modv(b, 3), mod_slot);
-        } else {
-            resid(at.out, h->ldD, w.wo2, 1, hA, hA, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+            at.ts = c.stamps(); at.ts_cap = g_gemm_ts_cap;
+            c.launched("k_attn (cross)", launch_attention(at, st));
+            STOPCHK();
+            if (zf) {
+                at.zstat_in = nullptr;
+                resid_z(at.out, h->ldD, w.wo2, hA, hA, w.bo2, nullptr, 0, modv(b, 3), mod_slot, xb0, x1 ? xnb : -1);
+            } else {
+                resid(at.out, h->ldD, w.wo2, 1, hA, hA, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
+            }
+            at.B = h->B; at.b0 = 0;
         }
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         if (u_is_z) { c.zG = p.zt_geglu + (long)b * 2 * 2 * h->I; c.zC = c.zG + 2 * h->I; c.zt_stride = (long)nblk * 2 * 2 * h->I; }
         gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU,
-             h->geglu_tile >= 0 ? h->geglu_tile : ((M <= h->opt_pp_max_m && (h->opt_gemm_pp & 1)) ? 60 : M <= 2048 ? 13 : h->opt_geglu_big));
+             (h->opt_gemm_pp & 1) ? 60 : 13);   // 128 x 288: ping-pong kernel / round-1 lockstep kernel
         STOPCHK();
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
         const float* b2 = w.b2;
@@ -1132,7 +1114,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
-            if (zf && h->opt_zmlp) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot);
+            if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot);
             else resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
@@ -1144,12 +1126,11 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             c.launched("k_cast_bf16");
             gemm(c, p.skipbf, h->ldD, h->blk[i].zw, h->blk[i].zb, p.cnres + (size_t)i * Mp * D, D, M, D, EPI_F32, tile_for(h, M, false));
         }
-        join_prefetch();
         return c.result();
     }
     // A18 FinalBlock: u = LN(x)*(1+scale)+shift -> Linear(D->C) -> transpose -> Conv1d(C,C,3,pad 1)
     STOPCHK();
-    gemm(c, u, h->ldD, h->w_fin, h->b_fin, p.y, h->C, M, h->C, EPI_F32, (M <= 2048 && h->opt_tile_fin >= 0) ? h->opt_tile_fin : tile_for(h, M, false));
+    gemm(c, u, h->ldD, h->w_fin, h->b_fin, p.y, h->C, M, h->C, EPI_F32, M <= 2048 ? ezdit_handle::kTileFin : tile_for(h, M, false));
     FinalConvArgs fc;
     fc.y = p.y; fc.ldy = h->C;
     fc.w = h->w_fin_cw; fc.b = h->w_fin_cb;
@@ -1157,7 +1138,6 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     STOPCHK();
     launch_final_conv(fc, st);
     c.launched("k_final_conv");
-    join_prefetch();
     return c.result();
 }
 
@@ -1395,9 +1375,9 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
     g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias; g.out = out; g.ldo = ldo;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk < 1 ? 1 : splitk;
     g.slab_stride = (long)rup(M, 128) * ldo;
-    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = h ? h->opt_xcd_map : 1; g.part_bf16 = 0; g.wt = h ? h->wt() : 0; memset(&g.hn, 0, sizeof g.hn);
+    g.conv_cpb = 0; g.conv_tap_bytes = 0; g.resid = nullptr; g.ldr = 0; g.xcd_map = 1; g.part_bf16 = 0; g.wt = h ? h->wt() : 0; memset(&g.hn, 0, sizeof g.hn);
     g.gate = nullptr; g.gate_slot_stride = 0; g.cur_step = nullptr; g.row_slot = nullptr; g.rows_per_b = 1;
-    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: bits 0-1 k_gemm2 experiment bits (GemmArgs.debug), bit 3 LDS-staged bf16 epilogue, bit 4 bf16 slabs, bits 8.. k_gemm_pp ablation variant
+    g.debug = variant / 1000; variant %= 1000;   // 1000 * bits + v: bit 3 LDS-staged bf16 epilogue, bit 4 bf16 slabs, bit 6 LayerNorm-algebra consumer on neutral tables, bits 8.. k_gemm_pp ablation variant (EZ_ABLATE builds)
     if (g.debug & 8) g.epi_lds = 1;
     if (g.debug & 16) g.part_bf16 = 1;   // 16000 + v: bf16 split-K slabs
     g.ts = g_gemm_ts; g.ts_cap = g_gemm_ts_cap;
@@ -1410,7 +1390,9 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
         if (rows > cap_rows) { if (zs) (void)hipFree(zs); HIPCHK(hipMalloc(&zs, rows * 12 * sizeof(float2))); cap_rows = rows;
             std::vector<float2> hst(rows * 12, make_float2(0.f, 96.f)); HIPCHK(hipMemcpy(zs, hst.data(), hst.size() * sizeof(float2), hipMemcpyHostToDevice)); }
         if (nn > cap_n) { if (zg0) (void)hipFree(zg0); if (zc) (void)hipFree(zc); HIPCHK(hipMalloc(&zg0, nn * 4)); HIPCHK(hipMalloc(&zc, nn * 4)); cap_n = nn; HIPCHK(hipMemset(zg0, 0, nn * 4)); HIPCHK(hipMemset(zc, 0, nn * 4)); }
-        g.zstat_in = zs; g.zs_stride = (long)cap_rows; g.zparts = 12; g.zD = 1152; g.zw = 96; g.zG = zg0; g.zC = bias ? bias : zc;   // C' = the bias itself: no copy in the timed path g.zt_slot_stride = 0; g.zeps = 1e-5f;
+        // C' = the bias itself: no copy in the timed path
+        g.zstat_in = zs; g.zs_stride = (long)cap_rows; g.zparts = 12; g.zD = 1152; g.zw = 96; g.zG = zg0; g.zC = bias ? bias : zc;
+        g.zt_slot_stride = 0; g.zeps = 1e-5f;
         g.debug &= ~64;
     }
     if (g.epi > EPI_GEGLU || g.tile > 127) return fail(EZDIT_E_INVALID, "bad gemm variant %d", variant);
@@ -1423,7 +1405,7 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* A, int lda, const 
 }
 
 // EPI_RESID (un-split residual projection + partial LayerNorm statistics + next operand), stand-alone:
-// h_out = h_in + gate * (A . W^T + bias); zu = bf16(h_out * zg); zstat[row][N / tile-width chunks] = (sum, M2 about the chunk mean)
+// h_out = h_in + gate * (A . W^T + bias); zu = bf16(h_out * zg); zstat[N / tile-width chunks][row] = (sum, sum of squares) over the chunk's columns (part-major)
 int ezdit_test_resid(int tile, const void* A, int lda, const void* W, int ldw, const float* bias, const float* h_in, const float* gate, const float* zg,
                      float* h_out, void* zu, int ld_zu, void* zstat, int M, int N, int K, ezdit_stream stream) {
     if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
@@ -1467,14 +1449,6 @@ int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** ptr, size_t* by
     return EZDIT_OK;
 }
 
-int ezdit_device_status(ezdit_handle* h, ezdit_stream stream) {
-    // No kernel of this library waits on another workgroup inside a launch any more (the in-launch split-K hand-off of round 2 was
-    // removed), so there is no device-side failure left to report: launch failures surface through the return codes of the calls.
-    (void)stream;
-    if (!h || !h->ws) return fail(EZDIT_E_STATE, "bind workspace first");
-    return EZDIT_OK;
-}
-
 int ezdit_last_launch_count(const ezdit_handle* h) { return h ? h->launches : 0; }
 int ezdit_debug_stop_after(ezdit_handle* h, int n) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
@@ -1483,53 +1457,27 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n) {
 }
 int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     if (!h || !name) return fail(EZDIT_E_INVALID, "null argument");
-    if (!strcmp(name, "prefetch")) h->prefetch = value;
-    else if (!strcmp(name, "geglu_tile")) h->geglu_tile = value;
-    else if (!strcmp(name, "split18")) h->opt_split18 = value;
-    else if (!strcmp(name, "split36")) h->opt_split36 = value;
-    else if (!strcmp(name, "split72")) h->opt_split72 = value;
+    if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
+    else if (!strcmp(name, "xkey1")) h->opt_xkey1 = value;
+    else if (!strcmp(name, "wt")) h->opt_wt = value;
+    else if (!strcmp(name, "gemm_pp")) h->opt_gemm_pp = value;
     else if (!strcmp(name, "tile_partial")) h->opt_tile_partial = value;
-    else if (!strcmp(name, "tile_f32")) h->opt_tile_f32 = value;
-    else if (!strcmp(name, "xcd_map")) h->opt_xcd_map = value;
-    else if (!strcmp(name, "slab_bf16")) h->opt_slab_bf16 = value;
-    else if (!strcmp(name, "fuse_qnorm")) h->opt_fuse_qnorm = value;
-    else if (!strcmp(name, "q2_pp")) h->opt_q2_pp = value;
-    else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
-    else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "attn_xcd")) h->opt_attn_xcd = value;
     else if (!strcmp(name, "row_variant")) h->opt_row_variant = value;
-    else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
-    else if (!strcmp(name, "attn_xk2")) h->opt_attn_xk2 = value;
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
-    else if (!strcmp(name, "qkv_affine")) h->opt_qkv_affine = value;
     else if (!strcmp(name, "epi_lds")) h->opt_epi_lds = value;
-    else if (!strcmp(name, "gemm_debug")) h->opt_gemm_debug = value;
-    else if (!strcmp(name, "wt")) h->opt_wt = value;
-    else if (!strcmp(name, "fuse_qkv")) h->opt_fuse_qkv = value;
-    else if (!strcmp(name, "gemm_pp")) h->opt_gemm_pp = value;
-    else if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
-    else if (!strcmp(name, "ztile")) h->opt_ztile = value;
-    else if (!strcmp(name, "zmlp")) h->opt_zmlp = value;
-    else if (!strcmp(name, "zfake")) h->opt_zfake = value;
-    else if (!strcmp(name, "zbig")) h->opt_zbig = value;
-    else if (!strcmp(name, "zbig_m")) h->opt_zbig_m = value;
-    else if (!strcmp(name, "zskip")) h->opt_zskip = value;
-    else if (!strcmp(name, "pp_max_m")) h->opt_pp_max_m = value;
-    else if (!strcmp(name, "qkv_waves9")) h->opt_qkv_waves9 = value;
-    else if (!strcmp(name, "fuse_resid")) h->opt_fuse_resid = value;
-    else if (!strcmp(name, "tile_partial_big")) h->opt_tile_partial_big = value;
-    else if (!strcmp(name, "tile_f32_big")) h->opt_tile_f32_big = value;
-    else if (!strcmp(name, "geglu_big")) h->opt_geglu_big = value;
-    else if (!strcmp(name, "split_big")) h->opt_split_big = value;
-    else if (!strcmp(name, "tile_p18")) h->opt_tile_p18 = value;
-    else if (!strcmp(name, "tile_p36")) h->opt_tile_p36 = value;
-    else if (!strcmp(name, "tile_p72")) h->opt_tile_p72 = value;
-    else if (!strcmp(name, "tile_qkv")) h->opt_tile_qkv = value;
-    else if (!strcmp(name, "tile_pe")) h->opt_tile_pe = value;
-    else if (!strcmp(name, "tile_fin")) h->opt_tile_fin = value;
+    else if (!strcmp(name, "qkv_affine")) h->opt_qkv_affine = value;
+    else if (!strcmp(name, "attn_xk2")) h->opt_attn_xk2 = value;
+    else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
+    else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
+    else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
+    else if (!strcmp(name, "q2_pp")) h->opt_q2_pp = value;
     else if (!strcmp(name, "stamp_launch")) h->opt_stamp_launch = value;
     else if (!strcmp(name, "trace_launches")) h->opt_trace_launches = value;
+#ifdef EZ_DIAG
+    else if (!strcmp(name, "zfake")) h->opt_zfake = value;
+#endif
     else return fail(EZDIT_E_INVALID, "unknown option %s", name);
     drop_graph(h);
     for (ezdit_handle* u : h->cn_users) drop_graph(u);   // a backbone's captured step embeds the attached ControlNet's kernels and arguments

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             constexpr int FN = DN / 32;
             const int mh = wave & 1, kq = wave >> 1;
             const int rowb = b * a.Lq;
-            // LayerNorm algebra: the partial statistics of the 64 operand rows of this tile (wave 0: one row per lane, part-major table: every
-            // load is one contiguous 512-byte run) and G' | C' of this head's columns (one float4 per thread of wave 1) are requested right behind
+            // LayerNorm algebra: the partial statistics of the 64 operand rows of this tile (the first 256 threads: FOUR threads per row, thread pg takes the
+            // parts pg, pg + 4, pg + 8 of the part-major table: a wave's load covers 16 rows x 4 parts = four contiguous 128-byte runs) and G' | C' of this head's columns (one float4 per thread of wave 1) are requested right behind
             // the first two K tiles, land under the projection's K loop, and are merged / parked in LDS behind the loop's last barrier; used in phase 1b
             float2* zrow_l = reinterpret_cast<float2*>(smem + SMEM);            // [64] (mu, r)
             float* zgc_l = reinterpret_cast<float*>(smem + SMEM + 64 * 8);      // [2][DQK] G' | C'
@@ -568,6 +568,19 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 
 int launch_attention(const AttnArgs& a0, hipStream_t st) {
     AttnArgs a = a0;
+    if (a.b0 > 0) {   // batch sub-range [b0, b0 + B): advance every per-batch-element pointer; the kernel sees batch elements 0 .. B - 1
+        const int DQK = a.dh == 64 ? 64 : 80, DV = a.dh == 64 ? 64 : 96;
+        const long b0 = a.b0;
+        if (a.q) a.q += b0 * a.H * a.Lqp * DQK;
+        if (a.k) a.k += b0 * a.H * a.Lkp * DQK;
+        if (a.vt) a.vt += b0 * a.H * DV * (long)a.Lkp;
+        if (a.kmask) a.kmask += b0 * a.Lk;
+        if (a.out) a.out += b0 * a.Lq * a.ldo;
+        if (a.q_raw) a.q_raw += b0 * a.Lq * a.ld_qraw;
+        if (a.xu) a.xu += b0 * a.Lq * a.ldu;
+        if (a.zstat_in) a.zstat_in += b0 * a.Lq;
+        a.b0 = 0;
+    }
     a.nq = (a.Lq + 63) / 64;
     a.ppx = (a.B * a.H + 7) / 8;
     const long nwg = (long)a.nq * a.H * a.B;

@@ -191,7 +191,7 @@ struct GemmArgs {
     int splitk;                 // >= 1 (EPI_PARTIAL only)
     int epi;
     int tile;                   // tile / pipeline configuration, see gemm.hip
-    int debug;                  // k_gemm2 experiment bits: 1 = s_setprio(1) over the first MFMA cluster of a K tile, 2 = static priority for waves 4-7
+    int debug;                  // bits 8..: timing-ablation variant of the ping-pong K loop (EZ_ABLATE builds, gemm_pp.h); 0 in the product
     // convolution-as-GEMM addressing (VAE decoder): K tile t reads A at byte offset (t / conv_cpb) * conv_tap_bytes +
     // (t % conv_cpb) * 128, i.e. tap t/conv_cpb is the SAME activation rows shifted by a fixed number of rows.
     // conv_cpb = 0: plain GEMM (offset t * 128).
@@ -220,6 +220,11 @@ struct GemmArgs {
     const float* zg; long zg_slot_stride;       // LayerNorm gain of the consumer (per slot when the stride is non-zero)
     float2* zstat_out;                          // [N tiles][zs_stride]: (sum, sum of squares) of h_new over the columns of each N tile, PART-MAJOR
     long zs_stride;                             // rows (elements) between the parts of zstat_out / zstat_in
+    // producer, DUAL form (null zd = off; gate and resid required): cross-attention over ONE valid key is the constant  W_o v_key + b_o  for every query
+    // (softmax over one key is 1; the uncond rows of classifier-free guidance: src/inference.py:44-50, attention.py:131-135), so for the rows of such
+    // batch elements -- the rows OUTSIDE [act_row0, act_row1) -- the attention-out projection adds that vector (zd [B][zd_stride], per batch element)
+    // on top of its own gated residual and emits the operand of the GEGLU GEMM (gain zg2) instead of the cross-attention q projection's
+    const float* zd; long zd_stride; const float* zg2; long zg2_slot_stride; int act_row0, act_row1;
     // consumer (EPI_QKV, EPI_GEGLU; null zstat_in = plain GEMM):
     const float2* zstat_in; int zparts; int zD; int zw; // [zparts][zs_stride] partial statistics of the operand's rows: zparts = ceil(zD / zw) <= Z_MAXP parts of zw columns (the last one ragged; zw = the producer's tile width)
     const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]
@@ -256,6 +261,10 @@ struct AttnArgs {
     const float2* zstat_in; long zs_stride; int zparts; int zD; int zw; const float* zG; const float* zC; float zeps;   // zstat_in [zparts][zs_stride], part-major
     unsigned long long* ts;     // test hook: [workgroup][8] shader-clock stamps (start, operands staged, tile loop end, merge end, end), nullable
     long ts_cap;                // workgroups `ts` has room for: the launcher drops `ts` for a larger grid
+    // batch sub-range: the launch covers the batch elements [b0, b0 + B) of the buffers above (all pointers are given for batch element 0 and
+    // advanced by the launcher).  Cross-attention of a CFG step runs over the conditional rows only: an uncond row's mask has ONE valid key, its
+    // output is a constant that the attention-out projection adds (GemmArgs.zd)
+    int b0;
 };
 int launch_attention(const AttnArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported
 
@@ -316,7 +325,6 @@ struct CfgDdimArgs {
     int* step_inc; unsigned* done;
 };
 void launch_cfg_ddim(const CfgDdimArgs& a, float* partial /* [P][64][4] scratch */, hipStream_t st);
-void launch_prefetch(const void* p, size_t bytes, unsigned* sink, hipStream_t st);  // warm the Infinity Cache
 void launch_set_int(int* p, int v, int add, hipStream_t st);  // *p = add ? *p + v : v
 struct Conv1dArgs {  // out[b][co][lo] = act(bias[co] + sum_{ci,k} w[co][ci][k] * x[b][ci][lo*stride + k - pad]); fp32
     const float* x; const float* w; const float* b; float* out;
@@ -326,6 +334,8 @@ struct Conv1dArgs {  // out[b][co][lo] = act(bias[co] + sum_{ci,k} w[co][ci][k] 
 };
 void launch_conv1d(const Conv1dArgs& a, hipStream_t st);
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu
+// y[n] = bias[n] + sum_k x[k] W[n][k]   (x fp32, rounded to bf16 first when x_bf16 -- what an activation that went through a bf16 buffer would be; W bf16 [N][ldw]; once per call)
+void launch_gemv_bf16w(const float* x, int x_bf16, const bf16_t* W, int ldw, const float* bias, float* y, int N, int K, hipStream_t st);
 // LayerNorm algebra tables (rowops.hip): (g, c) [n_slots][D] (stride slot_stride) -> bf16 rows (g hi, g lo, c hi, c lo) per slot, zero padded to ldo;
 // and back: zG[s][n] = tmp[4s][n] + tmp[4s+1][n], zC[s][n] = tmp[4s+2][n] + tmp[4s+3][n] (+ bias[n])
 void launch_z_hilo(const float* g, const float* c, long slot_stride, bf16_t* out, int ldo, int n_slots, int D, hipStream_t st);

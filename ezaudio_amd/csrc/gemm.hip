@@ -500,188 +500,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Large-tile kernel for many-row problems (batched prompts, M >= ~2000): 256 x 256 (or 192 x 256) output tile, 8 waves as 2 (M) x 4 (N),
-// wave tile 128 x 64 (96 x 64), BK = 64, TWO LDS stages with EARLY RELEASE.
-//
-// Why a second main loop: at 128 x 128 a K tile moves 32 KB for 2.1 MFLOP (64 FLOP per ingested byte) and the measured
-// L2 -> LDS ingest of a CU (~65 GB/s with 8 waves issuing) caps the loop at ~43 % of the CU's MFMA rate; 256 x 256 doubles
-// the reuse (128 FLOP / B).  A 2-deep ring of whole 64 KB stages, however, exposes the DMA latency of every tile (round 1's
-// tile 11).  Here every wave pulls ALL fragments of K tile t out of LDS during the first half of the tile's MFMAs
-// (k-steps 0, 1 compute while k-steps 2, 3 are read), so stage t & 1 is dead after half a tile: one barrier, and the
-// LDS-DMA of tile t + 2 is issued into it while k-steps 2, 3 still compute.  Tile t + 2's loads therefore fly for one and a
-// half K tiles (the prefetch distance of a 3-deep ring) out of 128 KB of LDS, and the wait at the top of tile t + 1 is a
-// COUNTED vmcnt that leaves tile t + 2's loads in flight across both barriers.
-// Order of one K tile (per wave, k-steps 0, 1 already in registers):
-//     mfma ks0 (half) | read ks2, ks3 | mfma ks0 (rest), ks1 | lgkmcnt(0) | barrier (stage free) | DMA A(t+2) | mfma ks2 | DMA W(t+2) |
-//     vmcnt(tile t+2 may fly) | barrier (tile t+1 visible) | read ks0, ks1 of tile t+1 | mfma ks3
-template <int BM, int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm2(GemmArgs a) {
-    constexpr int NT = 64 * WM * WN;
-    constexpr int TM = BM / WM, TN = BN / WN;
-    constexpr int FM = TM / 32, FN = TN / 32;
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
-    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT, LPT = LA + LB;   // LDS-DMA instructions per thread per K tile
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "whole DMA passes only");
-    static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile is made of 32x32 fragments");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int tilesM = (a.M + BM - 1) / BM;
-    const int tilesN = (a.N + BN - 1) / BN;
-    int tm, tn, z;
-    if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
-    const int row0 = tm * BM, col0 = tn * BN;
-    const int nk = a.K / BK;
-    const int kb = nk * z / a.splitk;
-    const int ke = nk * (z + 1) / a.splitk;
-    const int nt = ke - kb;
-
-    f32x16 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    uint32_t aoff[LA], boff[LB];
-    stage_offsets<BM, NT>(aoff, a.lda, row0, a.M - 1, tid);
-    stage_offsets<BN, NT>(boff, a.ldw, col0, a.wrows - 1, tid);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char* gA = reinterpret_cast<const char*>(a.A);
-    const char* gW = reinterpret_cast<const char*>(a.W) + (long)kb * BK * 2;
-    auto stage_a = [&](int t) {
-        const long a_off = a.conv_cpb ? (long)((kb + t) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t) % a.conv_cpb) * (BK * 2)
-                                      : (long)(kb + t) * (BK * 2);
-        stage_tile<BM, NT>(gA + a_off, aoff, smem + (t & 1) * STAGE_BYTES + wave_u * 1024, tid);
-    };
-    auto stage_w = [&](int t) {
-        stage_tile<BN, NT>(gW + (long)t * (BK * 2), boff, smem + (t & 1) * STAGE_BYTES + A_BYTES + wave_u * 1024, tid);
-    };
-    if (nt > 0) { stage_a(0); stage_w(0); }
-    if (nt > 1) { stage_a(1); stage_w(1); }
-
-    const int r32 = lane & 31, hi = lane >> 5;
-    uint32_t foff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) foff[ks] = r32 * 128 + (((2 * ks + hi) ^ ((r32 >> 1) & 7)) << 4);
-    const int a_base = wm * TM * 128, b_base = A_BYTES + wn * TN * 128;
-
-    // Software-pipelined over K tiles: when an iteration starts, k-steps 0 and 1 of its tile are already in registers (or on
-    // their way), so no MFMA ever waits on an LDS read issued right behind a barrier.
-    bf16x8 af[4][FM], bfr[4][FN];
-#define EZ_READ_KS(base, ks)                                                                                              \
-    do {                                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < FM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8*>((base) + foff[ks] + a_base + i * 4096);  \
-        _Pragma("unroll") for (int j = 0; j < FN; ++j) bfr[ks][j] = *reinterpret_cast<const bf16x8*>((base) + foff[ks] + b_base + j * 4096); \
-    } while (0)
-#define EZ_MFMA_KS(ks, i0, i1)                                                                                            \
-    do {                                                                                                                  \
-        _Pragma("unroll") for (int i = (i0); i < (i1); ++i)                                                               \
-            _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                                \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);           \
-    } while (0)
-    constexpr int IH = FM / 2 > 0 ? FM / 2 : 1;   // first part of k-step 0's MFMAs, issued ahead of the reads of k-steps 2, 3
-    if (nt > 0) {
-        if (nt > 1) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile 0 landed (this wave's part); tile 1 may still fly
-        __builtin_amdgcn_s_barrier();                           // ... and every other wave's part
-        EZ_READ_KS(smem, 0);
-        EZ_READ_KS(smem, 1);
-    }
-    // one LDS-DMA piece of K tile t (A pieces first, then W pieces)
-    auto stage_piece = [&](int t, long a_off, int p) {
-        char* dst = smem + (t & 1) * STAGE_BYTES + wave_u * 1024;
-        if (p < LA)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + a_off + aoff[p]),
-                                             (__attribute__((address_space(3))) void*)(dst + p * NT * 16), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + (long)t * (BK * 2) + boff[p - LA]),
-                                             (__attribute__((address_space(3))) void*)(dst + A_BYTES + (p - LA) * NT * 16), 16, 0, 0);
-    };
-    const bool prio = (a.debug & 1) != 0;
-    if ((a.debug & 2) && wave_u >= WM * WN / 2) __builtin_amdgcn_s_setprio(1);   // static priority for the later-dispatched half (T5 static form)
-    // RF: tile t + 2 exists (refill this tile's stage once it is released); NX: tile t + 1 exists (pre-read its k-steps 0, 1)
-    auto ktile = [&](int t, auto RF, auto NX) {
-        constexpr bool rf = decltype(RF)::value, nx = decltype(NX)::value;
-        const char* cT = smem + (t & 1) * STAGE_BYTES;
-        if (prio) __builtin_amdgcn_s_setprio(1);
-        EZ_MFMA_KS(0, 0, IH);
-        __builtin_amdgcn_sched_group_barrier(0x008, IH * FN, 0);
-        EZ_READ_KS(cT, 2);
-        EZ_READ_KS(cT, 3);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (FM + FN), 0);
-        EZ_MFMA_KS(0, IH, FM);
-        EZ_MFMA_KS(1, 0, FM);
-        __builtin_amdgcn_sched_group_barrier(0x008, (FM - IH) * FN + FM * FN, 0);
-        if (prio) __builtin_amdgcn_s_setprio(0);
-        // every fragment of K tile t is in registers: its stage is dead for this wave and, after the barrier, for all of them
-        // (sched_barrier on BOTH sides: hipcc otherwise sinks the register-only MFMAs below the inline-asm wait, which then
-        // drains the LDS reads right after they were issued)
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        if constexpr (rf) {
-            // refill it while k-step 2 computes: ONE piece behind each MFMA, so that no wave sits in a burst on the CU's
-            // vector-memory port while its MFMAs (and those of the wave sharing its SIMD, in lockstep) wait
-            const long ra_off = a.conv_cpb ? (long)((kb + t + 2) / a.conv_cpb) * a.conv_tap_bytes + (long)((kb + t + 2) % a.conv_cpb) * (BK * 2)
-                                           : (long)(kb + t + 2) * (BK * 2);
-            int p = 0;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[2][j], af[2][i], acc[i][j], 0, 0, 0);
-                    // pieces per MFMA: ceil so that all LPT pieces are out by the last MFMA of the k-step
-                    constexpr int PPM = (LPT + FM * FN - 1) / (FM * FN);
-#pragma unroll
-                    for (int q = 0; q < PPM; ++q, ++p)
-                        if (p < LPT) stage_piece(t + 2, ra_off, p);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x010, PPM, 0);
-                }
-        } else {
-            EZ_MFMA_KS(2, 0, FM);
-        }
-        if constexpr (nx) {
-            if constexpr (rf) wait_vmcnt<LPT>(); else wait_vmcnt<0>();   // tile t + 1 landed; tile t + 2 (just issued) keeps flying
-            __builtin_amdgcn_s_barrier();
-            const char* nT = smem + ((t + 1) & 1) * STAGE_BYTES;
-            EZ_READ_KS(nT, 0);
-            EZ_READ_KS(nT, 1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (FM + FN), 0);
-        }
-        EZ_MFMA_KS(3, 0, FM);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-    };
-    {
-        int t = 0;
-        for (; t + 2 < nt; ++t) ktile(t, std::true_type{}, std::true_type{});     // steady state
-        if (t + 1 < nt) { ktile(t, std::false_type{}, std::true_type{}); ++t; }   // last but one: nothing left to stage
-        if (t < nt) ktile(t, std::false_type{}, std::false_type{});               // last tile
-    }
-#undef EZ_READ_KS
-#undef EZ_MFMA_KS
-    if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
-        constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;
-        constexpr int NPASS = BM * (OC + 8) * 2 <= 2 * STAGE_BYTES ? 1 : 2;
-        static_assert((BM / NPASS) * (OC + 8) * 2 <= 2 * STAGE_BYTES, "epilogue tile must fit the two stages");
-        if (a.epi_lds && (EPI == EPI_GEGLU || a.part_bf16)) {
-            store_tile_lds<BM, BN, FM, FN, TM, TN, NT, EPI, NPASS>(a, acc, smem, row0, col0, wm, wn, lane, tid, z);
-            return;
-        }
-    }
-    store_tile<FM, FN, TM, TN, EPI>(a, acc, row0, col0, wm, wn, lane, z);
-}
-
 // choose the 8-box partition (pm x pn x pz boxes of bm x bn x bz tiles, one box per XCD) with the smallest per-XCD operand footprint
 // (bytes of A + W one XCD touches); returns the grid size
 int pick_boxes(GemmArgs& a, int BM, int BN) {
@@ -730,7 +548,7 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
 }
 
 // K-split-inside-the-workgroup kernel (gemm_ks.h): 8 waves, each with private LDS slots for its own K chunks, no barrier in the K loop
-template <int FM, int FN, int EPI, bool GATE, bool RES, int CK>
+template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, bool DUAL = false>
 int launch_ks(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.xcd_qkv = 0; a.xcd_panel = 0; a.splitk = 1;
@@ -746,31 +564,28 @@ int launch_ks(const GemmArgs& a0, hipStream_t st) {
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return 1;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES, CK>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES, CK, DUAL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (a.ts && (long)grid.x > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
-    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES, CK>), grid, dim3(512), SMEM, st, a);
+    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES, CK, DUAL>), grid, dim3(512), SMEM, st, a);
     return 0;
 }
-// tile ids of the K-split kernel: 70 = 48 x 96 (21 x 12 = 252 workgroups at M = 1000, N = 1152), 71 = 64 x 64, 72 = 32 x 96, 73 = 48 x 64,
-// 75 = 32 x 128 with one 64-wide K chunk per wave in flight; 76 = 48 x 96, 77 = 48 x 64 with two 32-wide chunks per wave
+// tile ids of the K-split kernel: 70 = 48 x 96 (21 x 12 = 252 workgroups at M = 1000, N = 1152), 72 = 32 x 96, 73 = 48 x 64 (the final Linear, N = 128), one 64-wide K chunk
+// per wave in flight.  Retired in round 5 (measured, never the default: profiles/r04a_gemm_microbench.txt, r05a_gemm_bench_pf.txt): 71 = 64 x 64, 75 = 32 x 128,
+// 76 / 77 = 48 x 96 / 48 x 64 with two 32-wide chunks per wave
 template <int EPI, bool GATE, bool RES>
 int launch_ks_tile(const GemmArgs& a, hipStream_t st) {
     switch (a.tile) {
         case 70: return launch_ks<3, 6, EPI, GATE, RES, 64>(a, st);
-        case 71: return launch_ks<4, 4, EPI, GATE, RES, 64>(a, st);
         case 72: return launch_ks<2, 6, EPI, GATE, RES, 64>(a, st);
         case 73: return launch_ks<3, 4, EPI, GATE, RES, 64>(a, st);
-        case 75: return launch_ks<2, 8, EPI, GATE, RES, 64>(a, st);
-        case 76: return launch_ks<3, 6, EPI, GATE, RES, 32>(a, st);
-        case 77: return launch_ks<3, 4, EPI, GATE, RES, 32>(a, st);
         default: return 1;
     }
 }
 
-// NS > 0: k_gemm with an NS-deep ring; NS == 0: k_gemm2 (two stages, early release)
+// lockstep kernel k_gemm with an NS-deep ring
 template <int BM, int BN, int WM, int WN, int NS, int EPI>
 int launch_t(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
@@ -778,7 +593,7 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     const int tilesN = (a.N + BN - 1) / BN;
     const int S = a.splitk;
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
-    if (EPI == EPI_PARTIAL && a.xcd_panel && NS > 0) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
+    if (EPI == EPI_PARTIAL && a.xcd_panel) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
     else a.xcd_panel = 0;
     if (EPI == EPI_QKV && a.xcd_qkv && a.hn.H % 4 == 0 && a.hn.B * (a.hn.H / 4) == 8 && tilesN == 3 * (a.hn.H / 4) && S == 1) {
         int nmax = 0;   // M tiles per batch element (a tile belongs to the batch element of its first row)
@@ -791,28 +606,19 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     } else {
         a.xcd_qkv = 0;
     }
-    constexpr int SMEM = (NS > 0 ? NS : 2) * (BM + BN) * 128;
+    constexpr int SMEM = NS * (BM + BN) * 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device
     static std::atomic<bool> attr_set[32];
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return 1;
-    if constexpr (NS > 0) {
-        if (!attr_set[dev].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
-            attr_set[dev].store(true, std::memory_order_release);
-        }
-        hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
-    } else {
-        if (!attr_set[dev].load(std::memory_order_acquire)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm2<BM, BN, WM, WN, EPI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
-            attr_set[dev].store(true, std::memory_order_release);
-        }
-        hipLaunchKernelGGL((k_gemm2<BM, BN, WM, WN, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm<BM, BN, WM, WN, NS, EPI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
+        attr_set[dev].store(true, std::memory_order_release);
     }
+    hipLaunchKernelGGL((k_gemm<BM, BN, WM, WN, NS, EPI>), grid, dim3(64 * WM * WN), SMEM, st, a);
     return 0;
 }
 
@@ -823,16 +629,12 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 //   9   128x128  4x2    3      96 KB  k_gemm     8 waves: split-K residual GEMMs at M <= 2048
 //   13  128x288  4x3    3     156 KB  k_gemm     12 waves: GEGLU GEMM fall-back (gemm_pp bit 0 off)
 //   25  128x64   4x2    4      96 KB  k_gemm     8 waves: small fp32 GEMMs
-//   40  256x256  2x4    -     128 KB  k_gemm2    two stages with early release (wave tile 128x64), for M > 2048
-//   41  192x256  2x4    -     112 KB  k_gemm2    wave tile 96x64: M = 4000 x N = 9216 -> 21 x 36 = 756 workgroups = 2.95 rounds of 256 CUs
-//   42  256x128  4x2    -      96 KB  k_gemm2    wave tile 64x64
+//   (40-42: round 2's large-tile kernel k_gemm2, 256x256 / 192x256 / 256x128, deleted in round 5: since round 4 no default path launched it)
 //   60  128x288  4x2 (32x144)         ring 3  156 KB  k_gemm_pp SCHED 1   GEGLU GEMM at M <= 2048
 //   61  128x144  4x1 per group        ring 4  144 KB  k_gemm_pp SCHED 2 (k-split); fused QKV GEMM (two heads of 72 per tile)
 //   62  128x128  4x2 (32x64)          ring 3   96 KB  k_gemm_pp SCHED 1
-//   63  64x128   2x2 per group        ring 4   96 KB  k_gemm_pp SCHED 2
-//   70-77  k_gemm_ks (K split over the waves of a workgroup, no ring): see launch_ks_tile
-//   64  128x144  4x1 per group        ring 3  108 KB  k_gemm_pp SCHED 2
-//   65  128x128  2x2 per group (64x64) ring 4 128 KB  k_gemm_pp SCHED 2
+//   (63-65: ping-pong experiments 64x128 / 128x144 ring 3 / 128x128 2x2, deleted in round 5)
+//   70, 72, 73  k_gemm_ks (K split over the waves of a workgroup, no ring): see launch_ks_tile
 template <int EPI>
 int launch_e(const GemmArgs& a, hipStream_t st) {
 #ifdef EZ_ABLATE   // timing ablations of the ping-pong K loop (VAR bits 8 / 16 / 32, gemm_pp.h; a.debug >> 8 selects): experiment builds only
@@ -858,15 +660,9 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
         case 9: return launch_t<128, 128, 4, 2, 3, EPI>(a, st);
         case 13: return launch_t<128, 288, 4, 3, 3, EPI>(a, st);
         case 25: return launch_t<128, 64, 4, 2, 4, EPI>(a, st);
-        case 40: return launch_t<256, 256, 2, 4, 0, EPI>(a, st);
-        case 41: return launch_t<192, 256, 2, 4, 0, EPI>(a, st);
-        case 42: return launch_t<256, 128, 4, 2, 0, EPI>(a, st);
         case 60: EZ_PP(128, 288, 4, 2, 3, 1)
         case 61: EZ_PP(128, 144, 4, 1, 4, 2)
         case 62: EZ_PP(128, 128, 4, 2, 3, 1)
-        case 63: EZ_PP(64, 128, 2, 2, 4, 2)
-        case 64: EZ_PP(128, 144, 4, 1, 3, 2)
-        case 65: EZ_PP(128, 128, 2, 2, 4, 2)
         default: break;
     }
 #undef EZ_PP
@@ -891,6 +687,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_RESID && a.tile >= 70) {   // K-split-inside-the-workgroup kernel: residual (optional) + gate (optional) + statistics + next operand
         if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.out || !a.bias || a.splitk != 1 || (a.gate && !a.resid)) return 1;
+        if (a.zd) {   // DUAL form: 48 x 96 tiles only
+            if (!a.gate || !a.zg2 || a.tile != 70 || a.rows_per_b <= 0) return 1;
+            return launch_ks<3, 6, EPI_RESID, true, true, 64, true>(a, st);
+        }
         if (a.gate) return launch_ks_tile<EPI_RESID, true, true>(a, st);
         if (a.resid) return launch_ks_tile<EPI_RESID, false, true>(a, st);
         return launch_ks_tile<EPI_RESID, false, false>(a, st);

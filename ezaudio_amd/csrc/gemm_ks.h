@@ -23,11 +23,35 @@
 
 namespace {
 
-// EPI_RESID operands of one thread (8 threads per output row; SL 16-byte column slots each): requested at kernel start, used after the loop
+// EPI_RESID operands of one thread (8 threads per output row; SL 16-byte column slots each): requested at kernel start, used after the loop.
+// They are loaded by INLINE ASM straight into AGPRs (the accumulators take 4 FM FN of the 128, these 16 SL): hipcc neither counts them in its
+// vmcnt bookkeeping nor shuffles them between register files.  Before (round 4, plain C++ loads): hipcc loaded three of the twelve into VGPRs,
+// copied them to AGPRs in front of the first MFMA and put `s_waitcnt vmcnt(0)` there -- the second chunk's LDS-DMA could not be re-issued before
+// the operands had landed -- and the device step counter, a dependent VECTOR load in front of them, drained the first chunk's DMA before
+// the operands were even requested: two full memory latencies on the critical path of every launch (profiles/r05_experiments.txt).
 template <int SL>
 struct KsOperands {
-    float4 b[SL], r[SL], g[SL], z[SL];
+    f32x4 b[SL], r[SL], g[SL], z[SL];
 };
+__device__ __forceinline__ f32x4 ks_ld16_agpr(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(v) : "v"(p) : "memory");
+    return v;
+}
+// all loads of this wave have landed; ties the operand registers to the wait so that no read of them can be scheduled above it
+template <int SL, int EPI, bool GATE, bool RES>
+__device__ __forceinline__ void ks_operands_wait(KsOperands<SL>& op) {
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        if constexpr (EPI == EPI_RESID) {
+            if constexpr (GATE && RES) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.r[q]), "+a"(op.g[q]), "+a"(op.z[q]));
+            else if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.r[q]), "+a"(op.z[q]));
+            else asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.z[q]));
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]));
+        }
+    }
+}
 
 // column of 16-byte (4-float) slot q of lane j of a row: slots come in pairs (8 contiguous columns: one 16-byte bf16 store) while they last,
 // then one single slot per lane (paired with lane ^ 1 for the bf16 store)
@@ -58,9 +82,13 @@ __device__ __forceinline__ bool ks_tile_of_block(const GemmArgs& a, int tilesM, 
 }
 
 // CK = K columns per chunk: 64 (one slot per wave) or 32 (two slots per wave: one is always in flight)
-template <int FM, int FN, int EPI, bool GATE, bool RES, int CK>
+// DUAL (EPI_RESID with gate and residual; the attention-out projection when cross-attention is skipped for single-key batch elements, GemmArgs.zd):
+// rows OUTSIDE [a.act_row0, a.act_row1) get  h_new = resid + gate (acc + bias) + zd[batch element][col]  and  A' = bf16(h_new * zg2): for them this
+// launch also is the cross-attention-out projection (whose output is the constant vector zd) and the producer of the GEGLU GEMM's operand
+template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, bool DUAL = false>
 __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     static_assert(EPI == EPI_F32 || EPI == EPI_RESID, "epilogues");
+    static_assert(!DUAL || (EPI == EPI_RESID && GATE && RES), "DUAL: the gated residual projection only");
     static_assert(FN % 2 == 0 && FM >= 1 && FM <= 4, "tile geometry: 8 lanes per output row, FN / 2 column slots each");
     static_assert(CK == 64 || CK == 32, "chunk width");
     constexpr int BM = 16 * FM, BN = 16 * FN;
@@ -83,6 +111,12 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // device step counter (selects the modulation slot of gate / gain): ONE SCALAR load, issued first thing and waited for (lgkmcnt) right
+    // in front of the operand requests -- as a vector load it shared the vmcnt queue with the LDS-DMA and drained it
+    int slot0 = 0;
+    if constexpr (EPI == EPI_RESID) {
+        if (a.cur_step) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(slot0) : "s"(a.cur_step) : "memory");
+    }
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     int tm, tn;
@@ -153,28 +187,53 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
 #pragma unroll
     for (int i = 1; i < NSL; ++i)                  // (chunk 0 went out with the offsets above)
         if (i < nmine) issue(wave + 8 * i, slot + i * CHUNK);
-    // ---- epilogue operands (bias, residual rows, gate, LayerNorm gain), requested BEHIND the first chunks -- their addresses need the device
-    // step counter, a scalar round trip that sat in front of the first LDS-DMA (2.6 us from kernel start to the first piece in situ) -- and
-    // carried through the K loop in registers.  EVERY thread issues them (rows / columns clamped; the threads beyond the 8 BM epilogue threads
-    // never use theirs) so that each wave has exactly NOPL loads behind its prologue chunks: the counted waits below rely on it
+    // ---- epilogue operands (bias, residual rows, gate, LayerNorm gain): requested right BEHIND the prologue chunks (inline-asm loads into AGPRs,
+    // KsOperands) and carried through the K loop.  EVERY thread issues them (rows / columns clamped; the threads beyond the 8 BM epilogue threads
+    // never use theirs) so that each wave has exactly NOPL loads behind its prologue chunks: the counted waits below rely on it, the
+    // sched_barriers pin the order, and tests/test_host.py counts the loads in the generated code
     constexpr int NOPL = SL * (1 + (EPI == EPI_RESID ? 1 + (RES ? 1 : 0) + (GATE ? 1 : 0) : 0));
-    KsOperands<SL> op = {};
+    KsOperands<SL> op;
+    bool alt = false;          // DUAL: this thread's row belongs to a batch element whose cross-attention is the constant zd
+    int brow = 0;              // ... its batch element
+    __builtin_amdgcn_sched_barrier(0);
     {
-        int slot_m = 0;
-        if constexpr (EPI == EPI_RESID) slot_m = (a.cur_step ? *a.cur_step : 0) + (a.row_slot ? a.row_slot[erow / a.rows_per_b] : 0);
+        if constexpr (EPI == EPI_RESID) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(slot0));
         const float* bsrc = a.bias ? a.bias : reinterpret_cast<const float*>(a.W);   // null bias: any valid address, the value is dropped below
-#pragma unroll
-        for (int q = 0; q < SL; ++q) {
-            int col = col0 + 4 * ks_slot_of<SL>(q, ej);
-            col = col < ncl ? col : ncl;
-            op.b[q] = *reinterpret_cast<const float4*>(bsrc + col);
+        const float* gsrc = nullptr;
+        const float* zsrc = nullptr;
+        auto request = [&](int slot_m) {
             if constexpr (EPI == EPI_RESID) {
-                if constexpr (RES) op.r[q] = *reinterpret_cast<const float4*>(a.resid + (long)erow * a.ldr + col);
-                if constexpr (GATE) op.g[q] = *reinterpret_cast<const float4*>(a.gate + (long)slot_m * a.gate_slot_stride + col);
-                op.z[q] = *reinterpret_cast<const float4*>(a.zg + (long)slot_m * a.zg_slot_stride + col);
+                if constexpr (GATE) gsrc = a.gate + (long)slot_m * a.gate_slot_stride;
+                zsrc = a.zg + (long)slot_m * a.zg_slot_stride;
+                if constexpr (DUAL) {
+                    alt = erow < a.act_row0 || erow >= a.act_row1;
+                    brow = (int)(((float)erow + 0.5f) * __builtin_amdgcn_rcpf((float)a.rows_per_b));   // erow / rows_per_b (rows < 2^22)
+                    if (alt) zsrc = a.zg2 + (long)slot_m * a.zg2_slot_stride;
+                }
             }
+#pragma unroll
+            for (int q = 0; q < SL; ++q) {
+                int col = col0 + 4 * ks_slot_of<SL>(q, ej);
+                col = col < ncl ? col : ncl;
+                op.b[q] = ks_ld16_agpr(bsrc + col);
+                if constexpr (EPI == EPI_RESID) {
+                    if constexpr (RES) op.r[q] = ks_ld16_agpr(a.resid + (long)erow * a.ldr + col);
+                    if constexpr (GATE) op.g[q] = ks_ld16_agpr(gsrc + col);
+                    op.z[q] = ks_ld16_agpr(zsrc + col);
+                }
+            }
+        };
+        // per-row timesteps (ezdit_forward with one t per batch element, never the sampler): the row's slot offset is a dependent vector load.
+        // Its own branch with its own copy of the requests: at a join hipcc's (path-insensitive) vmcnt bookkeeping would drain the LDS-DMA on BOTH paths
+        if (EPI == EPI_RESID && a.row_slot) {
+            request(slot0 + a.row_slot[erow / a.rows_per_b]);
+            asm volatile("; per-row slot" ::: "memory");
+        } else {
+            request(slot0);
+            asm volatile("; shared slot" ::: "memory");
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
     if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
     for (int i = 0; i < nmine; ++i) {
         // own LDS-DMA of chunk i landed (nothing else orders a ds_read behind it): wait until only the loads issued AFTER it are outstanding
@@ -205,25 +264,24 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         if (i + NSL < nmine) issue(wave + 8 * (i + NSL), cur);
         __builtin_amdgcn_sched_barrier(0);
         // transposed product (W fragment as the A operand): a lane owns output row lane & 15 and columns 4 (lane >> 4) + {0..3} of a fragment
+        // The LAST MFMA of the chunk carries 20 wait states: an inline-asm MFMA is invisible to hipcc's hazard recogniser, and whatever the register
+        // allocator puts on the loop's exit edge (round 5: the DUAL instantiation got `v_accvgpr_read a48 ..; v_accvgpr_mov a48, a52 ..` there, IN FRONT of
+        // the wait states that used to follow the loop, and read accumulators the matrix pipe had not written yet: wrong, run-to-run different results)
+        // now sits behind them by construction.  ~20 cycles per chunk, in front of a memory wait.
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
             for (int ii = 0; ii < FM; ++ii)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ii][j]) : "v"(bfr[j][ks]), "v"(af[ii][ks]));
+                for (int j = 0; j < FN; ++j) {
+                    if (ks == KSTEPS - 1 && ii == FM - 1 && j == FN - 1)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[ii][j]) : "v"(bfr[j][ks]), "v"(af[ii][ks]));
+                    else
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ii][j]) : "v"(bfr[j][ks]), "v"(af[ii][ks]));
+                }
     }
     if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
-    // the last MFMA's result is not interlocked against the reads below (inline asm): 20 wait states tied to the accumulators
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    // (the wait states between the last MFMA and the first read of an accumulator are inside the loop: see the last MFMA of a chunk)
 
     // ---- park this wave's partial tile in its OWN slot (dead: its last chunk was read above and nothing is in flight): [BM][S4] 16-byte
     // slots, slot s of row r at s ^ (r & 7) -- the 8 lanes of a store group hold 8 different rows of one column slot
@@ -240,6 +298,20 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     __syncthreads();
     if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
     if (!epi_thread) return;
+    ks_operands_wait<SL, EPI, GATE, RES>(op);   // (landed long ago whenever the wave had a second chunk: its vmcnt(0) covered them)
+    // DUAL: the constant cross-attention-out vector of this row's batch element, requested HERE -- behind the park (hipcc drains vmcnt in front of the
+    // first LDS write next to an LDS-DMA it cannot prove finished: requested in front of the park they were waited for at once) -- landing under the
+    // partial sums below; 252 workgroups read the same few KB: L2 hits
+    float4 dv[SL];
+    if constexpr (DUAL) {
+        const float* dsrc = a.zd + (long)brow * a.zd_stride;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) {
+            int col = col0 + 4 * ks_slot_of<SL>(q, ej);
+            col = col < ncl ? col : ncl;
+            dv[q] = *reinterpret_cast<const float4*>(dsrc + col);
+        }
+    }
 
     // ---- sum the eight partials in wave order (fixed: bit-reproducible) and finish the row segment
     float4 v[SL];
@@ -260,8 +332,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
-            const float4 bb = a.bias ? op.b[q] : make_float4(0.f, 0.f, 0.f, 0.f);   // (a select: the dummy load of a null bias may hold NaN bit patterns)
-            const float4 o = make_float4(v[q].x + bb.x, v[q].y + bb.y, v[q].z + bb.z, v[q].w + bb.w);
+            const f32x4 bb = a.bias ? op.b[q] : f32x4{0.f, 0.f, 0.f, 0.f};   // (a select: the dummy load of a null bias may hold NaN bit patterns)
+            const float4 o = make_float4(v[q].x + bb[0], v[q].y + bb[1], v[q].z + bb[2], v[q].w + bb[3]);
             if (row_ok && col < a.N) {
                 float* dst = out + (long)erow * a.ldo + col;
                 if (a.wt) st16_wt(dst, o); else *reinterpret_cast<float4*>(dst) = o;
@@ -274,9 +346,12 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
             const bool ok = col < a.N;
             // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
-            float4 x = make_float4(v[q].x + op.b[q].x, v[q].y + op.b[q].y, v[q].z + op.b[q].z, v[q].w + op.b[q].w);
-            if constexpr (GATE) { x.x *= op.g[q].x; x.y *= op.g[q].y; x.z *= op.g[q].z; x.w *= op.g[q].w; }
-            if constexpr (RES) { x.x += op.r[q].x; x.y += op.r[q].y; x.z += op.r[q].z; x.w += op.r[q].w; }
+            float4 x = make_float4(v[q].x + op.b[q][0], v[q].y + op.b[q][1], v[q].z + op.b[q][2], v[q].w + op.b[q][3]);
+            if constexpr (GATE) { x.x *= op.g[q][0]; x.y *= op.g[q][1]; x.z *= op.g[q][2]; x.w *= op.g[q][3]; }
+            if constexpr (RES) { x.x += op.r[q][0]; x.y += op.r[q][1]; x.z += op.r[q][2]; x.w += op.r[q][3]; }
+            if constexpr (DUAL) {   // + the cross-attention block's constant output for this batch element (exactly 0 for the rows that run cross-attention)
+                x.x += alt ? dv[q].x : 0.f; x.y += alt ? dv[q].y : 0.f; x.z += alt ? dv[q].z : 0.f; x.w += alt ? dv[q].w : 0.f;
+            }
             v[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
             s1 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
             if (row_ok && ok) {
@@ -295,8 +370,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         uint2 pk[SL];
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
-            pk[q].x = pack_bf2(v[q].x * op.z[q].x, v[q].y * op.z[q].y);
-            pk[q].y = pack_bf2(v[q].z * op.z[q].z, v[q].w * op.z[q].w);
+            pk[q].x = pack_bf2(v[q].x * op.z[q][0], v[q].y * op.z[q][1]);
+            pk[q].y = pack_bf2(v[q].z * op.z[q][2], v[q].w * op.z[q][3]);
         }
         bf16_t* zrow = a.zu + (long)erow * a.ld_zu;
         auto store8 = [&](int col, uint2 lo, uint2 hi) {   // columns [col, col + 8) of this row

@@ -507,27 +507,6 @@ __global__ __launch_bounds__(256) void k_conv1d(Conv1dArgs a) {
     else a.out[((long)b * a.Cout + co) * a.Lout + lo] = acc;
 }
 
-// EXPERIMENT, off by default (ezdit_set_option "prefetch"): measured -9...-13 % on MI355X, see DESIGN.md.
-// Touch a byte range so that it is resident in the memory-side Infinity Cache (256 MB) when the GEMMs of the NEXT block ask
-// for it: the step streams 1.75 GB of weights exactly once, every GEMM workgroup would otherwise start with an HBM round
-// trip (measured: the same GEMM takes 10 us on warm weights and 17 us in the step).  Runs on a side stream next to the
-// compute kernels; 64 small workgroups, so it takes CU slots from nobody.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-__global__ __launch_bounds__(256) void k_prefetch(const u32x4* __restrict__ p, long n16, unsigned* sink) {
-    unsigned acc = 0;
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride * 4) {
-        // 4 independent 16-byte non-temporal loads in flight per thread (stream through L2, fill the Infinity Cache)
-        const long i1 = i + stride, i2 = i1 + stride, i3 = i2 + stride;
-        const u32x4 a = __builtin_nontemporal_load(p + i);
-        const u32x4 b = i1 < n16 ? __builtin_nontemporal_load(p + i1) : a;
-        const u32x4 c = i2 < n16 ? __builtin_nontemporal_load(p + i2) : a;
-        const u32x4 d = i3 < n16 ? __builtin_nontemporal_load(p + i3) : a;
-        acc ^= a.x ^ b.y ^ c.z ^ d.w;
-    }
-    if (acc == 0x9e3779b9u) *sink = acc;  // never true in practice; keeps the loads alive
-}
-
 // out bf16 [M][ldo] = act(x fp32 [M][ldx]) for cols < N, zero for N <= col < ldo
 __global__ __launch_bounds__(256) void k_cast_bf16(const float* __restrict__ x, int ldx, bf16_t* __restrict__ out,
                                                    int ldo, int M, int N, int act) {
@@ -634,14 +613,27 @@ void launch_z_combine(const float* tmp, int ld_tmp, const float* bias, float* zG
     hipLaunchKernelGGL(k_z_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, ld_tmp, bias, zG, zC, slot_stride, n_slots, N);
 }
 
+// one wave per output: y[n] = bias[n] + x . W[n]  (the constant cross-attention-out vector of a single-key batch element, ezdit_prepare_context)
+__global__ __launch_bounds__(256) void k_gemv_bf16w(const float* __restrict__ x, int x_bf16, const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
+                                                    float* __restrict__ y, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const bf16_t* w = W + (long)n * ldw;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float xv = x_bf16 ? bf2f(f2bf(x[k])) : x[k];
+        acc = fmaf(xv, bf2f(w[k]), acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[n] = acc + (bias ? bias[n] : 0.f);
+}
+void launch_gemv_bf16w(const float* x, int x_bf16, const bf16_t* W, int ldw, const float* bias, float* y, int N, int K, hipStream_t st) {
+    hipLaunchKernelGGL(k_gemv_bf16w, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, x, x_bf16, W, ldw, bias, y, N, K);
+}
+
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st) {
     const long total = (long)M * ldo;
     hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, ldx, out, ldo, M, N, act);
-}
-
-void launch_prefetch(const void* p, size_t bytes, unsigned* sink, hipStream_t st) {
-    if (bytes < 16) return;
-    hipLaunchKernelGGL(k_prefetch, dim3(32), dim3(256), 0, st, reinterpret_cast<const u32x4*>(p), (long)(bytes / 16), sink);
 }
 
 void launch_conv1d(const Conv1dArgs& a, hipStream_t st) {

@@ -86,14 +86,21 @@ class LatentSampler:
                                                        C.c_void_p(self.stream.cuda_stream)))
         return self.latents
 
-    def finish(self):
-        """Wait for the sampler stream and hand back the latents.
+    def finish(self, block=True):
+        """Hand back the latents.  BLOCKS THE HOST by default (`stream.synchronize()` on the sampler stream), so the caller's stream needs no
+        ordering afterwards and the returned tensor is final.
 
-        The wait is a HOST wait on purpose: queueing a cross-stream wait (`current_stream.wait_stream(self.stream)`) while the step graphs
-        are still executing makes the graphs themselves run 5-6 % slower on MI355X / ROCm 7.2 (4.01 vs 4.24 ms per step over a 20-step
+        The host wait is deliberate: queueing a cross-stream wait (`current_stream.wait_stream(self.stream)`) while the step graphs are
+        still executing makes the graphs themselves run 5-6 % slower on MI355X / ROCm 7.2 (4.01 vs 4.24 ms per step over a 20-step
         loop, HIP events on the sampler stream, alternating in one process: profiles/r04_experiments.txt) -- a second hardware queue
-        parked on a barrier packet next to the running one.  After the host wait the caller's stream needs no ordering at all."""
-        self.stream.synchronize()
+        parked on a barrier packet next to the running one.
+
+        block=False keeps the round-3 contract for callers that pipeline host work: no host synchronisation, the CURRENT stream is made to wait
+        for the sampler stream (stream-ordered; costs the running graphs the 5-6 % above)."""
+        if block:
+            self.stream.synchronize()
+        else:
+            torch.cuda.current_stream(self.latents.device).wait_stream(self.stream)
         return self.latents
 
 

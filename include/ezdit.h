@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define EZDIT_ABI_VERSION 2
+#define EZDIT_ABI_VERSION 3
 
 typedef struct ezdit_handle ezdit_handle;
 typedef void* ezdit_stream; /* hipStream_t */
@@ -209,44 +209,37 @@ int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, 
                          ezdit_stream stream);
 /* copy an internal fp32/bf16 buffer (by name, e.g. "h", "u", "q", "k", "vt", "mod") for debugging. */
 int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t* bytes);
-/* Kept for ABI stability: returns EZDIT_OK (EZDIT_E_STATE before a workspace is bound) without synchronising.  Round 2's in-launch
- * split-K hand-off, the only device-side wait this library ever had, was removed; launch failures surface through return codes. */
-int ezdit_device_status(ezdit_handle* h, ezdit_stream stream);
 /* number of kernel launches issued by the last ezdit_forward (host counter). */
 int ezdit_last_launch_count(const ezdit_handle* h);
 /* n > 0: ezdit_forward returns after n kernel launches so a test can inspect intermediates; 0 = off. */
 int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
-/* Tuning / A-B knobs (tools/ab_sweep.py flips them on a live sampler, tools/ab_prepare.py re-prepares per option set; a captured graph is dropped and re-captured).  Defaults
- * are the measured best on MI355X; none changes results beyond fp rounding.  Unknown names return EZDIT_E_INVALID.
- *   GEMM tile ids (csrc/gemm.hip table): tile_partial, tile_f32, tile_qkv, tile_p18 / tile_p36 / tile_p72 (per K depth),
- *     geglu_tile, and for > 2048 rows tile_partial_big, tile_f32_big, geglu_big; split-K: split18 / split36 / split72, split_big
- *   xcd_map 0/1 (box-shaped workgroup -> XCD placement), slab_bf16 0/1 (split-K slabs in bf16), wt 0/1/2 (write-through (sc1) output stores; 2 = default: on while B L <= 2048)
- *   fuse_qkv 0/1 (head-norm + RoPE + V^T in the QKV GEMM epilogue), qkv_waves9 0/1, fuse_q2 0/1/2 (cross-attention computes its
- *     own q projection; 2 = also for large grids), fuse_qnorm 0/1, fuse_resid 0/1, attn_nkh 0/2/4 (attention key sub-blocks)
- *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), row_variant 0/1 (row kernel: one workgroup / one
- *     wave per row)
- *   cn_overlap 0/1 (fused sampler: ControlNet branch on a side stream next to the backbone's in-blocks)
- *   gemm_pp (ping-pong kernel k_gemm_pp at M <= pp_max_m rows (default: unlimited): bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; the split-K
- *     residual GEMMs select it with tile_partial = 62), pp_max_m (above it the large-tile k_gemm2 / lockstep-QKV path and no LayerNorm algebra)
+/* A/B knobs (a captured graph is dropped and re-captured; set them BEFORE ezdit_prepare_timesteps when they select the LayerNorm-algebra path).
+ * Defaults are the measured best on MI355X; none changes results beyond fp rounding.  Unknown names return EZDIT_E_INVALID.  Every name below is set
+ * by a test (tests/test_host.py: all of them on a handle; tests/test_gpu.py, tests/test_controlnet.py: each non-default value against the reference
+ * goldens or bitwise against the default).  Round 5 removed 30 names that only the experiments which settled them ever set (tile / split-K ids per
+ * shape, zbig*, ztile, zmlp, zskip, pp_max_m, prefetch, gemm_debug, fuse_resid, fuse_qkv, fuse_qnorm, qkv_waves9, xcd_map, slab_bf16, geglu_tile ...).
  *   zfuse 0/1, default 1 (LayerNorm algebra: attention-out / cross-attention-out / skip_linear / in-block MLP-out projections UN-SPLIT with the
  *     residual, per-column-tile LayerNorm statistics and the next GEMM's operand in their epilogue -- k_gemm_ks (csrc/gemm_ks.h) up to 2048 rows,
- *     the ping-pong kernel's 128 x 144 tile above (zbig 0/1) -- the consumer GEMM finishing the LayerNorm in its epilogue: no split-K slabs, no row
- *     kernel on those edges; needs gemm_pp = 3 and a LayerNorm-algebra q projection (fuse_q2 at small grids, q2_pp above)); ztile (70 ... 77:
- *     k_gemm_ks tile, csrc/gemm.hip), zmlp 0/1 and zskip 0/1 (MLP-out / skip_linear on the un-split producer too)
- *   q2_pp 0/1 (cross-attention q projection at grids too large for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue),
- *     zbig_m (rows above which the 128 x 144 producer replaces k_gemm_ks, default 2048), tile_pe / tile_fin (patch-embed / final-Linear GEMM at
- *     M <= 2048: a k_gemm_ks tile id, -1 = tile_f32)
- *   zfake 0/1 (DIAGNOSTIC, default 0: the consumers run their LayerNorm-algebra variant on a finished LayerNorm with neutral tables -- what
- *     the consumer side costs by itself; results change by the factor rsqrt(1 + 1e-5))
- *   gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of an M tile on XCD tm % 8) and
- *     row_affine 0/1 (the row kernel processes row panel p on XCD p % 8): a panel's slabs / residual stream / LayerNorm output stay in
- *     one XCD's L2 across the kernel boundary.  Placement only.
- *   epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks), qkv_affine 0/1 (fused QKV GEMM: every tile
- *     on the XCD whose attention workgroups read it), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
- *   gemm_debug (k_gemm2 experiment bits)
+ *     the ping-pong kernel's 128 x 144 tile above -- the consumer GEMM finishing the LayerNorm in its epilogue: no split-K slabs, no row
+ *     kernel on those edges; needs gemm_pp = 3 and a LayerNorm-algebra q projection (fuse_q2 at small grids, q2_pp above); 0 = split-K slabs + row kernel)
+ *   xkey1 0/1, default 1 (single-key cross-attention shortcut, needs zfuse: a batch element whose context mask has ONE valid key -- every unconditional
+ *     row of classifier-free guidance -- gets the constant W_o v_key + b_o from the attention-out projection instead of a cross-attention launch;
+ *     cross-attention and its out-projection then run over the other batch elements only.  Exact (softmax over one key is 1); 0 = every row through k_attn)
+ *   gemm_pp (ping-pong kernel k_gemm_pp: bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; 0 = the round-1/2 lockstep kernels and no LayerNorm algebra)
+ *   tile_partial (tile id of the split-K residual GEMMs at M <= 2048 rows: 9 = lockstep 128 x 128, 62 = the same tile on the ping-pong kernel; csrc/gemm.hip table)
+ *   wt 0/1/2 (write-through (sc1) output stores; 2 = default: on while B L <= 2048)
+ *   fuse_q2 0/1/2 (cross-attention computes its own q projection; 2 = also for large grids), q2_pp 0/1 (cross-attention q projection at grids too large
+ *     for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue; 0 = fp32 GEMM + normalisation inside k_attn)
+ *   attn_nkh 0/2/4 (attention key sub-blocks per tile, 0 = by grid size), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
+ *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), qkv_affine 0/1 (fused QKV GEMM: every tile on the XCD whose attention
+ *     workgroups read it), gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of
+ *     an M tile on XCD tm % 8) and row_affine 0/1 (the row kernel processes row panel p on XCD p % 8).  Placement only: bitwise identical results.
+ *   row_variant 0/1 (row kernel: one workgroup / one wave per row), epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks)
+ *   cn_overlap 0/1 (fused sampler: ControlNet branch on a side stream next to the backbone's in-blocks)
  *   stamp_launch i / trace_launches 0/1 (diagnostics, eager launches only: launch i of a forward writes its in-kernel cycle stamps to the buffer
  *     registered with ezdit_debug_gemm_timestamps; every launch of a forward is named on stderr -- tools/diag_stamps.py)
- *   prefetch 0/1 (Infinity-Cache weight prefetch on a side stream) */
+ * A library built with -DEZ_DIAG (EZAUDIO_DIAG=1 python -m ezaudio_amd.build) also knows zfake 0/1: the LayerNorm-algebra consumers run on a finished
+ * LayerNorm with neutral tables (what the consumer side costs by itself; results change by the factor rsqrt(1 + 1e-5)). */
 int ezdit_set_option(ezdit_handle* h, const char* name, int value);
 
 #ifdef __cplusplus

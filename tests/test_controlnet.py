@@ -8,7 +8,7 @@ import pytest
 from oracle.controlnet import CN_DEFAULT, ControlNetOracle, conv1d, energy_curve, make_controlnet_state_dict
 from oracle.dit import DiTOracle
 from oracle.weights import make_inputs, make_state_dict, model_config, uniform_pm1  # noqa: F401
-from tests.util import GOLDEN, rel_l2
+from tests.util import GOLDEN, record, rel_l2
 
 
 def cn_case(name):
@@ -127,7 +127,7 @@ def test_controlnet_sampler_matches_the_reference_controlnet_loop_golden(lib, gn
     lat = smp.finish()
     torch.cuda.synchronize()
     r = rel_l2(lat.cpu().numpy(), g['latent'])
-    print(f'{gname}: final-latent rel-L2 {r:.3e}')
+    record(f'{gname}: final-latent rel-L2 {r:.3e}')
     assert torch.isfinite(lat).all() and r < 2e-2
 
 
@@ -165,12 +165,12 @@ def test_controlnet_hip_matches_reference_golden(lib, name):
         assert len(skips) == cfg['depth'] // 2
         for i, s in enumerate(skips):
             r = rel_l2(s.cpu().numpy()[:, ::rs], g[f'res{i}{sfx}'])
-            print(f'{name} t={tt} residual {i}: rel-L2 {r:.3e}')
+            record(f'{name} t={tt} residual {i}: rel-L2 {r:.3e}')
             assert r < 2e-2
         pred = m.model(x257, t, _t(inp['ctx']), context_mask=_t(inp['ctx_mask']), cls_token=None, controlnet_skips=skips)
         ref = g['pred' + sfx]
         r = rel_l2(pred.cpu().numpy(), ref)
-        print(f'{name} t={tt} backbone prediction with ControlNet skips: rel-L2 {r:.3e}')
+        record(f'{name} t={tt} backbone prediction with ControlNet skips: rel-L2 {r:.3e}')
         assert r < 2e-2 and float(np.abs(pred.cpu().numpy() - ref).max()) < 0.15 * max(1.0, float(ref.std()) / 1.48)
 
 
@@ -218,9 +218,21 @@ def test_controlnet_fused_sampler_equals_stepwise_calls(lib, zfuse):
     # ... and the rest of the 50 steps: the ControlNet must see the CURRENT timestep's modulation at every step (the reference passes t
     # into it each step, src/inference_controlnet.py:92-96); a ControlNet pinned to the first timestep's slot drifts far beyond this gate
     smp.run(50 - steps)
-    lat = smp.finish()
+    lat = smp.finish().clone()
     torch.cuda.synchronize()
     assert rel_l2(lat.cpu().numpy(), tr[49]) < 2e-2
+    # option cn_overlap = 0: the ControlNet chain on the sampler's own stream instead of the side stream -- same kernels, same order per chain: bitwise
+    assert lib.ezdit_set_option(m._h, b'cn_overlap', 0) == 0
+    try:
+        smp.prepare(_t(inp['ctx'][0:1]), _t(inp['ctx_mask'][0:1]), _t(inp['ctx'][1:2]), _t(inp['ctx_mask'][1:2]), _t(init),
+                    torch.stack([_t(z) for z in noises], 0), 3.5, 0.0, 50, 1.0, controlnet=cn, condition=_t(cond1),
+                    conditioning_scale=scale)
+        smp.run(50)
+        serial = smp.finish().clone()
+        torch.cuda.synchronize()
+    finally:
+        assert lib.ezdit_set_option(m._h, b'cn_overlap', 1) == 0
+    assert torch.equal(serial, lat)
     # the fused run left conditioning_scale 0.8 attached to the backbone: the drop-in call surface (residuals already scaled by
     # DiTControlNet.forward, controlnet.py:313) must not apply it a second time
     x_probe = np.concatenate([init, init], 0)

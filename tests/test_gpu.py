@@ -14,7 +14,7 @@ import torch
 from oracle.dit import DiTOracle
 from oracle.sampler import sample as oracle_sample
 from oracle.weights import make_inputs, make_state_dict, model_config, uniform_pm1
-from tests.util import DIFF, golden_case, rel_l2, sampler_case
+from tests.util import DIFF, golden_case, record, rel_l2, sampler_case
 
 pytestmark = pytest.mark.gpu
 
@@ -51,26 +51,14 @@ def t_(a, dev='cuda:0'):
 # kernel level
 # ---------------------------------------------------------------------------------------------------
 # variant = tile_config * 4 + epilogue; epilogue 0 = fp32 (+bias), 1 = split-K partial slabs, 2 = GEGLU
-# tile_config: the table in csrc/gemm.hip (6, 9, 13, 25 lockstep k_gemm; 40-42 large-tile k_gemm2; 60-65 ping-pong k_gemm_pp)
+# tile_config: the table in csrc/gemm.hip (6, 9, 13, 25 lockstep k_gemm; 60-62 ping-pong k_gemm_pp; 70, 72, 73 K-split k_gemm_ks)
 @pytest.mark.parametrize('M,N,K,variant,splitk', [
     (1000, 1152, 1152, 6 * 4 + 0, 1),   # 128x64, waves 4x1
     (1000, 1152, 1152, 9 * 4 + 1, 3),   # 128x128, 8 waves, ring 3
     (1000, 1152, 1152, 13 * 4 + 0, 1),  # 128x288, ring 3
     (1000, 1152, 1152, 13 * 4 + 1, 6),  # 128x288, ring 3, 3 K tiles per slice
-    # k_gemm2 (two LDS stages with early release): 256x256, 192x256, 256x128 tiles
-    (4000, 1152, 1152, 40 * 4 + 0, 1),
-    (1000, 3456, 1152, 40 * 4 + 0, 1),
-    (4000, 1152, 4608, 40 * 4 + 1, 3),  # split-K 3: 24 K tiles per slice
-    (1000, 1152, 1152, 40 * 4 + 1, 9),  # 2 K tiles per slice: shorter than the pipeline
-    (300, 256, 64, 40 * 4 + 0, 1),      # single K tile
-    (300, 256, 128, 40 * 4 + 0, 1),     # two K tiles
-    (300, 300, 192, 40 * 4 + 1, 2),     # ragged M / N, uneven split (1 + 2 tiles)
-    (4000, 1152, 1152, 41 * 4 + 0, 1),  # 192x256
-    (500, 300, 192, 41 * 4 + 1, 3),
-    (4000, 1152, 2304, 42 * 4 + 1, 2),  # 256x128
-    (130, 128, 64, 42 * 4 + 0, 1),
     # ping-pong kernel (k_gemm_pp): two wave groups one barrier interval apart.  SCHED 1 (60: 128x288, 62: 128x128) and the k-split
-    # SCHED 2 (61 / 64: 128x144 ring 4 / 3, 63: 64x128, 65: 128x128); every K-tile count from 1 up (prologue, steady and drain paths, odd /
+    # SCHED 2 (61: 128x144 ring 4); every K-tile count from 1 up (prologue, steady and drain paths, odd /
     # even tile counts of the two groups), ragged M / N, uneven K splits; + 16000: bf16 slabs through LDS
     (1000, 1152, 1152, 60 * 4 + 0, 1),
     (130, 288, 64, 60 * 4 + 0, 1),             # single K tile
@@ -94,20 +82,7 @@ def t_(a, dev='cuda:0'):
     (500, 300, 256, 61 * 4 + 1, 1),            # four K tiles
     (500, 300, 320, 61 * 4 + 1, 1),            # five
     (1000, 1152, 1152, 61 * 4 + 1, 3),         # six per slice
-    (1000, 1152, 1152, 64 * 4 + 1, 2),
-    (77, 144, 192, 64 * 4 + 0, 1),
-    (200, 288, 128, 64 * 4 + 0, 1),
-    (130, 144, 64, 64 * 4 + 0, 1),
-    (1000, 1152, 1152, 63 * 4 + 0, 1),
-    (100, 128, 64, 63 * 4 + 0, 1),
-    (100, 200, 128, 63 * 4 + 0, 1),
-    (100, 200, 192, 63 * 4 + 1, 1),
-    (1000, 1152, 4608, 63 * 4 + 1, 2),
-    (1000, 1152, 448, 63 * 4 + 1, 1),          # seven K tiles
-    (1000, 1152, 1152, 65 * 4 + 1, 3),
-    (300, 256, 64, 65 * 4 + 0, 1),
-    (300, 256, 320, 16000 + 65 * 4 + 1, 1),
-    # K-split-inside-the-workgroup kernel (k_gemm_ks; 70: 48x96, 71: 64x64, 72: 32x96, 73: 48x64, 75: 32x128): K chunk counts below, at and
+    # K-split-inside-the-workgroup kernel (k_gemm_ks; 70: 48x96, 72: 32x96, 73: 48x64): K chunk counts below, at and
     # above the eight waves (idle waves, uneven shares), ragged M / N
     (1000, 1152, 1152, 70 * 4 + 0, 1),
     (1000, 1152, 4608, 70 * 4 + 0, 1),
@@ -117,20 +92,10 @@ def t_(a, dev='cuda:0'):
     (130, 96, 192, 70 * 4 + 0, 1),
     (50, 200, 576, 70 * 4 + 0, 1),             # nine chunks
     (4000, 1152, 1152, 70 * 4 + 0, 1),
-    (1000, 1152, 1152, 71 * 4 + 0, 1),
-    (100, 60, 320, 71 * 4 + 0, 1),
     (1000, 1152, 1152, 72 * 4 + 0, 1),
     (90, 100, 128, 72 * 4 + 0, 1),
     (1000, 1152, 1152, 73 * 4 + 0, 1),
     (90, 100, 640, 73 * 4 + 0, 1),
-    (1000, 1152, 1152, 75 * 4 + 0, 1),
-    (33, 132, 192, 75 * 4 + 0, 1),
-    (1000, 1152, 1152, 76 * 4 + 0, 1),         # two 32-wide chunks per wave in flight
-    (1000, 1152, 4608, 76 * 4 + 0, 1),
-    (77, 100, 64, 76 * 4 + 0, 1),
-    (50, 200, 192, 76 * 4 + 0, 1),             # six 32-wide chunks: two waves idle
-    (130, 96, 576, 77 * 4 + 0, 1),
-    (1000, 1024, 1024, 77 * 4 + 0, 1),
 ])
 def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     g = torch.Generator().manual_seed(M + N + K)
@@ -165,12 +130,24 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
     assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
 
 
-ZW = {61: 144, 70: 96, 71: 64, 72: 96, 73: 64, 75: 128, 76: 96, 77: 64}   # statistics part width = the producer's tile width
+ZW = {61: 144, 70: 96, 72: 96, 73: 64}   # statistics part width = the producer's tile width
 
 
-@pytest.mark.parametrize('tile,mode', [(61, 'gr'), (61, 'r'), (61, ''), (70, 'gr'), (70, 'r'), (70, ''), (71, 'gr'), (72, 'gr'), (73, 'r'), (75, 'gr'), (75, ''), (76, 'gr'), (76, ''), (77, 'r')])
+@pytest.mark.parametrize('tile,mode', [(61, 'gr'), (61, 'r'), (61, ''), (70, 'gr'), (70, 'r'), (70, ''), (72, 'gr'), (72, 'r'), (73, 'r')])
 @pytest.mark.parametrize('M,N,K', [(1000, 1152, 1152), (1000, 1152, 4608), (192, 144, 192), (192, 128, 128), (77, 576, 64), (500, 1024, 320), (1000, 1152, 2304)])
 def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K, tile, mode):
+    _resid_case(lib, dev, M, N, K, tile, mode)
+
+
+@pytest.mark.parametrize('tile', [61, 70])
+def test_residual_gemm_statistics_survive_a_row_mean_far_above_the_spread(lib, dev, tile):
+    """The statistics are the one-pass (sum, sum of squares) form: the relative error of the merged variance is eps_fp32 (1 + mu^2 / var) (common.h).
+    Rows whose mean is 50x their spread -- far beyond what the residual stream shows -- must still give a variance good to 1e-2 (measured ~1e-3)
+    and a mean good to 1e-5 relative (round-4 ADVICE)."""
+    _resid_case(lib, dev, 192, 1152, 128, tile, 'gr', hmean=50.0, var_rtol=1e-2, mean_atol=1e-3)
+
+
+def _resid_case(lib, dev, M, N, K, tile, mode, hmean=0.7, var_rtol=2e-5, mean_atol=2e-5):
     """Producer side of the LayerNorm algebra (EPI_RESID of the K-split-inside-the-workgroup kernel k_gemm_ks, tiles 70+, and of the ping-pong
     kernel's 128 x 144 tile, 61, the producer for batched prompts):
     h_new = h + gate * (A W^T + b) in fp32 (mode 'gr'; 'r': no gate; '': no residual either -- skip_linear), its per-column-tile
@@ -182,7 +159,7 @@ def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K, tile, mode):
     W = torch.zeros(Np, K, dtype=torch.bfloat16)
     W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
     bias, gate, zg = torch.randn(N, generator=g), torch.rand(N, generator=g), 1 + 0.3 * torch.randn(N, generator=g)
-    h_in = torch.randn(M, N, generator=g) + 0.7          # a row mean that is not small against the spread
+    h_in = torch.randn(M, N, generator=g) + hmean        # a row mean that is not small against the spread
     ref = A.float().double() @ W[:N].float().double().T + bias.double()
     if 'g' in mode:
         ref = gate.double() * ref
@@ -205,15 +182,15 @@ def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K, tile, mode):
     n = torch.tensor([min(cw, N - cw * p) for p in range(parts)], dtype=torch.float64)
     mean = st[:, :, 0].sum(1) / N                                  # part-wise (sum, sum of squares): the merge is two plain sums
     var = st[:, :, 1].sum(1) / N - mean ** 2
-    np.testing.assert_allclose(mean.numpy(), ref.mean(1).numpy(), rtol=0, atol=2e-5)
-    np.testing.assert_allclose(var.numpy(), ref.var(1, unbiased=False).numpy(), rtol=2e-5)
+    np.testing.assert_allclose(mean.numpy(), ref.mean(1).numpy(), rtol=0, atol=mean_atol)
+    np.testing.assert_allclose(var.numpy(), ref.var(1, unbiased=False).numpy(), rtol=var_rtol)
     del n
     want = (got * zg.double()).float()
     assert rel_l2(zu.float().cpu().numpy()[:, :N], want.numpy()) < 3e-3     # one bf16 rounding
     assert (zu.float().cpu()[:, N:] == 0).all()
 
 
-@pytest.mark.parametrize('tile', [6, 13, 40, 41, 42, 2013, 2040, 2041, 2042, 2060, 2061, 2062, 2063, 2064, 2065])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel
+@pytest.mark.parametrize('tile', [6, 13, 2013, 2060, 2061, 2062])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
@@ -307,7 +284,7 @@ def test_forward_matches_reference_golden(lib, dev, name):
         ref = g[f'pred_t{t}']
         assert np.isfinite(pred).all()
         r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
-        print(f'{name} t={t}: rel-L2 {r:.3e} max-abs {a:.3e}')
+        record(f'{name} t={t}: rel-L2 {r:.3e} max-abs {a:.3e}')
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, t, r, a)
 
 
@@ -333,7 +310,42 @@ def test_layernorm_algebra_and_split_k_paths_match_reference_golden(lib, dev, na
     assert n_z == n_base - (2 * nblk + cfg['depth'])      # attention-out and cross-out of every block, MLP-out in front of in / mid blocks, skip_linear of the out-blocks
     for what, p in (('zfuse', pred), ('split-K', base)):
         r, a = rel_l2(p, ref), float(np.abs(p - ref).max())
-        print(f'{name} t={t} {what}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {n_base} -> {n_z}')
+        record(f'{name} t={t} {what}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {n_base} -> {n_z}')
+        assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
+
+
+@pytest.mark.parametrize('size,n_valid,act', [('s', (9, 1), (0, 1)), ('s', (1, 9), (1, 2)), ('s64', (1, 1), (0, 0)), ('s', (9, 1, 5), None), ('s', (9, 4, 1, 1), (0, 2)),
+                                              ('xs', (1, 6, 20, 1), (1, 3))])
+def test_single_key_cross_attention_shortcut_matches_the_general_path(lib, dev, size, n_valid, act):
+    """Option xkey1 (default ON): a batch element whose context mask has ONE valid key gets its cross-attention block as the constant
+    W_o v_key + b_o, added by the attention-out projection (k_gemm_ks DUAL), and cross-attention + cross-out run over the remaining contiguous batch
+    range `act` only (None: the multi-key elements are not contiguous -> the general path runs, bitwise).  Judge: the numpy oracle (which does the
+    masked softmax like the reference); the general path (xkey1 = 0, every row through k_attn) must agree with the shortcut far inside the gate."""
+    from oracle.dit import DiTOracle
+    cfg = model_config(size)
+    sd = make_state_dict(cfg, 77)
+    B, L, Lc = len(n_valid), 100, 20
+    inp = make_inputs(cfg, B=B, L=L, Lc=Lc, n_valid=n_valid, seed=23)
+    m = get_model(size, 77)
+    ref, _ = DiTOracle(cfg, sd).forward(inp['x'], 499, inp['ctx'], inp['ctx_mask'])
+    outs, launches = {}, {}
+    try:
+        for v in (1, 0):
+            assert lib.ezdit_set_option(m._h, b'xkey1', v) == 0
+            outs[v] = _forward(m, inp, 499, {}).cpu().numpy()
+            launches[v] = m.last_launch_count
+    finally:
+        assert lib.ezdit_set_option(m._h, b'xkey1', 1) == 0
+    nblk = cfg['depth'] + 1
+    if act is None:
+        np.testing.assert_array_equal(outs[1], outs[0])
+        assert launches[1] == launches[0]
+    else:
+        assert launches[1] == launches[0] - (2 * nblk if act[0] == act[1] else 0)   # nothing left for cross-attention: both launches of every block go
+        assert rel_l2(outs[1], outs[0]) < 4e-3
+    for v in (1, 0):
+        r, a = rel_l2(outs[v], ref), float(np.abs(outs[v] - ref).max())
+        record(f'{size} n_valid={n_valid} xkey1={v}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {launches[v]}')
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
@@ -351,7 +363,7 @@ def test_forward_odd_lengths_against_oracle(lib, dev, size, L):
     ref, _ = o.forward(inp['x'], 499, inp['ctx'], inp['ctx_mask'])
     assert pred.shape == ref.shape == (2, cfg['out_chans'], L)
     r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
-    print(f'{size} L={L}: rel-L2 {r:.3e} max-abs {a:.3e}')
+    record(f'{size} L={L}: rel-L2 {r:.3e} max-abs {a:.3e}')
     assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
@@ -412,7 +424,7 @@ def test_sampler_matches_reference_loop_golden(lib, dev, name, tol):
     m = get_model(meta['size'], meta['seed_w'])
     lat = _run_sampler(m, inp, init, noises, meta).cpu().numpy()
     r = rel_l2(lat, g['latent'])
-    print(f'{name}: final-latent rel-L2 {r:.3e}')
+    record(f'{name}: final-latent rel-L2 {r:.3e}')
     assert np.isfinite(lat).all() and r < tol
 
 
@@ -483,7 +495,7 @@ def test_reference_style_loop_drives_the_operator(lib, dev):
         latents = sched.step(model_output=out, timestep=t, sample=latents, eta=eta, variance_noise=t_(noises[i])).prev_sample
     torch.cuda.synchronize()
     r = rel_l2(latents.cpu().numpy(), g['latent'])
-    print(f'reference-style loop on the drop-in operator: final-latent rel-L2 {r:.3e}')
+    record(f'reference-style loop on the drop-in operator: final-latent rel-L2 {r:.3e}')
     assert r < 2e-2
 
 
@@ -531,11 +543,12 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
-                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1))])
+                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1)),
+                                        ('fuse_q2', (1, 0)), ('q2_pp', (1, 0)), ('xkey1', (1, 0))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -548,7 +561,15 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
         assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
         outs.append(_forward(m, inp, 499, kw).cpu().numpy())
     assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0   # shipped defaults
-    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse'):   # placement / issue order / launch structure only: bitwise identical
+    if opt == 'q2_pp':   # only consulted when the q projection is not fused into k_attn
+        assert lib.ezdit_set_option(m._h, b'fuse_q2', 0) == 0
+        outs = []
+        for v in values:
+            assert lib.ezdit_set_option(m._h, opt.encode(), v) == 0
+            outs.append(_forward(m, inp, 499, kw).cpu().numpy())
+        assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0
+        assert lib.ezdit_set_option(m._h, b'fuse_q2', 1) == 0
+    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1'):   # placement / issue order / launch structure only: bitwise identical
         for o in outs[1:]:
             np.testing.assert_array_equal(outs[0], o)
     else:   # row_variant: same math, different rounding points; gemm_pp / tile_partial: another kernel (other MFMA shape, other fp32 summation order over K)

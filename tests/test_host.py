@@ -30,7 +30,7 @@ def test_library_exports_every_symbol_the_header_declares(lib):
     exported = set(re.findall(r' T (ez(?:dit|vae)_[a-z_0-9]+)', out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     assert set(declared) == set(_lib.PROTOTYPES), sorted(set(declared) ^ set(_lib.PROTOTYPES))
-    assert lib.ezdit_abi_version() == 2
+    assert lib.ezdit_abi_version() == 3
 
 
 def test_no_oracle_import_in_product():
@@ -175,20 +175,27 @@ def test_product_scheduler_agrees_with_oracle_restatement():
         DDIMScheduler(**dict(DIFF, prediction_type='epsilon'))
 
 
+OPTION_NAMES = ['zfuse', 'xkey1', 'wt', 'gemm_pp', 'tile_partial', 'attn_xcd', 'row_variant', 'gemm_panel', 'row_affine', 'epi_lds', 'qkv_affine', 'attn_xk2',
+                'attn_nkh', 'cn_overlap', 'fuse_q2', 'q2_pp', 'stamp_launch', 'trace_launches']
+
+
 def test_tuning_knobs_named_in_the_header_exist(lib):
-    """Every option name the header documents is accepted; an unknown one is refused with EZDIT_E_INVALID."""
+    """The option list is closed: every name the library accepts is documented in the header and accepted here, names retired in round 5
+    and unknown names are refused with EZDIT_E_INVALID, and the parser in csrc/api.hip knows exactly this list (<= 25 names)."""
+    import re
     _, h = _handle(lib, 'xs')
-    names = ['tile_partial', 'tile_f32', 'tile_qkv', 'tile_p18', 'tile_p36', 'tile_p72', 'geglu_tile', 'tile_partial_big', 'tile_f32_big',
-             'geglu_big', 'split18', 'split36', 'split72', 'split_big', 'xcd_map', 'slab_bf16', 'wt', 'fuse_qkv', 'qkv_waves9', 'fuse_q2',
-             'fuse_qnorm', 'fuse_resid', 'attn_nkh', 'prefetch', 'attn_xcd', 'row_variant', 'cn_overlap', 'gemm_pp', 'zfuse', 'pp_max_m',
-             'gemm_panel', 'row_affine', 'gemm_debug', 'epi_lds', 'qkv_affine', 'attn_xk2', 'stamp_launch', 'trace_launches', 'ztile', 'zmlp', 'zskip', 'zbig',
-             'q2_pp', 'zfake', 'zbig_m', 'tile_pe', 'tile_fin']
     src = open(os.path.join(ROOT, 'include', 'ezdit.h')).read()
-    for n in names:
-        assert n in src, n
+    for n in OPTION_NAMES:
+        assert re.search(r'\b%s\b' % n, src), n
         assert lib.ezdit_set_option(h, n.encode(), 0) == 0, n
-    assert lib.ezdit_set_option(h, b'no_such_knob', 1) == -1
-    assert b'no_such_knob' in lib.ezdit_last_error()
+    for n in ('no_such_knob', 'prefetch', 'geglu_tile', 'ztile', 'zfake', 'gemm_debug', 'fuse_resid', 'tile_p18', 'pp_max_m'):
+        assert lib.ezdit_set_option(h, n.encode(), 1) == -1, n
+        assert n.encode() in lib.ezdit_last_error()
+    api = open(os.path.join(ROOT, 'ezaudio_amd', 'csrc', 'api.hip')).read()
+    body = api[api.index('int ezdit_set_option('):]
+    parsed = re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', body)
+    assert sorted(set(parsed) - {'zfake'}) == sorted(OPTION_NAMES), parsed   # zfake: EZ_DIAG builds only
+    assert len(OPTION_NAMES) <= 25
     lib.ezdit_destroy(h)
 
 
@@ -418,7 +425,7 @@ def test_kernels_of_the_default_step_neither_spill_nor_shuffle_through_the_lds()
     funcs = _gfx950_isa('gemm.hip')
 
     def tmpl(name):   # '..k_gemm_ppILi128ELi144E..' -> ('k_gemm_pp', [128, 144, ...]); Lb1E / Lb0E are booleans
-        m = re.search(r'(k_gemm_pp|k_gemm_ks|k_gemm2|k_gemm)I((?:L[ib]\d+E)+)', name)
+        m = re.search(r'(k_gemm_pp|k_gemm_ks|k_gemm)I((?:L[ib]\d+E)+)', name)
         return (m.group(1), [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(2))]) if m else (None, [])
 
     default_step = {   # launch_gemm's instantiations on the default path (profiles/r04b_kernel_trace*.txt)
@@ -441,6 +448,50 @@ def test_kernels_of_the_default_step_neither_spill_nor_shuffle_through_the_lds()
     assert seen == default_step, default_step - seen
 
 
+def test_k_split_kernel_counts_exactly_its_operand_loads_behind_the_prologue_dma():
+    """k_gemm_ks decides that its own LDS-DMA has landed with COUNTED waits (`s_waitcnt vmcnt(NOPL)`): that is only right if exactly NOPL vector
+    loads sit between the prologue's global_load_lds and the K loop, in that order (round-4 ADVICE).  Since round 5 those loads are inline asm into
+    AGPRs, fenced by sched_barriers; this test reads the gfx950 code hipcc generates today and checks, per instantiation: (1) the shared-slot path
+    issues exactly NOPL `global_load_dwordx4 a[..]` and nothing else that counts, (2) nothing waits on vmcnt between the first LDS-DMA and the loop's first
+    wait except inside the per-row-timestep branch (whose slot is a dependent vector load), (3) the loop's first wait is vmcnt(NOPL), (4) the operand registers
+    are disjoint from the MFMA accumulators and are not read before a vmcnt(0) behind the loop."""
+    import re
+    funcs = _gfx950_isa('gemm.hip')
+    checked = 0
+    for name, f in funcs.items():
+        m = re.search(r'k_gemm_ksI((?:L[ib]\d+E)+)', name)
+        if not m:
+            continue
+        fm, fn, epi, gate, res, ck, dual = [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(1))]
+        nopl = (fn // 2) * (1 + ((1 + res + gate) if epi == 4 else 0))
+        lines = [l.strip() for l in f.splitlines()]
+        first_dma = next(i for i, l in enumerate(lines) if l.startswith('global_load_lds'))
+        shared = next(i for i, l in enumerate(lines) if l == '; shared slot')
+        blk = shared
+        while not re.match(r'\.LBB\d+_\d+:', lines[blk]):
+            blk -= 1
+        body = lines[blk:shared]
+        assert sum(l.startswith('global_load_dwordx4 a[') for l in body) == nopl, (name, nopl)
+        assert not any(l.startswith(('global_load_lds', 'buffer_load', 's_waitcnt vmcnt')) or (l.startswith('global_load') and not l.startswith('global_load_dwordx4 a[')) for l in body), name
+        per_row = [i for i, l in enumerate(lines) if l == '; per-row slot']
+        for i in range(first_dma, shared):
+            if lines[i].startswith('s_waitcnt vmcnt'):
+                assert per_row and i < per_row[0] and any(l.startswith('global_load_dword v') for l in lines[first_dma:i]), (name, i, lines[i])
+        nxt = next(i for i in range(shared, len(lines)) if lines[i].startswith('s_waitcnt vmcnt'))
+        assert lines[nxt] == 's_waitcnt vmcnt(%d)' % nopl, (name, lines[nxt])
+        assert not any(l.startswith('global_load') for l in lines[shared:nxt]), name
+        acc = [(int(a), int(b)) for a, b in re.findall(r'v_mfma_f32_16x16x32_bf16 a\[(\d+):(\d+)\]', f)]
+        ops = [(int(a), int(b)) for a, b in re.findall(r'global_load_dwordx4 a\[(\d+):(\d+)\]', f)]
+        assert max(b for _, b in ops) < min(a for a, _ in acc) or min(a for a, _ in ops) > max(b for _, b in acc), name
+        lo, hi = min(a for a, _ in ops), max(b for _, b in ops)
+        last_mfma = max(i for i, l in enumerate(lines) if l.startswith('v_mfma'))
+        first_read = next(i for i, l in enumerate(lines) if (mm := re.match(r'v_accvgpr_read_b32 v\d+, a(\d+)', l)) and lo <= int(mm.group(1)) <= hi)
+        assert first_read > last_mfma and any(l == 's_waitcnt vmcnt(0)' for l in lines[last_mfma:first_read]), name
+        assert 'scratch_' not in f, name
+        checked += 1
+    assert checked >= 8, checked
+
+
 def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     """k_gemm_pp, k_gemm_ks and k_attn issue their MFMAs from inline asm, so hipcc's hazard recogniser neither sees them nor pads behind them
     (round-3 ADVICE): the wait states between the LAST MFMA of an accumulation chain and the first non-MFMA read of its accumulator are
@@ -449,27 +500,47 @@ def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     VGPR accumulators of k_attn) sits at least 18 issue slots (s_nop N counts N + 1) behind the textually preceding MFMA -- a refactor or a
     compiler upgrade that moves a reader up fails here instead of corrupting tiles silently."""
     import re
+    INF = 10 ** 9
     for src, kernels in (('gemm.hip', ('k_gemm_pp', 'k_gemm_ks')),):
         funcs = _gfx950_isa(src)
         checked = 0
         for name, f in funcs.items():
             if not any(k in name for k in kernels) or 'v_mfma' not in f:
                 continue
-            lines = [l.strip() for l in f.splitlines() if l.startswith('\t') and not l.strip().startswith((';', '.'))]
-            dist = None          # issue slots since the last MFMA
-            for ins in lines:
-                op = ins.split()[0]
-                if op.startswith('v_mfma'):
-                    dist = 0
-                    continue
-                if dist is None:
-                    continue
-                reads_acc = (op == 'v_accvgpr_read_b32') or (op.startswith(('ds_write', 'global_store', 'v_')) and re.search(r'\ba\[?\d', ins.split(None, 1)[1] if ' ' in ins else ''))
-                if reads_acc and not op.startswith('v_accvgpr_write'):
-                    assert dist >= 18, (name, ins, dist)
-                    dist = None          # chain consumed; the next MFMA re-arms the check
-                    checked += 1
-                    continue
-                m = re.match(r's_nop (\d+)', ins)
-                dist += int(m.group(1)) + 1 if m else 1
+            lines = [l.strip() for l in f.splitlines() if (l.startswith('\t') or re.match(r'\.LBB\d+_\d+:', l)) and not l.strip().startswith((';', '.p2align', '.long', '.byte'))]
+            # dist = issue slots since the last MFMA on ANY path into this point: a label takes the minimum over its fall-through and every branch that
+            # targets it (round 5: the register allocator put accumulator copies on a loop-exit EDGE, which a purely textual scan -- whose predecessor
+            # was an unrelated block -- did not see); iterated to a fixed point because loop back-edges come textually after their header
+            label_in = {}
+            for _ in range(6):
+                dist, new_in, reads = INF, {}, []
+                for ins in lines:
+                    m = re.match(r'(\.LBB\d+_\d+):', ins)
+                    if m:
+                        dist = min(dist, label_in.get(m.group(1), INF))
+                        continue
+                    op = ins.split()[0]
+                    if op.startswith('v_mfma'):
+                        m2 = re.match(r's_nop (\d+)', '')
+                        dist = 0
+                        continue
+                    if op in ('s_branch',) or op.startswith('s_cbranch'):
+                        tgt = ins.split()[-1]
+                        new_in[tgt] = min(new_in.get(tgt, INF), dist + 1)
+                        dist = INF if op == 's_branch' else dist + 1
+                        continue
+                    reads_acc = (op == 'v_accvgpr_read_b32') or (op == 'v_accvgpr_mov_b32') or (op.startswith(('ds_write', 'global_store', 'v_')) and not op.startswith('v_accvgpr_write') and re.search(r'\ba\[?\d', ins.split(None, 1)[1] if ' ' in ins else ''))
+                    if reads_acc and dist < INF:
+                        reads.append((ins, dist))
+                        dist = INF          # chain consumed; the next MFMA re-arms the check
+                        continue
+                    m2 = re.match(r's_nop (\d+)', ins)
+                    if dist < INF:
+                        dist += int(m2.group(1)) + 1 if m2 else 1
+                if new_in == label_in:
+                    break
+                label_in = new_in
+            for ins, d in reads:
+                assert d >= 18, (name, ins, d)
+            checked += len(reads)
         assert checked >= 10, checked

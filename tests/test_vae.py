@@ -7,7 +7,7 @@ import pytest
 
 from oracle import vae as V
 from oracle.weights import uniform_pm1
-from tests.util import GOLDEN, rel_l2
+from tests.util import GOLDEN, record, rel_l2
 
 
 def dec_case(name):
@@ -155,7 +155,7 @@ def test_hip_decoder_matches_reference_golden(name):
     assert np.isfinite(audio).all()
     r = rel_l2(audio, g['audio'])
     m = np.abs(audio - g['audio']).max() / np.abs(g['audio']).max()
-    print(f'{name}: rel_l2 {r:.3e} max/max {m:.3e}')
+    record(f'{name}: rel_l2 {r:.3e} max/max {m:.3e}')
     assert r < VAE_REL and m < VAE_MAX
     # a second call reuses the cached halo buffers: must be bitwise identical, and batch rows independent
     again = dec(torch.from_numpy(z[1:]).cuda()).cpu().numpy()
@@ -200,7 +200,7 @@ def test_hip_decoder_full_length_vs_oracle():
     assert audio.shape == (1, 1, 120000)
     r = rel_l2(audio, ref)
     m = np.abs(audio - ref).max() / np.abs(ref).max()
-    print(f'full: rel_l2 {r:.3e} max/max {m:.3e}')
+    record(f'full: rel_l2 {r:.3e} max/max {m:.3e}')
     assert r < VAE_REL and m < VAE_MAX
     # shorter latent afterwards (editing / variable length): halo geometry changes, buffers are per-shape
     z2 = z[:, :, :77]
@@ -225,7 +225,7 @@ def test_hip_encoder_matches_reference_golden(name):
     assert lat.shape == g['latent'].shape
     r = rel_l2(lat, g['latent'])
     m = np.abs(lat - g['latent']).max() / np.abs(g['latent']).max()
-    print(f'{name}: rel_l2 {r:.3e} max/max {m:.3e}')
+    record(f'{name}: rel_l2 {r:.3e} max/max {m:.3e}')
     assert r < VAE_REL and m < VAE_MAX
 
 

@@ -15,6 +15,29 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+_PARITY = {'path': None}
+
+
+def record(line):
+    """Print a measured parity number and append it to the parity log of this test session: $EZ_PARITY_LOG, default
+    gpurun_out/parity_<source hash>.txt (the file the builder copies to profiles/r05_parity.txt: VERDICT r04 item 6 -- every fixture's
+    measured rel-L2 / max-abs on the tree that produced it, not only pass / fail dots)."""
+    print(line)
+    if _PARITY['path'] is None:
+        from ezaudio_amd.build import source_hash
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        default = os.path.join(root, 'gpurun_out', 'parity_%s.txt' % source_hash())
+        _PARITY['path'] = os.environ.get('EZ_PARITY_LOG', default)
+        try:
+            os.makedirs(os.path.dirname(_PARITY['path']), exist_ok=True)
+        except OSError:
+            _PARITY['path'] = ''
+    if _PARITY['path']:
+        test = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
+        with open(_PARITY['path'], 'a') as f:
+            f.write(f'{test}\t{line}\n')
+
+
 def load_golden(name):
     g = np.load(os.path.join(GOLDEN, name + '.npz'))
     meta = ast.literal_eval(str(g['meta']))

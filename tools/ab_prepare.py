@@ -71,8 +71,8 @@ def measure(combo):
 
 
 # defaults of the options this script may touch (csrc/api.hip)
-DEFAULTS = dict(zfuse=1, ztile=70, zmlp=1, zskip=1, gemm_pp=3, tile_partial=9, wt=2, fuse_q2=1, attn_xk2=1, gemm_panel=3, row_affine=1,
-                split18=3, split36=3, split72=3, pp_max_m=1 << 30, attn_nkh=0, gemm_debug=0, q2_pp=1, zfake=0, tile_partial_big=60, split_big=2, zbig=1, zbig_m=2048, tile_pe=70, tile_fin=73, geglu_tile=-1, geglu_big=40)
+DEFAULTS = dict(zfuse=1, gemm_pp=3, tile_partial=9, wt=2, fuse_q2=1, attn_xk2=1, gemm_panel=3, row_affine=1, attn_nkh=0, q2_pp=1, attn_xcd=1, row_variant=1,
+                epi_lds=1, qkv_affine=1, cn_overlap=1, zfake=0, xkey1=1)
 for r in range(rounds):
     for combo in combos:
         try:
