@@ -971,7 +971,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         u_is_z = true;
     };
     // single-key shortcut (opt_xkey1): cross-attention + its out-projection cover the batch elements [xb0, xb0 + xnb) only
-    const bool x1 = zf && h->opt_xkey1 && h->xkey1 && h->ztile() == ezdit_handle::kZTile;
+    const bool x1 = zf && h->opt_xkey1 && h->xkey1;
     const int xb0 = x1 ? h->act_b0 : 0, xnb = x1 ? h->act_b1 - h->act_b0 : h->B;
 
     // LN1 of block 0 on the patch embedding (ControlNet: x = patch_embed(x) + controlnet_pre(condition) first, :263-266)

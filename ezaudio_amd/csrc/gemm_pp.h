@@ -275,9 +275,11 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
 // of the NEXT GEMM, whose epilogue finishes the LayerNorm (GemmArgs.z*).  After the k-split exchange a wave holds 16 rows x ALL BN columns
 // of the tile (WN == 1): a row's statistics are an in-lane sum over FN fragments plus two xor-shuffles.  The per-column vectors (bias, gate,
 // LayerNorm gain) were parked in LDS behind the ring (`vec`: [3][BN]); the residual rows `r4` were requested right after the K loop.
-template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, bool GATE, bool RES>
+// DUAL (GemmArgs.zd, see k_gemm_ks): the rows outside [act_row0, act_row1) also get the constant cross-attention-out vector of their batch element
+// (`d4`, requested with the residual rows) and the gain of the GEGLU GEMM's LayerNorm (`vec` row 3) instead of the q projection's.
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, bool GATE, bool RES, bool DUAL>
 __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int lane, int tid,
-                                               const float* vec, const float4 (&r4)[FM][FN]) {
+                                               const float* vec, const float4 (&r4)[FM][FN], const float4 (&d4)[FM][FN]) {
     static_assert(TN == BN, "one wave holds whole tile rows");
     constexpr int PITCH = BN + 8;
     static_assert(BN % 8 == 0, "16-byte row chunks");
@@ -289,6 +291,7 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = row0 + wm * TM + i * 16 + m_in;
+        const bool alt = DUAL && (row < a.act_row0 || row >= a.act_row1);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -302,6 +305,7 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
                 x.x *= g4.x; x.y *= g4.y; x.z *= g4.z; x.w *= g4.w;
             }
             if constexpr (RES) { x.x += r4[i][j].x; x.y += r4[i][j].y; x.z += r4[i][j].z; x.w += r4[i][j].w; }
+            if constexpr (DUAL) { x.x += alt ? d4[i][j].x : 0.f; x.y += alt ? d4[i][j].y : 0.f; x.z += alt ? d4[i][j].z : 0.f; x.w += alt ? d4[i][j].w : 0.f; }
             if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
             s1 += (x.x + x.y) + (x.z + x.w);
             s2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, s2))));
@@ -309,7 +313,7 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
                 float* dst = out + (long)row * a.ldo + col;
                 if (a.wt) st16_wt(dst, x); else *reinterpret_cast<float4*>(dst) = x;
             }
-            const float4 z4 = *reinterpret_cast<const float4*>(vec + 2 * BN + cl);
+            const float4 z4 = *reinterpret_cast<const float4*>(vec + (alt ? 3 : 2) * BN + cl);
             pk[i][j].x = pack_bf2(x.x * z4.x, x.y * z4.y);
             pk[i][j].y = pack_bf2(x.z * z4.z, x.w * z4.w);
         }
@@ -529,7 +533,7 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
 // dynamic LDS of k_gemm_pp: ring | (mu, r) per row | per-column vectors | EPI_QKV: 256 bytes per wave that the RoPE-table warm-up DMA lands in
 template <int BM, int BN, int NS, int EPI>
 constexpr int pp_smem_bytes() {
-    return NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 3 : 2) * BN * 4 + (EPI == EPI_QKV ? 8 * 256 : 0);
+    return NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 4 : 2) * BN * 4 + (EPI == EPI_QKV ? 8 * 256 : 0);
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR>
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // with that tile (the counted wait that leaves only the YOUNGER tiles in flight) and turned into (mu, r) / parked in LDS behind the ring
     // (z_finish) in front of the barrier that opens the K loop: the first tile's wait is needed anyway, the requests overlap it, no register
     // rides through the loop and the epilogue needs no extra barrier (so the GEGLU math still overlaps the other group's last MFMA phase).  Ledger of the alternatives: profiles/r04_experiments.txt.
-    float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only); EPI_RESID: [3][BN] bias | gate | LayerNorm gain
+    float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only); EPI_RESID: [4][BN] bias | gate | LayerNorm gain | DUAL: the alternative gain
     ZStatRegs zst;
     float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool z_shared_slot = a.row_slot == nullptr;
@@ -592,7 +596,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // G' / C' live in the table of the CURRENT modulation slot: their address needs the device step counter (slot0, a scalar load issued at
     // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
     // of the first tile (it did: +1 us per consumer launch)
-    constexpr bool RGATE = EPI == EPI_RESID && (VAR & 64) != 0, RRES = EPI == EPI_RESID && (VAR & 128) != 0;
+    constexpr bool RGATE = EPI == EPI_RESID && (VAR & 64) != 0, RRES = EPI == EPI_RESID && (VAR & 128) != 0, RDUAL = EPI == EPI_RESID && (VAR & 256) != 0;
+    static_assert(!RDUAL || (RGATE && RRES), "DUAL: the gated residual projection only");
     auto z_late_load = [&]() {
         if constexpr (EPI == EPI_QKV) {
             // q / k tiles: the RoPE rows of the tile's 128 tokens (2 x 18 KB of the cos / sin tables) are read in the epilogue, by every workgroup
@@ -609,12 +614,13 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             }
         }
         if constexpr (EPI == EPI_RESID) {   // producer side: bias | gate | gain of the tile's columns, one float4 per thread (the modulation slot is shared: launch_gemm checks)
-            static_assert(3 * (BN / 4) <= NT, "one float4 per thread");
-            if (tid < 3 * (BN / 4)) {
+            static_assert(4 * (BN / 4) <= NT, "one float4 per thread");
+            if (tid < (RDUAL ? 4 : 3) * (BN / 4)) {
                 const int which = tid / (BN / 4), t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
                 cp = cp < a.N - 4 ? cp : a.N - 4;
-                const float* src = which == 0 ? a.bias : which == 1 ? (RGATE ? a.gate + (long)slot0 * a.gate_slot_stride : a.bias) : a.zg + (long)slot0 * a.zg_slot_stride;
+                const float* src = which == 0 ? a.bias : which == 1 ? (RGATE ? a.gate + (long)slot0 * a.gate_slot_stride : a.bias) : which == 2 ? a.zg + (long)slot0 * a.zg_slot_stride
+                                   : (RDUAL ? a.zg2 + (long)slot0 * a.zg2_slot_stride : a.bias);
                 zgc_reg = *reinterpret_cast<const float4*>(src + cp);
             }
         }
@@ -635,7 +641,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     };
     auto z_finish = [&]() {   // behind a wait for the loads of z_late_load; the caller puts a workgroup barrier between this and the first reader
         if constexpr (EPI == EPI_RESID) {
-            if (tid < 3 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
+            if (tid < (RDUAL ? 4 : 3) * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
         }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
             if (tid < 4 * BM) {
@@ -898,18 +904,21 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     if constexpr (SCHED == 2) {
         // EPI_RESID: the residual rows this wave finishes after the exchange (16 rows x the tile's columns) are requested NOW and land under the exchange
         constexpr int RF = EPI == EPI_RESID ? FM / 2 : 1, RN = EPI == EPI_RESID ? FN : 1;
-        float4 rres[RF][RN];
+        float4 rres[RF][RN], dres[RDUAL ? RF : 1][RDUAL ? RN : 1];
         if constexpr (RRES) {
             const int m_in = lane & 15, cg = lane >> 4;
 #pragma unroll
             for (int i = 0; i < RF; ++i) {
                 int row = row0 + (wm * 2 + grp) * (TM / 2) + i * 16 + m_in;
                 row = row < a.M ? row : a.M - 1;
+                const float* dsrc = nullptr;
+                if constexpr (RDUAL) dsrc = a.zd + (long)(int)(((float)row + 0.5f) * __builtin_amdgcn_rcpf((float)a.rows_per_b)) * a.zd_stride;   // row / rows_per_b
 #pragma unroll
                 for (int j = 0; j < RN; ++j) {
                     int col = col0 + wn * TN + j * 16 + 4 * cg;
                     col = col < a.N - 4 ? col : a.N - 4;
                     rres[i][j] = *reinterpret_cast<const float4*>(a.resid + (long)row * a.ldr + col);
+                    if constexpr (RDUAL) dres[i][j] = *reinterpret_cast<const float4*>(dsrc + col);
                 }
             }
         }
@@ -951,7 +960,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         if constexpr (EPI == EPI_RESID) {
             static_assert(WN == 1, "EPI_RESID: a wave holds whole tile rows after the exchange");
             static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "A' tile must fit the ring");
-            pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres);
+            if constexpr (RDUAL) pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES, true>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres, dres);
+            else pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES, false>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres, rres);
         }
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");

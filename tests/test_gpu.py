@@ -314,9 +314,11 @@ def test_layernorm_algebra_and_split_k_paths_match_reference_golden(lib, dev, na
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
-@pytest.mark.parametrize('size,n_valid,act', [('s', (9, 1), (0, 1)), ('s', (1, 9), (1, 2)), ('s64', (1, 1), (0, 0)), ('s', (9, 1, 5), None), ('s', (9, 4, 1, 1), (0, 2)),
-                                              ('xs', (1, 6, 20, 1), (1, 3))])
-def test_single_key_cross_attention_shortcut_matches_the_general_path(lib, dev, size, n_valid, act):
+@pytest.mark.parametrize('size,n_valid,act,L', [('s', (9, 1), (0, 1), 100), ('s', (1, 9), (1, 2), 100), ('s64', (1, 1), (0, 0), 100), ('s', (9, 1, 5), None, 100), ('s', (9, 4, 1, 1), (0, 2), 100),
+                                                ('xs', (1, 6, 20, 1), (1, 3), 100),
+                                                # > 2048 token rows: the ping-pong kernel's 128 x 144 producer in its DUAL form (BASELINE config #4's layout: P cond rows, then P uncond rows)
+                                                ('s', (12, 20, 5, 17, 1, 1, 1, 1), (0, 4), 300), ('s64', (1, 1, 1, 9, 4, 20, 7, 2), (3, 8), 290), ('s', (9, 1, 5, 1, 1, 1, 7, 1), None, 300)])
+def test_single_key_cross_attention_shortcut_matches_the_general_path(lib, dev, size, n_valid, act, L):
     """Option xkey1 (default ON): a batch element whose context mask has ONE valid key gets its cross-attention block as the constant
     W_o v_key + b_o, added by the attention-out projection (k_gemm_ks DUAL), and cross-attention + cross-out run over the remaining contiguous batch
     range `act` only (None: the multi-key elements are not contiguous -> the general path runs, bitwise).  Judge: the numpy oracle (which does the
@@ -324,7 +326,7 @@ def test_single_key_cross_attention_shortcut_matches_the_general_path(lib, dev, 
     from oracle.dit import DiTOracle
     cfg = model_config(size)
     sd = make_state_dict(cfg, 77)
-    B, L, Lc = len(n_valid), 100, 20
+    B, Lc = len(n_valid), 20
     inp = make_inputs(cfg, B=B, L=L, Lc=Lc, n_valid=n_valid, seed=23)
     m = get_model(size, 77)
     ref, _ = DiTOracle(cfg, sd).forward(inp['x'], 499, inp['ctx'], inp['ctx_mask'])
@@ -345,7 +347,7 @@ def test_single_key_cross_attention_shortcut_matches_the_general_path(lib, dev, 
         assert rel_l2(outs[1], outs[0]) < 4e-3
     for v in (1, 0):
         r, a = rel_l2(outs[v], ref), float(np.abs(outs[v] - ref).max())
-        record(f'{size} n_valid={n_valid} xkey1={v}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {launches[v]}')
+        record(f'{size} L={L} n_valid={n_valid} xkey1={v}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {launches[v]}')
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
