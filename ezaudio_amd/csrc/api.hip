@@ -138,11 +138,12 @@ struct ezdit_handle {
         return ((opt_gemm_pp & 2) && D % (2 * dh) == 0) ? 2 : (D % (4 * dh) == 0 ? 1 : 0);
     }
     // the cross-attention kernel computes its own q projection (8-wave form: small grids, or forced by fuse_q2 = 2)
-    bool q2_fused() const { return opt_fuse_q2 && ((long)B * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0; }
+    // (nb = batch elements the cross-attention launch covers: with the single-key shortcut only the multi-key ones)
+    bool q2_fused(int nb) const { return opt_fuse_q2 && ((long)nb * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0; }
     // the LayerNorm-algebra path can run for the bound shape under the current options (its tables are built by ezdit_prepare_timesteps only then)
     bool zfuse_usable() const {
         // the cross-attention q projection must be one of the two LayerNorm-algebra consumers: fused into k_attn (small grids) or the ping-pong GEMM with the q epilogue
-        return opt_zfuse && (D + zwidth() - 1) / zwidth() <= Z_MAXP && (opt_gemm_pp & 1) && qkv_mode() == 2 && (q2_fused() || opt_q2_pp);
+        return opt_zfuse && (D + zwidth() - 1) / zwidth() <= Z_MAXP && (opt_gemm_pp & 1) && qkv_mode() == 2 && (q2_fused(B) || opt_q2_pp);
     }
     int ztile() const { return (M > kZBigM && !per_row) ? 61 : kZTile; }   // producer of the LayerNorm algebra for the bound shape (the ping-pong producer shares one modulation slot per launch)
     int zwidth() const { return ztile() == 61 ? 144 : 96; }   // statistics part = the producer's tile width
@@ -1038,7 +1039,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         STOPCHK();
         // one prompt: the cross-attention kernel also computes its own q = LN_head(u . Wq^T) (8-wave form, Lcp % 128 == 0)
         // (x1: over the batch elements [xb0, xb0 + xnb) only -- the others are single-key rows served by the attention-out projection above)
-        const bool fuse_q2 = h->q2_fused();
+        const bool fuse_q2 = h->q2_fused(xnb);   // four prompts per GPU with the shortcut: 4 x 16 x 8 = 512 workgroups -> fused (10.38 -> 10.22 ms per step of 4)
         const long xr0 = (long)xb0 * h->L;          // first row of the sub-range
         const int xM = xnb * h->L;
         if (xnb > 0) {

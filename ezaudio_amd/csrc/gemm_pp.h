@@ -64,6 +64,24 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// the same on a pair of values with packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: two IEEE operations per lane and issue slot; the two
+// reciprocals and the two exponentials stay scalar -- the transcendental unit has no packed form): the GEGLU epilogue evaluates 72 GELUs per
+// lane, ~16 VALU instructions each in the scalar form, on the two waves that share a SIMD (in-situ stamps: 6.3K of the 10K-cycle epilogue)
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 z = __builtin_elementwise_abs(x) * f32x2{0.70710678118654752440f, 0.70710678118654752440f};
+    const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2 p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    const f32x2 a = (z * f32x2{-1.4426950408889634f, -1.4426950408889634f}) * z;
+    const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+    const f32x2 erf_abs = __builtin_elementwise_fma(-(p * t), e, f32x2{1.0f, 1.0f});
+    const f32x2 s = {copysignf(erf_abs[0], x[0]), copysignf(erf_abs[1], x[1])};
+    return (x * f32x2{0.5f, 0.5f}) * (s + f32x2{1.0f, 1.0f});
+}
+
 // XCD-aware tile map shared by the GEMM kernels: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the
 // (M tiles x N tiles x K splits) grid, M tiles fastest inside.  Returns false for a padding slot of a ragged box.
 __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn, int& z) {
@@ -97,6 +115,14 @@ __device__ __forceinline__ void copy_out_bf16(const bf16_t* tile, int pitch, int
             }
         }
     }
+}
+
+// m / L and m % L for a token row m < 2^22 and a batch-element length 1 <= L <= 2048 without the ~40-instruction integer division (twice per
+// 16-byte chunk in the fused-QKV copy-out loops): the quotient of (m + 0.5) / L sits at least 0.5 / L away from an integer, far more than the
+// fp32 error of the product with the approximate reciprocal (<= 3 ulp of a value <= 240 x 2048 / L)
+__device__ __forceinline__ void divmod_rows(int m, int L, float rcpL, int& b, int& l) {
+    b = (int)(((float)m + 0.5f) * rcpL);
+    l = m - b * L;
 }
 
 // modulation slot of a row: the device step counter (slot0, read once per kernel) + the row's batch element offset (per-row timesteps only)
@@ -232,13 +258,16 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
                 mu = mr.x; r = mr.y;
             }
             const float rm = r * mu;
+            const f32x2 r2 = {r, r}, nrm2 = {-rm, -rm};
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const float x0 = fmaf(r, acc[i][j][0], fmaf(-rm, g4[j].x, c4[j].x)), x1 = fmaf(r, acc[i][j][1], fmaf(-rm, g4[j].y, c4[j].y));
-                const float x2 = fmaf(r, acc[i][j][2], fmaf(-rm, g4[j].z, c4[j].z)), x3 = fmaf(r, acc[i][j][3], fmaf(-rm, g4[j].w, c4[j].w));
-                const auto e0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x0), __float_as_uint(x2), false, false);
-                const auto e1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x1), __float_as_uint(x3), false, false);
-                pk[i][j] = pack_bf2(__uint_as_float(e0[0]) * gelu_erf(__uint_as_float(e0[1])), __uint_as_float(e1[0]) * gelu_erf(__uint_as_float(e1[1])));
+                // packed fp32: (x0, x1) and (x2, x3) in one FMA each (the same two IEEE roundings per element as fmaf(r, acc, fmaf(-rm, g, c)))
+                const f32x2 x01 = __builtin_elementwise_fma(r2, f32x2{acc[i][j][0], acc[i][j][1]}, __builtin_elementwise_fma(nrm2, f32x2{g4[j].x, g4[j].y}, f32x2{c4[j].x, c4[j].y}));
+                const f32x2 x23 = __builtin_elementwise_fma(r2, f32x2{acc[i][j][2], acc[i][j][3]}, __builtin_elementwise_fma(nrm2, f32x2{g4[j].z, g4[j].w}, f32x2{c4[j].z, c4[j].w}));
+                const auto e0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x01[0]), __float_as_uint(x23[0]), false, false);
+                const auto e1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x01[1]), __float_as_uint(x23[1]), false, false);
+                const f32x2 o = f32x2{__uint_as_float(e0[0]), __uint_as_float(e1[0])} * gelu_erf2(f32x2{__uint_as_float(e0[1]), __uint_as_float(e1[1])});
+                pk[i][j] = pack_bf2(o[0], o[1]);
             }
         }
     }
@@ -384,6 +413,7 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
         }
     }
     const HeadNormArgs& hn = a.hn;
+    const float rcpL = __builtin_amdgcn_rcpf((float)hn.L);
     const int D = hn.H * DH;
     const int part = col0 / D;                 // 0 q, 1 k, 2 v
     const int head0 = (col0 % D) / DH;         // first head of this tile
@@ -425,7 +455,8 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
         // (a conditional load between a request and its use has the same effect on the vmcnt bookkeeping)
         auto rope_rows = [&](int k) {
             const int m = row0 + ((tid + k * NT) >> 2) / NH;
-            const int l = (m < a.M ? m : a.M - 1) % hn.L;
+            int b_, l;
+            divmod_rows(m < a.M ? m : a.M - 1, hn.L, rcpL, b_, l);
             const float* w = part == 0 ? hn.qn_w : hn.kn_w;
             const float2* c2 = reinterpret_cast<const float2*>((rope ? hn.rope_cos + (long)l * (DH / 2) : w) + (sub & 1) * E);
             const float2* s2 = reinterpret_cast<const float2*>((rope ? hn.rope_sin + (long)l * (DH / 2) : w) + (sub & 1) * E);
@@ -487,7 +518,8 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
             const int c8 = q % CP, hh = (q / CP) % NH, r = q / (CP * NH);
             const int m = row0 + r;
             if (m < a.M) {
-                const int b = m / hn.L, l = m % hn.L;
+                int b, l;
+                divmod_rows(m, hn.L, rcpL, b, l);
                 bf16_t* dst = dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + c8 * 8;
                 const uint4 v = *reinterpret_cast<const uint4*>(qk_st + (r * NH + hh) * DH + c8 * 8);
                 if (a.wt) st16_wt(dst, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
@@ -504,7 +536,8 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
                 const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * DH + d
                 const int m = row0 + r;
                 if (m < a.M) {
-                    const int b = m / hn.L, l = m % hn.L;
+                    int b, l;
+                    divmod_rows(m, hn.L, rcpL, b, l);
                     const int hh = cc / DH, d = cc % DH;
                     bf16_t* dst = hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l;
                     const uint32_t v = pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
@@ -516,7 +549,8 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
                 const int r = it % BM, cc = it / BM;
                 const int m = row0 + r;
                 if (m < a.M) {
-                    const int b = m / hn.L, l = m % hn.L;
+                    int b, l;
+                    divmod_rows(m, hn.L, rcpL, b, l);
                     const int hh = cc / DH, d = cc % DH;
                     hn.vt[(((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l] = f2bf(tile[r * PITCH + cc]);
                 }
@@ -608,7 +642,9 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
                 const int r = tid >> 2, which = tid & 3;
                 int m = row0 + r;
                 m = m < a.M ? m : a.M - 1;
-                const char* src = reinterpret_cast<const char*>((which & 2) ? hn.rope_sin : hn.rope_cos) + ((long)(m % hn.L) * (hn.dh / 2) + ((which & 1) ? hn.dh / 2 - 1 : 0)) * 4;
+                int b_, l_;
+                divmod_rows(m, hn.L, __builtin_amdgcn_rcpf((float)hn.L), b_, l_);
+                const char* src = reinterpret_cast<const char*>((which & 2) ? hn.rope_sin : hn.rope_cos) + ((long)l_ * (hn.dh / 2) + ((which & 1) ? hn.dh / 2 - 1 : 0)) * 4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(smem + NS * STAGE + BM * 8 + 2 * BN * 4 + wave * 256), 4, 0, 0);
             }
