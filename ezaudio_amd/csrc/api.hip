@@ -958,6 +958,9 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         memset(&g, 0, sizeof g);
         g.A = A + r0 * lda; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
         g.out = h_out + r0 * D; g.ldo = D; g.M = Ms; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->ztile();
+        // few rows (the cross-attention-out projection over one prompt's conditional rows, M = 500): 48-row tiles leave 11 x 12 = 132 workgroups for 256 CUs;
+        // 32 x 96 tiles (id 72) give 16 x 12 = 192 with 11 % fewer operand bytes each: 3.968 -> 3.951 ms per step, bit-identical (profiles/r05_experiments.txt)
+        if (g.tile == ezdit_handle::kZTile && dual_blk < 0 && Ms <= 672 && g.K <= 2 * D) g.tile = 72;
         g.xcd_map = 1; g.wt = h->wt();
         g.resid = h_in ? h_in + r0 * D : nullptr; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot ? row_slot + eb0 : nullptr; g.rows_per_b = h->L;

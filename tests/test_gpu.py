@@ -133,7 +133,7 @@ def test_gemm_against_fp32_matmul(lib, dev, M, N, K, variant, splitk):
 ZW = {61: 144, 70: 96, 72: 96, 73: 64}   # statistics part width = the producer's tile width
 
 
-@pytest.mark.parametrize('tile,mode', [(61, 'gr'), (61, 'r'), (61, ''), (70, 'gr'), (70, 'r'), (70, ''), (72, 'gr'), (72, 'r'), (73, 'r')])
+@pytest.mark.parametrize('tile,mode', [(61, 'gr'), (61, 'r'), (61, ''), (70, 'gr'), (70, 'r'), (70, ''), (72, 'gr'), (72, 'r'), (72, ''), (73, 'r')])
 @pytest.mark.parametrize('M,N,K', [(1000, 1152, 1152), (1000, 1152, 4608), (192, 144, 192), (192, 128, 128), (77, 576, 64), (500, 1024, 320), (1000, 1152, 2304)])
 def test_residual_gemm_with_layernorm_statistics(lib, dev, M, N, K, tile, mode):
     _resid_case(lib, dev, M, N, K, tile, mode)
