@@ -421,7 +421,10 @@ def main():
                             'mode': 'prompt-sharded replicas, one all-gather of the finished latents; no collective in the step loop'},
             'roofline': {'bound': 'mfma', 'kernel': 'whole denoising step (all kernels of the DiT forward + CFG/DDIM)',
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
-                         'flops_per_step': fl, 'event_ms_per_step': ev_ms / a.steps, 'traffic': None},
+                         'flops_per_step': fl, 'event_ms_per_step': ev_ms / a.steps, 'traffic': None,
+                         'flops_note': 'algorithmic FLOPs of the FULL step: NOT reduced for the exact single-key shortcut (the unconditional rows have one valid context key, '
+                                       'so their cross-attention + out-projection is the constant W_o v + b_o added by the attention-out projection; the cross-attention q projection, '
+                                       'attention and out-projection of those rows -- 2 L D^2 + 2 L Lc D of the 18 L D^2 + ... MACs per block and unconditional row, 5.4 % of flops_per_step -- are not executed)'},
         }
         if a.size == 'xl' and P == 1 and not a.controlnet and L == 500:
             mt = measured_traffic()

@@ -18,6 +18,8 @@ SOURCES = ['gemm.hip', 'attn.hip', 'rowops.hip', 'api.hip', 'vae.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 if os.environ.get('EZAUDIO_ABLATE'):   # timing-only variants of the ping-pong K loop (VAR bits 8 / 16 / 32 of k_gemm_pp, tools/microbench/gemm_bench.cpp); never in the shipped build
     FLAGS.append('-DEZ_ABLATE')
+if os.environ.get('EZAUDIO_DIAG'):      # diagnostic build: the `zfake` option (LayerNorm-algebra consumers on neutral tables); never in the shipped build
+    FLAGS.append('-DEZ_DIAG')
 
 
 def source_hash():

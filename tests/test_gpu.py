@@ -369,6 +369,27 @@ def test_forward_odd_lengths_against_oracle(lib, dev, size, L):
     assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
 
 
+@pytest.mark.parametrize('heads,dh', [(3, 72), (5, 64)])
+def test_forward_with_an_odd_head_count_takes_the_unfused_qkv_path(lib, dev, heads, dh):
+    """No tile of the fused QKV GEMMs holds whole heads when the head count is odd (ping-pong: two heads per tile, lockstep: four): the step then
+    runs the fp32 q|k|v projection + k_headnorm and normalises the cross-attention q inside k_attn (qkv_mode 0 in csrc/api.hip) -- a path no shipped
+    config takes and that lost its option in round 5, so it gets its own fixture here.  Judge: the numpy oracle."""
+    from ezaudio_amd import MaskDiT
+    from oracle.dit import DiTOracle
+    cfg = dict(model_config('xs'), embed_dim=heads * dh, num_heads=heads)
+    sd = make_state_dict(cfg, 5)
+    inp = make_inputs(cfg, B=2, L=90, Lc=20, n_valid=(11, 1), seed=29)
+    m = MaskDiT(device='cuda:0', **cfg)
+    m.load_state_dict(sd)
+    pred = _forward(m, inp, 499, {}).cpu().numpy()
+    ref, _ = DiTOracle(cfg, sd).forward(inp['x'], 499, inp['ctx'], inp['ctx_mask'])
+    r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
+    record(f'odd heads H={heads} dh={dh}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {m.last_launch_count}')
+    assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
+    nblk = cfg['depth'] + 1
+    assert m.last_launch_count > nblk * 11   # the unfused path really ran: projection + head-norm launches on top of the split-K + row-kernel edges
+
+
 def test_forward_per_row_timesteps_and_determinism(lib, dev):
     cfg, sd, inp, kw, g, meta = golden_case('xs')
     m = get_model('xs', meta['seed_w'])
