@@ -283,6 +283,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
     // (the wait states between the last MFMA and the first read of an accumulator are inside the loop: see the last MFMA of a chunk)
 
+    ks_operands_wait<SL, EPI, GATE, RES>(op);   // (landed long ago whenever the wave had a second chunk: its vmcnt(0) covered them; here, in front of the DUAL requests below)
     // ---- park this wave's partial tile in its OWN slot (dead: its last chunk was read above and nothing is in flight): [BM][S4] 16-byte
     // slots, slot s of row r at s ^ (r & 7) -- the 8 lanes of a store group hold 8 different rows of one column slot
     {
@@ -295,23 +296,23 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
                 mine[r * S4 + (s ^ (r & 7))] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
     }
-    __syncthreads();
-    if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
-    if (!epi_thread) return;
-    ks_operands_wait<SL, EPI, GATE, RES>(op);   // (landed long ago whenever the wave had a second chunk: its vmcnt(0) covered them)
-    // DUAL: the constant cross-attention-out vector of this row's batch element, requested HERE -- behind the park (hipcc drains vmcnt in front of the
-    // first LDS write next to an LDS-DMA it cannot prove finished: requested in front of the park they were waited for at once) -- landing under the
-    // partial sums below; 252 workgroups read the same few KB: L2 hits
-    float4 dv[SL];
+    // DUAL: the constant cross-attention-out vector of this row's batch element, requested HERE by inline asm -- behind the park's LDS writes (hipcc drains
+    // vmcnt in front of the first LDS write next to an LDS-DMA it cannot prove finished) and in FRONT of the barrier: the vector is cold (each block's
+    // own, first touched here) and lands under the barrier and the partial sums; as plain C++ loads behind the barrier their miss sat in the epilogue
+    // (in-situ stamps r05e: DUAL epilogue 9.3K cycles against 6.3 ... 7.8K of the plain form)
+    f32x4 dv[SL];
     if constexpr (DUAL) {
         const float* dsrc = a.zd + (long)brow * a.zd_stride;
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             int col = col0 + 4 * ks_slot_of<SL>(q, ej);
             col = col < ncl ? col : ncl;
-            dv[q] = *reinterpret_cast<const float4*>(dsrc + col);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dv[q]) : "v"(dsrc + col) : "memory");
         }
     }
+    __syncthreads();
+    if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
+    if (!epi_thread) return;
 
     // ---- sum the eight partials in wave order (fixed: bit-reproducible) and finish the row segment
     float4 v[SL];
@@ -328,6 +329,10 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         v[q] = t;
     }
     float* out = reinterpret_cast<float*>(a.out);
+    if constexpr (DUAL) {   // the asm loads of dv have landed; ties the registers to the wait
+#pragma unroll
+        for (int q = 0; q < SL; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dv[q]));
+    }
     if constexpr (EPI == EPI_F32) {
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             if constexpr (GATE) { x.x *= op.g[q][0]; x.y *= op.g[q][1]; x.z *= op.g[q][2]; x.w *= op.g[q][3]; }
             if constexpr (RES) { x.x += op.r[q][0]; x.y += op.r[q][1]; x.z += op.r[q][2]; x.w += op.r[q][3]; }
             if constexpr (DUAL) {   // + the cross-attention block's constant output for this batch element (exactly 0 for the rows that run cross-attention)
-                x.x += alt ? dv[q].x : 0.f; x.y += alt ? dv[q].y : 0.f; x.z += alt ? dv[q].z : 0.f; x.w += alt ? dv[q].w : 0.f;
+                x.x += alt ? dv[q][0] : 0.f; x.y += alt ? dv[q][1] : 0.f; x.z += alt ? dv[q][2] : 0.f; x.w += alt ? dv[q][3] : 0.f;
             }
             v[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
             s1 += (v[q].x + v[q].y) + (v[q].z + v[q].w);

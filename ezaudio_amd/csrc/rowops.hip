@@ -278,12 +278,11 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs a) {
 }
 
 // out[b][co][l] = bias[co] + sum_{ci,k} w[co][ci][k] * y[b][l+k-1][ci]      (fp32 FMA: this is the model output)
-// workgroup = 8 frames x all C (<= 128) output channels of one batch element; thread = one output channel x 4 frames (round 5: 2 frames -- every
-// thread streams its 1.5 KB weight row from the L2, so frames per thread is what amortises it: 19.4 -> measured in profiles/r05*_kernel_trace.txt): its
-// weight row [C][3] is read with 16-byte loads (12 floats = 4 input channels x 3 taps per step), activations are LDS broadcasts (every lane
-// of a wave reads the same word).  Same accumulation order per output as before (ci ascending, taps 0..2): bit-identical.
+// workgroup = 4 frames x all C (<= 128) output channels of one batch element; thread = one output channel x 2 frames: its
+// weight row [C][3] is read with 16-byte loads (12 floats = 4 input channels x 3 taps per step), activations are LDS
+// broadcasts (every lane of a wave reads the same word).
 __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
-    constexpr int TL = 8, FT = 4;
+    constexpr int TL = 4;
     extern __shared__ float sy[];  // [(TL+2)][C]
     const int C = a.C;
     const int ltiles = (a.L + TL - 1) / TL;
@@ -295,11 +294,9 @@ __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
         sy[r * C + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
     }
     __syncthreads();
-    const int ll = (threadIdx.x >> 7) * FT;
+    const int ll = (threadIdx.x >> 7) * 2;
     for (int co = threadIdx.x & 127; co < C; co += 128) {
-    float acc[FT];
-#pragma unroll
-    for (int f = 0; f < FT; ++f) acc[f] = a.b[co];
+    float acc0 = a.b[co], acc1 = acc0;
     const float* wr = a.w + (long)co * C * 3;
     const float* s0 = sy + ll * C;
     // 4 steps of the weight row in flight at once (same accumulation order: the loop was one L2 round trip per 4 input channels, 32 in a row)
@@ -309,20 +306,14 @@ __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
         const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float y[FT + 2];
-#pragma unroll
-            for (int r = 0; r < FT + 2; ++r) y[r] = s0[r * C + ci + e];
-#pragma unroll
-            for (int f = 0; f < FT; ++f) {
-                acc[f] = fmaf(w[3 * e], y[f], acc[f]); acc[f] = fmaf(w[3 * e + 1], y[f + 1], acc[f]); acc[f] = fmaf(w[3 * e + 2], y[f + 2], acc[f]);
-            }
+            const float y0 = s0[ci + e], y1 = s0[C + ci + e], y2 = s0[2 * C + ci + e], y3 = s0[3 * C + ci + e];
+            acc0 = fmaf(w[3 * e], y0, acc0); acc0 = fmaf(w[3 * e + 1], y1, acc0); acc0 = fmaf(w[3 * e + 2], y2, acc0);
+            acc1 = fmaf(w[3 * e], y1, acc1); acc1 = fmaf(w[3 * e + 1], y2, acc1); acc1 = fmaf(w[3 * e + 2], y3, acc1);
         }
     }
-#pragma unroll
-    for (int f = 0; f < FT; ++f) {
-        const int l = l0 + ll + f;
-        if (l < a.L) a.out[((long)b * C + co) * a.L + l] = acc[f];
-    }
+    const int l = l0 + ll;
+    if (l < a.L) a.out[((long)b * C + co) * a.L + l] = acc0;
+    if (l + 1 < a.L) a.out[((long)b * C + co) * a.L + l + 1] = acc1;
     }
 }
 
@@ -563,8 +554,8 @@ void launch_assemble(const AssembleArgs& a, hipStream_t st) {
 }
 
 void launch_final_conv(const FinalConvArgs& a, hipStream_t st) {
-    const int ltiles = (a.L + 7) / 8;
-    const size_t sh = (size_t)10 * a.C * sizeof(float);
+    const int ltiles = (a.L + 3) / 4;
+    const size_t sh = (size_t)6 * a.C * sizeof(float);
     hipLaunchKernelGGL(k_final_conv, dim3(a.B * ltiles), dim3(256), sh, st, a);
 }
 
