@@ -1,5 +1,8 @@
 #!/bin/bash
 # same-box A/B of the working tree against _base/ (one prompt x2, four prompts x1): bash scripts/r05_ab.sh <tag>
+# _base/ (git-ignored, travels with gpurun) is the library of the commit to compare against, built with
+#     rm -rf _base && mkdir _base && git archive HEAD ezaudio_amd tools/ab_prepare.py include | tar -x -C _base && (cd _base && python -m ezaudio_amd.build)
+# every line also prints |latents|: equal checksums on both sides = the change is bit-identical
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 for i in 1 2; do
