@@ -328,6 +328,9 @@ def test_single_key_cross_attention_shortcut_matches_the_general_path(lib, dev, 
     sd = make_state_dict(cfg, 77)
     B, Lc = len(n_valid), 20
     inp = make_inputs(cfg, B=B, L=L, Lc=Lc, n_valid=n_valid, seed=23)
+    for e, nv in enumerate(n_valid):   # the single valid key need not be key 0: move it to position 3 + e for every other single-key element
+        if nv == 1 and e % 2 == 1:
+            inp['ctx_mask'][e] = np.roll(inp['ctx_mask'][e], 3 + e)
     m = get_model(size, 77)
     ref, _ = DiTOracle(cfg, sd).forward(inp['x'], 499, inp['ctx'], inp['ctx_mask'])
     outs, launches = {}, {}
