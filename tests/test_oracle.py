@@ -117,3 +117,26 @@ def test_flops_formula_matches_survey():
     assert abs(flops_per_step(l, 2, 500, 100) / 1e12 - 1.057) < 2e-3
     n = sum(int(np.prod(s)) for k, (s, kind) in param_shapes(xl).items() if kind != 'inv_freq')
     assert abs(n / 1e6 - 874.76) < 0.01  # 874.76 M parameters
+
+
+def test_single_key_cross_attention_is_the_constant_the_shortcut_adds():
+    """The identity the product's `xkey1` shortcut rests on (csrc/api.hip), checked on the oracle that is pinned to the reference:
+    when a batch element's context mask has ONE valid key, the cross-attention module (attention.py:122-149 -- to_q / to_k / to_v, per-head LayerNorm, masked
+    softmax, proj) returns proj(v_key) for EVERY query row, whatever the queries are and wherever the key sits; with more valid keys it does not."""
+    cfg = model_config('xs')
+    from oracle.weights import make_inputs, make_state_dict
+    sd = make_state_dict(cfg, 3)
+    o = DiTOracle(cfg, sd, np.float64)
+    D, L, Lc = cfg['embed_dim'], 40, 20
+    inp = make_inputs(cfg, B=3, L=L, Lc=Lc, n_valid=(1, 1, 6), seed=5)
+    mask = inp['ctx_mask'].copy()
+    mask[1] = np.roll(mask[1], 7)                      # the single key of element 1 is key 7
+    ctx = o.context_embed(inp['ctx'].astype(np.float64))
+    x = uniform_pm1('q.x', 3 * L * D, 9).reshape(3, L, D).astype(np.float64) * 1.7
+    pfx = 'model.in_blocks.0.cross_attn'
+    out = o.attention(pfx, x, context=ctx, key_mask=mask)
+    wv, wo, bo = o.p(f'{pfx}.to_v.weight'), o.p(f'{pfx}.proj.weight'), o.p(f'{pfx}.proj.bias')
+    for b, key in ((0, 0), (1, 7)):
+        d = (ctx[b, key] @ wv.T) @ wo.T + bo           # W_o v_key + b_o
+        np.testing.assert_allclose(out[b], np.broadcast_to(d, (L, D)), rtol=0, atol=1e-12)
+    assert np.abs(out[2] - out[2][0:1]).max() > 1e-3   # six valid keys: the rows differ
