@@ -709,8 +709,11 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
     else HIPCHK(hipMemsetAsync(km, 1, Mc, c.st));
     // single-key batch elements (opt_xkey1): their cross-attention output is a constant.  The mask is read back once per call (B Lc bytes)
     std::vector<int> key1(h->B, -1);   // the valid key of a single-key batch element, -1 otherwise
+    const bool old_x1 = h->xkey1; const int old_b0 = h->act_b0, old_b1 = h->act_b1;
     h->xkey1 = false; h->act_b0 = 0; h->act_b1 = h->B;
-    if (mask) {
+    // (the read-back below synchronises the stream: ezdit_prepare_context is not a per-step entry point and must not be called inside a stream capture;
+    // it is skipped when its result could not be used -- the option must be set BEFORE this call)
+    if (mask && h->opt_xkey1 && h->zfuse_usable()) {
         std::vector<uint8_t> hm((size_t)Mc);
         HIPCHK(hipMemcpyAsync(hm.data(), mask, Mc, hipMemcpyDeviceToHost, c.st));
         HIPCHK(hipStreamSynchronize(c.st));
@@ -728,6 +731,12 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
             h->act_b0 = first < 0 ? 0 : first;
             h->act_b1 = first < 0 ? 0 : last + 1;
         }
+    }
+    // the captured step bakes (xkey1, act_b0, act_b1) into its launch structure (DUAL attention-out, cross-attention over a batch sub-range):
+    // a context with another single-key pattern must not replay the old graph -- nor may a backbone that captured this ControlNet's kernels
+    if (h->xkey1 != old_x1 || h->act_b0 != old_b0 || h->act_b1 != old_b1) {
+        drop_graph(h);
+        for (ezdit_handle* u : h->cn_users) drop_graph(u);
     }
     // context_embed: Linear -> SiLU -> Linear  (udit.py:94-97)
     launch_cast_bf16(ctx, h->Cctx, h->buf<bf16_t>("ctx_bf"), h->ldCtx, Mc, h->Cctx, 0, c.st);
@@ -761,11 +770,19 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
             // d[b] = W_o v_key + b_o for the single-key batch elements: v_key is row (b Lc + key) of the fp32 value projection above, rounded to bf16
             // as the attention kernel's V^T operand and output would be (P = 1 exactly), W_o the bf16 out-projection the step uses
             const WRef wo2 = h->wref(bn(b, "wo2"));
-            for (int e = 0; e < h->B; ++e) {
-                if (key1[e] < 0) continue;
-                launch_gemv_bf16w(h->buf<float>("ckv") + ((size_t)e * h->Lc + key1[e]) * 2 * D + D, 1, wo2.W, wo2.ld, h->w<float>(bn(b, "bo2")),
-                                  h->p.zd + ((size_t)b * h->B + e) * D, D, D, c.st);
-                c.launched("k_gemv_bf16w");
+            GemvBatch gb;
+            gb.x = h->buf<float>("ckv"); gb.y = h->p.zd + (size_t)b * h->B * D; gb.n = 0;
+            for (int e = 0; e <= h->B; ++e) {   // one launch per GEMV_MAXB single-key batch elements (one launch per block for every CFG batch up to 32 prompts)
+                if (e < h->B && key1[e] >= 0) {
+                    gb.xoff[gb.n] = ((long)e * h->Lc + key1[e]) * 2 * D + D;
+                    gb.yoff[gb.n] = (long)e * D;
+                    gb.n++;
+                }
+                if (gb.n == GEMV_MAXB || (e == h->B && gb.n > 0)) {
+                    launch_gemv_bf16w(gb, 1, wo2.W, wo2.ld, h->w<float>(bn(b, "bo2")), D, D, c.st);
+                    c.launched("k_gemv_bf16w");
+                    gb.n = 0;
+                }
             }
         }
     }

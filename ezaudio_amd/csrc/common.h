@@ -334,8 +334,11 @@ struct Conv1dArgs {  // out[b][co][lo] = act(bias[co] + sum_{ci,k} w[co][ci][k] 
 };
 void launch_conv1d(const Conv1dArgs& a, hipStream_t st);
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st);  // act 1 = silu
-// y[n] = bias[n] + sum_k x[k] W[n][k]   (x fp32, rounded to bf16 first when x_bf16 -- what an activation that went through a bf16 buffer would be; W bf16 [N][ldw]; once per call)
-void launch_gemv_bf16w(const float* x, int x_bf16, const bf16_t* W, int ldw, const float* bias, float* y, int N, int K, hipStream_t st);
+// y[yoff[i] + n] = bias[n] + sum_k x[xoff[i] + k] W[n][k] for i < n vectors in ONE launch (x fp32, rounded to bf16 first when x_bf16 -- what an activation
+// that went through a bf16 buffer would be; W bf16 [N][ldw]; once per call)
+constexpr int GEMV_MAXB = 32;
+struct GemvBatch { const float* x; float* y; int n; long xoff[GEMV_MAXB]; long yoff[GEMV_MAXB]; };
+void launch_gemv_bf16w(const GemvBatch& g, int x_bf16, const bf16_t* W, int ldw, const float* bias, int N, int K, hipStream_t st);
 // LayerNorm algebra tables (rowops.hip): (g, c) [n_slots][D] (stride slot_stride) -> bf16 rows (g hi, g lo, c hi, c lo) per slot, zero padded to ldo;
 // and back: zG[s][n] = tmp[4s][n] + tmp[4s+1][n], zC[s][n] = tmp[4s+2][n] + tmp[4s+3][n] (+ bias[n])
 void launch_z_hilo(const float* g, const float* c, long slot_stride, bf16_t* out, int ldo, int n_slots, int D, hipStream_t st);

@@ -613,11 +613,12 @@ void launch_z_combine(const float* tmp, int ld_tmp, const float* bias, float* zG
     hipLaunchKernelGGL(k_z_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, ld_tmp, bias, zG, zC, slot_stride, n_slots, N);
 }
 
-// one wave per output: y[n] = bias[n] + x . W[n]  (the constant cross-attention-out vector of a single-key batch element, ezdit_prepare_context)
-__global__ __launch_bounds__(256) void k_gemv_bf16w(const float* __restrict__ x, int x_bf16, const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias,
-                                                    float* __restrict__ y, int N, int K) {
+// one wave per output: y[i][n] = bias[n] + x[xrow[i]] . W[n]  (the constant cross-attention-out vectors of the single-key batch elements of ONE block,
+// ezdit_prepare_context: up to GEMV_MAXB of them per launch, blockIdx.y = i)
+__global__ __launch_bounds__(256) void k_gemv_bf16w(GemvBatch g, int x_bf16, const bf16_t* __restrict__ W, int ldw, const float* __restrict__ bias, int N, int K) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
+    const float* x = g.x + g.xoff[blockIdx.y];
     const bf16_t* w = W + (long)n * ldw;
     float acc = 0.f;
     for (int k = lane; k < K; k += 64) {
@@ -625,10 +626,11 @@ __global__ __launch_bounds__(256) void k_gemv_bf16w(const float* __restrict__ x,
         acc = fmaf(xv, bf2f(w[k]), acc);
     }
     acc = wave_sum(acc);
-    if (lane == 0) y[n] = acc + (bias ? bias[n] : 0.f);
+    if (lane == 0) g.y[g.yoff[blockIdx.y] + n] = acc + (bias ? bias[n] : 0.f);
 }
-void launch_gemv_bf16w(const float* x, int x_bf16, const bf16_t* W, int ldw, const float* bias, float* y, int N, int K, hipStream_t st) {
-    hipLaunchKernelGGL(k_gemv_bf16w, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, x, x_bf16, W, ldw, bias, y, N, K);
+void launch_gemv_bf16w(const GemvBatch& g, int x_bf16, const bf16_t* W, int ldw, const float* bias, int N, int K, hipStream_t st) {
+    if (g.n <= 0) return;
+    hipLaunchKernelGGL(k_gemv_bf16w, dim3((unsigned)((N + 3) / 4), (unsigned)g.n), dim3(256), 0, st, g, x_bf16, W, ldw, bias, N, K);
 }
 
 void launch_cast_bf16(const float* x, int ldx, bf16_t* out, int ldo, int M, int N, int act, hipStream_t st) {

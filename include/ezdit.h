@@ -10,8 +10,12 @@
  *   - every pointer marked `dev` is a DEVICE pointer owned by the caller; the library never
  *     allocates or frees persistent device memory.  Weights live in one caller-owned blob laid out
  *     by ezdit_param_info(); all activations / tables live in one caller-owned workspace.
- *   - every entry point that takes a stream is ASYNCHRONOUS on that stream: no device sync, no
- *     host read of device data (a sampler step is hipGraph-capturable).
+ *   - the PER-STEP entry points (ezdit_forward, ezdit_controlnet_forward, ezdit_sampler_run, ezdit_set_step,
+ *     ezdit_cfg_ddim_step, the ezvae_* ops) are ASYNCHRONOUS on their stream: no device sync, no host read of
+ *     device data (a sampler step is hipGraph-capturable).  The once-per-call SET-UP entry points synchronise the
+ *     stream and must not be called inside a stream capture: ezdit_bind_workspace (diagnostic builds only),
+ *     ezdit_prepare_context (reads the context mask back to find single-key batch elements when `xkey1` is on),
+ *     ezdit_prepare_timesteps and ezdit_sampler_begin (host staging buffers of the timestep / coefficient tables).
  *   - return 0 = OK, negative = error; ezdit_last_error() gives a thread-local message.  No C++
  *     exception crosses the ABI.
  *   - a handle is bound to the device that was current at ezdit_create() and is NOT thread-safe:

@@ -465,6 +465,44 @@ def test_sampler_graph_equals_eager_and_batch_equals_single(lib, dev):
         assert torch.equal(c[i:i + 1], a)   # samples never interact -> sharding-invariant, bitwise
 
 
+def test_context_with_another_single_key_pattern_drops_the_captured_step(lib, dev):
+    """the captured step bakes the single-key layout (DUAL attention-out rows, cross-attention batch sub-range) into its launch
+    structure.  A C-ABI caller that re-prepares the context with ANOTHER pattern -- here: cond | uncond swapped, so the single-key element moves from batch
+    row 1 to row 0 -- then rewinds with ezdit_set_step(0) and replays with use_graph = 1 must get the graph of the NEW pattern: bitwise the eager result."""
+    import ctypes as C
+    from ezaudio_amd import _lib
+    from ezaudio_amd.sampler import LatentSampler
+    from ezaudio_amd.scheduler import DDIMScheduler
+    cfg, sd, inp, init, noises, g, meta = sampler_case('smp_xs')
+    m = get_model('xs', meta['seed_w'])
+    smp = LatentSampler(m, DDIMScheduler(**DIFF))
+    steps = 4
+    text, tm = t_(inp['ctx'][0:1]), t_(inp['ctx_mask'][0:1])
+    un, um = t_(inp['ctx'][1:2]), t_(inp['ctx_mask'][1:2])
+    assert int(tm.sum()) > 1 and int(um.sum()) == 1
+    sn = torch.stack([t_(z) for z in noises[:steps]], 0)
+    st = C.c_void_p(smp.stream.cuda_stream)
+
+    def run(use_graph):
+        with torch.cuda.stream(smp.stream):
+            _lib.check(lib.ezdit_sampler_run(m._h, steps, 1 if use_graph else 0, st))
+        smp.stream.synchronize()
+        return smp.latents.clone()
+
+    smp.prepare(text, tm, un, um, t_(init), sn, 5.0, 0.75, steps, 1.0)
+    first = run(True)                                   # captures the step for the layout [multi-key | single-key]
+    outs = {}
+    for use_graph in (True, False):
+        with torch.cuda.stream(smp.stream):
+            m.prepare_context(torch.cat([un, text], 0), torch.cat([um, tm], 0))   # [single-key | multi-key]: no sampler_begin in between
+            _lib.check(lib.ezdit_set_step(m._h, 0, st))
+        smp.latents.copy_(t_(init))
+        outs[use_graph] = run(use_graph)
+    assert torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[True], outs[False])
+    assert not torch.equal(outs[True], first)           # the swapped pair really is another computation
+
+
 def test_fused_cfg_ddim_step_against_oracle_loop(lib, dev):
     """Drive OUR denoiser from the oracle's restatement of the reference loop (B2 surface) and compare with the
     fully fused device loop: isolates CFG + rescale + DDIM (fp32 on both sides)."""
