@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libezaudio_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class EzditConfig(C.Structure):
@@ -32,7 +32,7 @@ class EzditDdimCoef(C.Structure):
 
 
 P_F32, P_BF16 = 0, 1
-T_NONE, T_GEGLU8 = 0, 1
+T_NONE, T_GEGLU8, T_QKROPE = 0, 1, 2
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 PROTOTYPES = {

@@ -52,8 +52,8 @@ struct BlkW {   // per-block parameters used on the per-step path (no string / m
 };
 struct WsPtrs {  // workspace regions used on the per-step path, resolved once at ezdit_bind_workspace
     int* ints; float *rope_cos, *rope_sin, *coef, *cfgpart;
-    bf16_t* ape; float *h, *skips; bf16_t *u, *ucat; float* qkv; bf16_t *q, *k, *vt, *ao, *act; float *part, *y, *pred;
-    uint8_t* kmask; bf16_t *kc, *vct; float *mod, *modf;
+    bf16_t* ape; float *h, *skips; bf16_t *u, *ucat; float* qkv; bf16_t *q, *k, *v, *ao, *act; float *part, *y, *pred;
+    uint8_t* kmask; bf16_t *kc, *vc; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
     float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
     float* zd;   // [nblk][B][D] constant cross-attention-out vectors of the single-key batch elements (opt_xkey1)
@@ -111,7 +111,7 @@ struct ezdit_handle {
     // (one round of 256 workgroups at M = 4000) and k_gemm_ks's 48 x 96 tile (id 70) up to there
     static constexpr int kTilePartialBig = 60, kSplitBig = 2, kZTile = 70, kZBigM = 2048;
     int opt_tile_partial = 9;   // split-K residual GEMMs at M <= 2048: 9 = lockstep 128 x 128 (k_gemm), 62 = the same tile on the ping-pong kernel
-    int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp): bit 0 GEGLU GEMM (128x288), bit 1 fused QKV GEMM (128 x two heads, k-split); 0 = the round-1/2 lockstep kernels
+    int opt_gemm_pp = 3;   // ping-pong kernel (k_gemm_pp): bit 0 GEGLU GEMM (128x288; 0 = the round-1 lockstep kernel and no LayerNorm algebra); bit 1 retired in round 6 (the fused QKV GEMM always runs on it)
     // LayerNorm algebra (common.h, GemmArgs.z*): the attention-out, cross-attention-out, skip_linear and (in front of an in / mid block) MLP-out
     // projections run UN-SPLIT (k_gemm_ks, gemm_ks.h: 48 x 96 tiles, 252 workgroups at M = 1000; the ping-pong kernel's 128 x 144 tile above 2048 rows) with
     // the gated residual, per-column-tile LayerNorm statistics and the next GEMM's operand bf16(h g) in their epilogue; the consumer (fused QKV
@@ -119,6 +119,13 @@ struct ezdit_handle {
     // of the 102 row-kernel launches of an XL step less (239 launches instead of 325), the same algebra as the reference (goldens pass at the
     // same gates).  Needs gemm_pp bits 0 and 1 and a LayerNorm-algebra q projection; otherwise the step falls back to split-K slabs + the row kernel.
     int opt_zfuse = 1;
+    // GEGLU GEMM on the co-resident kernel (k_gemm_co, gemm_co.h: 4-wave workgroups with a 128 x 144 tile, TWO per CU, so that a workgroup's prologue and
+    // epilogue run under its neighbour's K loop): 0 = never, 1 = above kCoM rows (batched prompts: the ping-pong kernel runs 4 rounds of workgroups there), 2 = always
+    int opt_geglu_co = 0;
+    int opt_qkv_co = 0;   // the same choice for the fused QKV GEMM (no k-split exchange in the 4-wave form)
+    int qkv_tile() const { return (opt_qkv_co == 2 || (opt_qkv_co == 1 && M > kCoM)) ? 66 : 61; }
+    static constexpr int kCoM = 2048;
+    int geglu_tile() const { return !(opt_gemm_pp & 1) ? 13 : (opt_geglu_co == 2 || (opt_geglu_co == 1 && M > kCoM)) ? 66 : 60; }
     // Single-key cross-attention shortcut (needs the LayerNorm-algebra path).  Softmax over ONE valid key is exactly 1, so for a batch element whose
     // context mask has a single valid key -- every unconditional row of classifier-free guidance: the T5 encoding of "" is one EOS token
     // (src/inference.py:44-50, attention.py:131-135) -- cross-attention returns v_key for every query and the cross-attention block adds the
@@ -132,11 +139,11 @@ struct ezdit_handle {
 #ifdef EZ_DIAG
     int opt_zfake = 0;   // DIAGNOSTIC build only: the consumers run their LayerNorm-algebra variant on a FINISHED LayerNorm with neutral statistics (mean 0, variance 1, G' = 0, C' = bias): what the consumer side costs by itself
 #endif
-    // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
-    // (odd head counts: fp32 projection + k_headnorm)
-    int qkv_mode() const {
-        return ((opt_gemm_pp & 2) && D % (2 * dh) == 0) ? 2 : (D % (4 * dh) == 0 ? 1 : 0);
-    }
+    // fused QKV GEMM (per-head LayerNorm + RoPE + the attention layouts in the epilogue, all in registers): 2 = ping-pong kernel (tiles of two whole heads),
+    // 0 = no (odd head counts: fp32 projection + k_headnorm).  Static since round 6: the q / k rows of `wqkv` are PACKED in the RoPE-pair order the
+    // register epilogue needs (EZDIT_T_QKROPE) whenever two heads tile the projection, so no option can route such a model to the unfused path.
+    bool qk_perm() const { return D % (2 * dh) == 0; }
+    int qkv_mode() const { return qk_perm() ? 2 : 0; }
     // the cross-attention kernel computes its own q projection (8-wave form: small grids, or forced by fuse_q2 = 2)
     // (nb = batch elements the cross-attention launch covers: with the single-key shortcut only the multi-key ones)
     bool q2_fused(int nb) const { return opt_fuse_q2 && ((long)nb * H * ((L + 63) / 64) <= 512 || opt_fuse_q2 == 2) && Lcp % 128 == 0; }
@@ -165,7 +172,6 @@ struct ezdit_handle {
     // chunks: in the MFMA C layout a lane owns one row, so a direct store instruction scatters 4-8 bytes into 32-64 different lines.
     // Bit-identical; XL 4.384 -> 4.281 ms/step (+2.4 %), L +1.8 % for the GEGLU / slab part alone.
     int opt_epi_lds = 1;
-    int opt_qkv_affine = 1;   // fused QKV GEMM: every tile on the XCD whose attention workgroups read it (single prompt: B * H / 4 == 8); +0.2 ... 0.5 %
     // cross-attention q projection: two K tiles per ring slot, barrier and counted wait (a wave's work per K tile is 3 MFMAs: the loop is its
     // fixed cost per iteration).  Bit-identical; XL 4.319 -> 4.285 ms/step (+0.8 %), L +1.1 %.
     int opt_attn_xk2 = 1;
@@ -317,7 +323,7 @@ void build_params(ezdit_handle* h) {
             add_param(h, bn(b, "wskip"), {p + ".skip_linear.weight"}, Bf, D, 2 * D);
             add_param(h, bn(b, "bskip"), {p + ".skip_linear.bias"}, F, 1, D);
         }
-        add_param(h, bn(b, "wqkv"), {p + ".attn.to_q.weight", p + ".attn.to_k.weight", p + ".attn.to_v.weight"}, Bf, 3 * D, D);
+        add_param(h, bn(b, "wqkv"), {p + ".attn.to_q.weight", p + ".attn.to_k.weight", p + ".attn.to_v.weight"}, Bf, 3 * D, D, h->qk_perm() ? EZDIT_T_QKROPE : EZDIT_T_NONE);
         add_param(h, bn(b, "wo"), {p + ".attn.proj.weight"}, Bf, D, D);
         add_param(h, bn(b, "wq2"), {p + ".cross_attn.to_q.weight"}, Bf, D, D);
         add_param(h, bn(b, "wo2"), {p + ".cross_attn.proj.weight"}, Bf, D, D);
@@ -373,7 +379,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("qkv", Mp * 3 * D * 4);
     add("q", (size_t)B * H * Lp * h->DQK * 2);
     add("k", (size_t)B * H * Lp * h->DQK * 2);
-    add("vt", (size_t)B * H * h->DV * Lp * 2);
+    add("v", (size_t)B * H * Lp * h->DV * 2);
     add("ao", Mp * h->ldD * 2);
     add("act", Mp * h->ldI * 2);
     add("part", (size_t)8 * Mp * D * 4);
@@ -388,7 +394,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("cu", Mcp * h->ldD * 2);
     add("ckv", Mcp * 2 * D * 4);
     add("kc", (size_t)nblk * B * H * Lcp * h->DQK * 2);
-    add("vct", (size_t)nblk * B * H * h->DV * Lcp * 2);
+    add("vc", (size_t)nblk * B * H * Lcp * h->DV * 2);
     // time path
     const long ns = n_slots > 0 ? n_slots : 1;
     add("ts", ns * 4);
@@ -476,10 +482,10 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     g.wt = h->wt();
     g.epi_lds = h->opt_epi_lds;
     g.rows_per_b = 1;
-    if (c.hn) { g.hn = *c.hn; c.hn = nullptr; g.xcd_qkv = h->opt_qkv_affine && h->opt_attn_xcd; }
+    if (c.hn) { g.hn = *c.hn; c.hn = nullptr; }
     if (c.panel) { g.xcd_panel = 1; c.panel = false; }
 #ifdef EZ_DIAG
-    if (!c.zG && h->opt_zfake && (epi == EPI_QKV || epi == EPI_GEGLU) && (tile == 60 || tile == 61) && (h->D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
+    if (!c.zG && h->opt_zfake && (epi == EPI_QKV || epi == EPI_GEGLU) && (tile == 60 || tile == 61 || tile == 66) && (h->D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
         g.zw = h->zwidth(); g.zstat_in = h->buf<float2>("zneutral"); g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D;
         g.zG = h->buf<float>("zzeros"); g.zC = bias ? bias : g.zG; g.zt_slot_stride = 0; g.zeps = 1e-5f; g.rows_per_b = h->L;
     }
@@ -552,9 +558,9 @@ void resolve_workspace(ezdit_handle* h) {
     p.ints = h->buf<int>("ints"); p.rope_cos = h->buf<float>("rope_cos"); p.rope_sin = h->buf<float>("rope_sin");
     p.coef = h->buf<float>("coef"); p.cfgpart = h->buf<float>("cfgpart");
     p.ape = h->buf<bf16_t>("ape"); p.h = h->buf<float>("h"); p.skips = h->buf<float>("skips"); p.u = h->buf<bf16_t>("u"); p.ucat = h->buf<bf16_t>("ucat");
-    p.qkv = h->buf<float>("qkv"); p.q = h->buf<bf16_t>("q"); p.k = h->buf<bf16_t>("k"); p.vt = h->buf<bf16_t>("vt");
+    p.qkv = h->buf<float>("qkv"); p.q = h->buf<bf16_t>("q"); p.k = h->buf<bf16_t>("k"); p.v = h->buf<bf16_t>("v");
     p.ao = h->buf<bf16_t>("ao"); p.act = h->buf<bf16_t>("act"); p.part = h->buf<float>("part"); p.y = h->buf<float>("y");
-    p.pred = h->buf<float>("pred"); p.kmask = h->buf<uint8_t>("kmask"); p.kc = h->buf<bf16_t>("kc"); p.vct = h->buf<bf16_t>("vct");
+    p.pred = h->buf<float>("pred"); p.kmask = h->buf<uint8_t>("kmask"); p.kc = h->buf<bf16_t>("kc"); p.vc = h->buf<bf16_t>("vc");
     p.mod = h->buf<float>("mod"); p.modf = h->buf<float>("modf");
     p.zd = h->buf<float>("zd");
     p.zstat = h->buf<float2>("zstat"); p.zt_qkv = h->buf<float>("zt_qkv"); p.zt_geglu = h->buf<float>("zt_geglu"); p.zt_q2 = h->buf<float>("zt_q2");
@@ -762,7 +768,7 @@ int ezdit_prepare_context(ezdit_handle* h, const float* ctx, const uint8_t* mask
         hn.q_col = -1; hn.k_col = 0; hn.v_col = D;
         hn.kn_w = h->w<float>(bn(b, "c.knw")); hn.kn_b = h->w<float>(bn(b, "c.knb"));
         hn.k = h->buf<bf16_t>("kc") + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
-        hn.vt = h->buf<bf16_t>("vct") + (size_t)b * h->B * h->H * h->DV * h->Lcp;
+        hn.v = h->buf<bf16_t>("vc") + (size_t)b * h->B * h->H * h->Lcp * h->DV;
         hn.B = h->B; hn.H = h->H; hn.L = h->Lc; hn.Lp = h->Lcp; hn.dh = h->dh;
         launch_headnorm(hn, c.st);
         c.launched("k_headnorm");
@@ -963,8 +969,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     auto modv = [&](int blk, int which) { return mod + ((long)blk * 6 + which) * D; };
     // LayerNorm algebra (opt_zfuse): un-split residual projection whose epilogue produces h_new, its partial LayerNorm statistics and
     // A' = bf16(h_new * zg) for the next GEMM; the consumer finishes the LayerNorm.  u_is_z tells the next consumer what `u` holds.
-    // fused QKV GEMM (head-norm + RoPE + V^T in the epilogue): 2 = ping-pong kernel (tiles of two whole heads), 1 = lockstep kernel (four), 0 = no
-    const int qkv_mode = h->qkv_mode();
+    const int qkv_mode = h->qkv_mode();   // 2: fused QKV GEMM (ping-pong kernel), 0: fp32 projection + k_headnorm
     const bool zf = h->z_tables_ready && h->zfuse_usable();
     // eb0 / enb: the launch covers the batch elements [eb0, eb0 + enb) only (enb < 0: all); dual_blk >= 0: DUAL form for block dual_blk (GemmArgs.zd)
     auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
@@ -1025,13 +1030,14 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         hn.qn_w = w.aqnw; hn.qn_b = w.aqnb;
         hn.kn_w = w.aknw; hn.kn_b = w.aknb;
         hn.rope_cos = p.rope_cos; hn.rope_sin = p.rope_sin;
-        hn.q = p.q; hn.k = p.k; hn.vt = p.vt;
+        hn.q = p.q; hn.k = p.k; hn.v = p.v;
         hn.B = h->B; hn.H = h->H; hn.L = h->L; hn.Lp = h->Lp; hn.dh = h->dh;
         if (qkv_mode) {
-            // head-norm + RoPE + V^T inside the projection GEMM (64 x 4-head tiles): no fp32 q|k|v round trip, one launch less
+            // head-norm + RoPE + the attention layouts inside the projection GEMM (128 x two-head tiles): no fp32 q|k|v round trip, one launch less
+            hn.perm = 1;   // (qkv_mode == 2 <=> the weights were packed with EZDIT_T_QKROPE)
             c.hn = &hn;
             if (u_is_z) { c.zG = p.zt_qkv + (long)b * 2 * 3 * D; c.zC = c.zG + 3 * D; c.zt_stride = (long)nblk * 2 * 3 * D; }
-            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, qkv_mode == 2 ? 61 : 1);   // lockstep form: 1 x 9 waves (head_dim 72)
+            gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, h->qkv_tile());
         } else {
             gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32, tile_for(h, M, false));
             STOPCHK();
@@ -1040,7 +1046,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         }
         AttnArgs at;
         memset(&at, 0, sizeof at);
-        at.q = hn.q; at.k = hn.k; at.vt = hn.vt; at.kmask = nullptr;
+        at.q = hn.q; at.k = hn.k; at.v = hn.v; at.kmask = nullptr;
         at.nkh = h->opt_attn_nkh; at.xcd_map = h->opt_attn_xcd; at.wt = h->wt();
         at.out = p.ao; at.ldo = h->ldD;
         at.B = h->B; at.H = h->H; at.Lq = h->L; at.Lk = h->L; at.Lqp = h->Lp; at.Lkp = h->Lp; at.dh = h->dh;
@@ -1099,7 +1105,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             }
             at.q = p.q;
             at.k = p.kc + (size_t)b * h->B * h->H * h->Lcp * h->DQK;
-            at.vt = p.vct + (size_t)b * h->B * h->H * h->DV * h->Lcp;
+            at.v = p.vc + (size_t)b * h->B * h->H * h->Lcp * h->DV;
             at.kmask = p.kmask;
             at.Lk = h->Lc; at.Lkp = h->Lcp;
             STOPCHK();
@@ -1117,8 +1123,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         // ---- GEGLU MLP (blocks.py:154-156) ----
         STOPCHK();
         if (u_is_z) { c.zG = p.zt_geglu + (long)b * 2 * 2 * h->I; c.zC = c.zG + 2 * h->I; c.zt_stride = (long)nblk * 2 * 2 * h->I; }
-        gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU,
-             (h->opt_gemm_pp & 1) ? 60 : 13);   // 128 x 288: ping-pong kernel / round-1 lockstep kernel
+        gemm(c, u, h->ldD, w.w1, w.b1, p.act, h->ldI, M, 2 * h->I, EPI_GEGLU, h->geglu_tile());   // 128 x 288 ping-pong kernel / 128 x 144 co-resident kernel / round-1 lockstep kernel
         STOPCHK();
         // x += (1 - gate_mlp) * (mlp + bias); the LN that follows belongs to the NEXT consumer
         const float* b2 = w.b2;
@@ -1444,12 +1449,12 @@ int ezdit_test_resid(int tile, const void* A, int lda, const void* W, int ldw, c
     return EZDIT_OK;
 }
 
-int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const void* vt, const uint8_t* kmask, void* out, int B,
+int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const void* v, const uint8_t* kmask, void* out, int B,
                          int Lq, int Lk, int Lqp, int Lkp, ezdit_stream stream) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");
     AttnArgs a;
     memset(&a, 0, sizeof a);
-    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.kmask = kmask;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.kmask = kmask;
     a.nkh = h->opt_attn_nkh; a.xcd_map = h->opt_attn_xcd;
     a.out = (bf16_t*)out; a.ldo = h->ldD;
     a.B = B; a.H = h->H; a.Lq = Lq; a.Lk = Lk; a.Lqp = Lqp; a.Lkp = Lkp; a.dh = h->dh;
@@ -1480,6 +1485,8 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     if (!h || !name) return fail(EZDIT_E_INVALID, "null argument");
     if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
     else if (!strcmp(name, "xkey1")) h->opt_xkey1 = value;
+    else if (!strcmp(name, "geglu_co")) h->opt_geglu_co = value;
+    else if (!strcmp(name, "qkv_co")) h->opt_qkv_co = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;
     else if (!strcmp(name, "gemm_pp")) h->opt_gemm_pp = value;
     else if (!strcmp(name, "tile_partial")) h->opt_tile_partial = value;
@@ -1488,7 +1495,6 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "gemm_panel")) h->opt_gemm_panel = value;
     else if (!strcmp(name, "row_affine")) h->opt_row_affine = value;
     else if (!strcmp(name, "epi_lds")) h->opt_epi_lds = value;
-    else if (!strcmp(name, "qkv_affine")) h->opt_qkv_affine = value;
     else if (!strcmp(name, "attn_xk2")) h->opt_attn_xk2 = value;
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;

@@ -13,17 +13,23 @@
 //   * the output is accumulated transposed as well: O^T[d, q] = V^T . P^T, so the online-softmax rescale
 //     factor (per q) is lane-local for the accumulators, and P^T (B operand: lane = q, 8 keys per lane) is
 //     exactly the S^T registers converted to bf16 -- P never leaves registers.  The MFMA contraction order
-//     over keys is permuted accordingly (k-slot (hi, j) <-> key 16*step + 8*(j>>2) + 4*hi + (j&3)); the
-//     producer stores V TRANSPOSED ([dh][keys], keys contiguous) so the matching A fragment is two 8-byte reads.
+//     over keys is permuted accordingly (k-slot (hi, j) <-> key 16*step + 8*(j>>2) + 4*hi + (j&3)).  V is stored ROW-MAJOR
+//     ([keys][DV], as the projection produces it) and the matching A fragment -- 4 + 4 consecutive KEYS of one channel -- is two
+//     ds_read_b64_tr_b16 (gfx950's transposing LDS read: the 16 lanes of a group fetch a [4 keys][16 channels] block, 8 bytes each, and
+//     every lane receives one channel's column of it).  Round 6; before, the producer stored V^T and the fragment was two plain 8-byte reads
+//     (20-31 % of the LDS-active cycles were bank conflicts, and the QKV epilogue needed a transposing store path).
 //   * staging is register-prefetched (issue the global loads of tile t+1, compute tile t out of LDS, then
 //     write the registers to the other LDS buffer): one barrier per tile, HBM/L2 latency hidden behind the
-//     MFMAs + softmax of a whole tile.  LDS row strides are padded (K: +16 B, V^T: +8 B) so that the
-//     ds_read_b128 / ds_read_b64 fragment reads are bank-conflict free.
+//     MFMAs + softmax of a whole tile.  LDS row strides: K rows are padded by 16 B (conflict-free ds_read_b128); a V row is 192 B
+//     (= DV bf16 at head_dim 72; head_dim 64 pads 128 -> 192): the 4 key rows x 64 B a half-wave's transposing read touches then fall
+//     into the four quarters of the 64 banks.
 //   * head_dim 72 (EzAudio-XL) is zero padded to 80 for the QK^T contraction (5 k-steps of 16) and to 96
 //     output rows (3 tiles of 32) for P.V; head_dim 64 needs no padding.
 #include "common.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // reductions over the lane pair (lane, lane ^ 32) by one VALU v_permlane32_swap (hipcc lowers __shfl_xor(x, 32) to ds_bpermute_b32: an
 // LDS-pipe round trip of ~100+ cycles in the middle of the softmax dependency chain, twice per tile).  After swapping x with itself,
@@ -59,12 +65,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int NKS = DQK / 16;  // k-steps of the QK^T contraction
     constexpr int NDT = DV / 32;   // 32-row tiles of O^T
     constexpr int KSTR = DQK * 2 + 16;   // LDS row stride of a K row (bytes)
-    constexpr int VSTR = TK * 2 + 8;     // LDS row stride of a V^T row (TK keys)
-    constexpr int KBYTES = TK * KSTR, VBYTES = DV * VSTR;
+    constexpr int VSTR = 192;            // LDS row stride of a V row (DV channels; see header)
+    static_assert(DV * 2 <= VSTR, "V row");
+    constexpr int KBYTES = TK * KSTR, VBYTES = TK * VSTR;
     constexpr int BUF = KBYTES + VBYTES;
     constexpr int KCH = TK * DQK * 2 / 16;   // 16-byte chunks of a K tile (contiguous in global memory)
-    constexpr int VCPR = TK / 8;             // 16-byte chunks per V^T row
-    constexpr int VCH = DV * VCPR;           // 16-byte chunks of a V^T tile
+    constexpr int VCPR = DV / 8;             // 16-byte chunks per V row
+    constexpr int VCH = TK * VCPR;           // 16-byte chunks of a V tile (contiguous in global memory: rows are DV wide there)
     constexpr int KPT = (KCH + NT - 1) / NT, VPT = (VCH + NT - 1) / NT;
     static_assert(KPT <= 3 && VPT <= 3, "staging registers");
     // fused projection (NKH == 4): 3-deep ring of [64 rows of x | DN rows of W] K tiles, then 4 partial [64][DS] fp32 tiles
@@ -90,21 +97,22 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     int qt, h, b;
     if (a.xcd_map) {
         const int xcd = blockIdx.x & 7, sl = blockIdx.x >> 3;
-        const int pair = xcd * a.ppx + sl / a.nq;
-        qt = sl % a.nq;
+        const int sq = ez_div(sl, a.mnq);   // (division-free: common.h ez_div)
+        const int pair = xcd * a.ppx + sq;
+        qt = sl - sq * a.nq;
         if (pair >= a.B * a.H) return;   // whole workgroup, before any barrier
-        b = pair / a.H; h = pair % a.H;
+        b = ez_div(pair, a.mH); h = pair - b * a.H;
     } else {
         qt = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
     }
     const int q0 = qt * 64 + qs * 32;
     const long bh = (long)b * a.H + h;
     unsigned long long* ts = (a.ts && tid < 64) ? a.ts + 8 * (long)blockIdx.x : nullptr;
-    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }   // [6], [7]: 100 MHz device-wide clock
+    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = ez_stamp_start(); }   // [6], [7]: 100 MHz device-wide clock
 
     const bf16_t* Q = a.q + (bh * a.Lqp + q0 + r32) * DQK + 8 * hi;
     const char* Kg = reinterpret_cast<const char*>(a.k + bh * a.Lkp * DQK);
-    const bf16_t* VTg = a.vt + bh * DV * (long)a.Lkp;
+    const bf16_t* Vg = a.v + bh * DV * (long)a.Lkp;
     const uint8_t* km = a.kmask ? a.kmask + (long)b * a.Lk : nullptr;
 
     bf16x8 qf[NKS];
@@ -332,17 +340,17 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
         ck = ck < KCH ? ck : KCH - 1;
         cv = cv < VCH ? cv : VCH - 1;
         koff[i] = (uint32_t)ck * 16u;
-        voff[i] = ((uint32_t)(cv / VCPR) * (uint32_t)a.Lkp + (uint32_t)(cv % VCPR) * 8u) * 2u;
+        voff[i] = (uint32_t)cv * 16u;
     }
     // buffer loads: descriptor (SGPRs, wave-uniform) + the per-thread 32-bit offset above + the tile offset as the scalar soffset -> no
     // per-tile address arithmetic at all
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Kg), 0, a.Lkp * DQK * 2, 0x00020000);
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(VTg), 0, DV * a.Lkp * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Vg), 0, DV * a.Lkp * 2, 0x00020000);
     auto kchunk = [&](int i, int key0) -> uint4 {
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(krs, (int)koff[i], key0 * DQK * 2, 0));
     };
     auto vchunk = [&](int i, int key0) -> uint4 {
-        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(vrs, (int)voff[i], key0 * 2, 0));
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(vrs, (int)voff[i], key0 * DV * 2, 0));
     };
     auto kstore = [&](int i, char* kb, const uint4& val) {
         const int c = tid + NT * i;
@@ -350,11 +358,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     };
     auto vstore = [&](int i, char* vb, const uint4& val) {
         const int c = tid + NT * i;
-        if (c < VCH) {
-            char* dst = vb + (c / VCPR) * VSTR + (c % VCPR) * 16;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
-            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(val.z, val.w);
-        }
+        if (c < VCH) *reinterpret_cast<uint4*>(vb + (c / VCPR) * VSTR + (c % VCPR) * 16) = val;
     };
 #define LOAD_TILE(t)                                   \
     do {                                               \
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
         if (t + 1 < ntiles) LOAD_TILE(t + 1);
         const char* kb = smem + (t & 1) * BUF;
         const char* vb = kb + KBYTES;
+        const char* vtr = vb + (32 * kh + 4 * hi + ((lane & 15) >> 2)) * VSTR + ((lane & 16) + 4 * (lane & 3)) * 2;   // this lane's corner of the transposing reads
         const int key0 = t * TK + kh * 32;
         if (key0 < a.Lk) {  // wave-uniform: the whole 32-key sub-tile may lie beyond Lk
             // validity of this wave's 32 keys as one bit mask (bit j <-> key0 + j), built BEFORE the MFMAs
@@ -487,11 +492,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf2(p[8 * step + 2 * e], p[8 * step + 2 * e + 1]);
 #pragma unroll
                 for (int tt = 0; tt < NDT; ++tt) {
-                    // A fragment: V^T[32tt + r32][keys 32kh + 16step + 4hi + {0..3}] and [... + 8 + {0..3}]
-                    const char* vp = vb + (32 * tt + r32) * VSTR + (32 * kh + 16 * step + 4 * hi) * 2;
-                    union { bf16x8 v; uint2 h2[2]; } vf;
-                    vf.h2[0] = *reinterpret_cast<const uint2*>(vp);
-                    vf.h2[1] = *reinterpret_cast<const uint2*>(vp + 16);
+                    // A fragment: V[keys 32kh + 16step + 4hi + {0..3} and ... + 8 + {0..3}][channel 32tt + r32], gathered by two transposing reads: the 16 lanes
+                    // of a group (same hi, same half of the 32 channels) address the [4 keys][16 channels] block row by row -- lane i of the group: key i >> 2,
+                    // channels 4 (i & 3) .. + 3 -- and lane i receives channel i of all four keys (measured layout: tools/microbench/tr_probe.hip)
+                    const char* vp = vtr + (16 * step) * VSTR + 64 * tt;
+                    union { bf16x8 v; s16x4 h2[2]; } vf;
+                    vf.h2[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+                    vf.h2[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 8 * VSTR));
                     // register classes by constraint: O^T (and S^T above) in VGPRs -- the rescale and the softmax are VALU code, which cannot
                     // address AGPRs; with the builtin hipcc parked O^T in AGPRs and copied all 16 NDT values out and back every tile.  The staging
                     // registers and part of the Q fragments end up in the AGPR half (hipcc's choice under the 128-VGPR cap)
@@ -573,7 +580,7 @@ int launch_attention(const AttnArgs& a0, hipStream_t st) {
         const long b0 = a.b0;
         if (a.q) a.q += b0 * a.H * a.Lqp * DQK;
         if (a.k) a.k += b0 * a.H * a.Lkp * DQK;
-        if (a.vt) a.vt += b0 * a.H * DV * (long)a.Lkp;
+        if (a.v) a.v += b0 * a.H * DV * (long)a.Lkp;
         if (a.kmask) a.kmask += b0 * a.Lk;
         if (a.out) a.out += b0 * a.Lq * a.ldo;
         if (a.q_raw) a.q_raw += b0 * a.Lq * a.ld_qraw;
@@ -583,6 +590,7 @@ int launch_attention(const AttnArgs& a0, hipStream_t st) {
     }
     a.nq = (a.Lq + 63) / 64;
     a.ppx = (a.B * a.H + 7) / 8;
+    a.mnq = ez_magic(a.nq); a.mH = ez_magic(a.H);
     const long nwg = (long)a.nq * a.H * a.B;
     dim3 grid(a.nq, a.H, a.B);
     if (a.xcd_map) grid = dim3(8 * a.ppx * a.nq, 1, 1);

@@ -46,6 +46,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// test-hook stamp [6]: the 100 MHz device-wide clock at kernel start, tagged in its top 16 bits with the CU the workgroup runs on
+// (XCC_ID[3:0] << 8 | HW_ID[15:8] = SE / SH / CU): tools/microbench/gemm_bench.cpp rebuilds every CU's timeline from it (who shared a CU with whom, idle gaps between workgroups)
+__device__ __forceinline__ unsigned long long ez_stamp_start() {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    const unsigned long long id = ((unsigned long long)(xcc & 15u) << 8) | ((hw >> 8) & 255u);
+    return (__builtin_amdgcn_s_memrealtime() & 0xffffffffffffull) | (id << 48);
+}
+
+// Division of a small non-negative integer by a launch constant WITHOUT the ~35-instruction integer division (v_rcp_iflag + readfirstlane + two correction
+// steps, on the scalar unit of a prologue that has nothing else to do: the workgroup -> tile maps of the GEMM and attention kernels ran 4 - 8 of them in a
+// row, ~1K cycles in front of the first LDS-DMA of every launch).  The host passes m = ceil(2^32 / d) (0 for d = 1); x / d = mulhi(x, m) exactly while x d < 2^32.
+inline unsigned ez_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+__device__ __forceinline__ int ez_div(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
+
 int ez_fail(int code, const char* fmt, ...);   // api.hip: record the message behind ezdit_last_error(), return code
 
 // ------------------------------------------------------------------------------------------
@@ -156,8 +170,9 @@ struct HeadNormArgs {
     int q_col, k_col, v_col;  // starting column of each part, -1 = absent
     const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;  // [dh]
     const float* rope_cos; const float* rope_sin;  // [max_len][dh/2] or null (no RoPE)
-    bf16_t* q; bf16_t* k; bf16_t* vt;  // [B][H][Lp][DQK], [B][H][Lp][DQK], [B][H][DV][Lp]
+    bf16_t* q; bf16_t* k; bf16_t* v;   // [B][H][Lp][DQK], [B][H][Lp][DQK], [B][H][Lp][DV] (row-major: keys x channels)
     int B, H, L, Lp, dh;
+    int perm;   // EPI_QKV: the q / k weight rows are in the RoPE-pair order of EZDIT_T_QKROPE (gemm_pp.h qkrope_col): epilogue in registers, v tiles included
 };
 
 struct RowArgs {
@@ -203,14 +218,13 @@ struct GemmArgs {
     // (hardware deals workgroups to XCDs round-robin), so each XCD's private 4 MB L2 sees only its box's slice of A and W.
     // Filled by launch_gemm (xcd_map: 0 = legacy 1 x 8 x 1, 1 = smallest per-XCD footprint).
     int xcd_map; int pm, pn, pz, bm, bn, bz;
+    unsigned mbm, mbn, msplit, mG;   // ez_magic() of bm, bn, splitk and (N tiles x splitk): filled by the launchers (launch_magic, gemm.hip)
     int wt;                       // output stores are write-through (sc1)
     HeadNormArgs hn;              // EPI_QKV only (x / ldx / *_col unused)
     int part_bf16;                // EPI_PARTIAL: slabs are stored as bf16 (half the bytes written back and re-read by k_row)
     // split-K slabs with all workgroups of an M tile (N tiles x K splits) on ONE XCD (M tile tm -> XCD tm % 8): the slabs and the row kernel
     // that reduces them (row panel p on XCD p % 8, RowArgs.affine) stay inside that XCD's L2
     int xcd_panel;
-    // EPI_QKV: place every tile on the XCD whose attention workgroups consume it (single prompt: B * H / 4 == 8; gemm.hip)
-    int xcd_qkv;
     // ---- LayerNorm algebra (k_gemm_pp).  LN(x) g + c followed by a GEMM with W equals  r (x g) W^T - r mu (g W^T) + c W^T  row by row, with
     // (mu, r) the row's mean and 1 / sqrt(var + eps): the producer of x stores A' = bf16(x g) and partial statistics, the consumer runs the
     // plain GEMM on A' and applies  acc := r (acc - mu G'[col]) + C'[col]  in its epilogue, G' = g W^T and C' = c W^T (+ bias) precomputed
@@ -238,7 +252,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero =
 struct AttnArgs {
     const bf16_t* q;    // [B][H][Lqp][DQK]
     const bf16_t* k;    // [B][H][Lkp][DQK]
-    const bf16_t* vt;   // [B][H][DV][Lkp]
+    const bf16_t* v;    // [B][H][Lkp][DV] (row-major; the P.V operand is gathered with transposing LDS reads, attn.hip)
     const uint8_t* kmask;  // nullable [B][Lk], 1 = attend
     bf16_t* out; int ldo;  // [B*Lq][ldo], head h occupies cols [h*dh, (h+1)*dh)
     int B, H, Lq, Lk, Lqp, Lkp, dh;
@@ -254,6 +268,7 @@ struct AttnArgs {
     // run on ONE XCD (hardware deals workgroup i to XCD i % 8), so each pair's K / V^T is fetched into exactly one L2.
     // 0 = (query tile, head, batch) grid: the query tiles of a pair land on 8 different XCDs (8x the K/V traffic).
     int xcd_map; int nq, ppx;   // nq / ppx filled by launch_attention
+    unsigned mnq, mH;           // ez_magic(nq), ez_magic(H): filled by launch_attention
     int wt;                     // output stores are write-through (sc1)
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
     // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "gemm_pp.h"
 #include "gemm_ks.h"
+#include "gemm_co.h"
 
 #include <atomic>
 #include <type_traits>
@@ -220,44 +221,19 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile map: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the tile grid, M tiles fastest inside
+    // XCD-aware tile map (gemm_pp.h tile_of_block / panel_of_block: division-free): workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the tile grid
     const int tilesM = (a.M + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
-    const int xcd = blockIdx.x & 7;
-    const int l = blockIdx.x >> 3;
     int tm, tn, z;
     if (EPI == EPI_PARTIAL && a.xcd_panel) {
-        // panel placement: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8), so the
-        // tile's slabs, arrival word and row operator stay inside that XCD's L2 (see the hand-off below)
-        const int G = tilesN * a.splitk;
-        tm = xcd + 8 * (l / G);
-        tn = (l % G) / a.splitk;
-        z = (l % G) % a.splitk;
-    } else if (EPI == EPI_QKV && a.xcd_qkv) {
-        // consumer placement: the attention kernel runs the 4 consecutive (batch, head) pairs 4x .. 4x + 3 on XCD x (launch_attention, ppx = 4),
-        // and one N tile of this GEMM is q, k or v of exactly such a group of 4 heads: XCD x = (batch b, head group hg) computes the
-        // M tiles of batch b for the N tiles {q, k, v} x hg, so what attention reads was written into the L2 it reads from
-        const int hq = a.hn.H / 4;
-        const int b = xcd / hq, hg = xcd % hq;
-        const int t0 = (b * a.hn.L + BM - 1) / BM;
-        const int t1 = b + 1 < a.hn.B ? ((b + 1) * a.hn.L + BM - 1) / BM : tilesM;
-        tm = t0 + l % a.bm;
-        tn = (l / a.bm) * hq + hg;
-        z = 0;
-        if (tm >= t1 || l / a.bm >= 3) return;
-    } else {
-        const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
-        const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
-        tm = xm * a.bm + lm;
-        tn = xn * a.bn + ln;
-        z = xz * a.bz + lz;
-    }
-    if (tm >= tilesM || tn >= tilesN || z >= a.splitk) return;
+        panel_of_block(a, tilesN, tm, tn, z);
+        if (tm >= tilesM) return;
+    } else if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
     const int row0 = tm * BM, col0 = tn * BN;
 
     const int nk = a.K / BK;
-    const int kb = nk * z / a.splitk;
-    const int ke = nk * (z + 1) / a.splitk;
+    int kb, ke;
+    ksplit_range(a, nk, z, kb, ke);
     const int nt = ke - kb;
 
     f32x16 acc[FM][FN];
@@ -368,127 +344,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm(GemmArgs a) {
     }
 
     // ---- epilogue (lane <-> output element mapping: see store_tile) ----
-    const int row_in = lane & 31;
-    if constexpr (EPI == EPI_QKV) {
-        // ---- fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection): the tile holds FOUR WHOLE heads
-        // of q, of k or of v (BN = 4 x head_dim, and D is a multiple of BN), staged through LDS so that head boundaries
-        // need not coincide with MFMA fragments.  attention.py:137-142, rotary.py:6-18.
-        static_assert((BN == 288 || BN == 256) && BM == 64, "EPI_QKV is built for 64 x (4 heads) tiles");
-        constexpr int DH = BN / 4, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
-        float* tile = reinterpret_cast<float*>(smem);            // [BM][PITCH] fp32, reuses the ring
-        bf16_t* qk_st = reinterpret_cast<bf16_t*>(smem + BM * PITCH * 4);   // [BM][4][DH] bf16: normalised q / k heads on their way out
-        static_assert(BM * PITCH * 4 + BM * BN * 2 <= NS * STAGE_BYTES && (BM * PITCH * 4) % 16 == 0 && (DH * 2) % 16 == 0, "epilogue tile + staging must fit the ring");
-        __syncthreads();                                          // every wave is done with the last K tile
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = wn * TN + j * 32 + 8 * g + 4 * hi;
-                    *reinterpret_cast<float4*>(tile + (wm * TM + i * 32 + row_in) * PITCH + col) =
-                        make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                }
-        __syncthreads();
-        const HeadNormArgs& hn = a.hn;
-        const int D = hn.H * DH;
-        const int part = col0 / D;                 // 0 q, 1 k, 2 v
-        const int head0 = (col0 % D) / DH;         // first of the 4 heads of this tile
-        if (part < 2) {
-            // 4 lanes per (row, head): each owns DH / 4 contiguous channels; LN via two xor-shuffles, RoPE partner (i +- DH/2) in lane ^ 2
-            constexpr int E = DH / 4;
-            const float* w = part == 0 ? hn.qn_w : hn.kn_w;
-            const float* bb = part == 0 ? hn.qn_b : hn.kn_b;
-            bf16_t* dstbase = part == 0 ? hn.q : hn.k;
-            for (int it = tid; it < BM * 4 * 4; it += NT) {
-                const int sub = it & 3, hh = (it >> 2) & 3, r = it >> 4;
-                const int m = row0 + r;
-                const bool ok = m < a.M;
-                const int mm = ok ? m : a.M - 1;
-                const int b = mm / hn.L, l = mm % hn.L;
-                const float* src = tile + r * PITCH + hh * DH + sub * E;
-                float v[E];
-#pragma unroll
-                for (int i = 0; i < E / 2; ++i) {
-                    const float2 t2 = *reinterpret_cast<const float2*>(src + 2 * i);
-                    v[2 * i] = t2.x; v[2 * i + 1] = t2.y;
-                }
-                float s1 = 0.f;
-#pragma unroll
-                for (int i = 0; i < E; ++i) s1 += v[i];
-                s1 += __shfl_xor(s1, 1, 64);
-                s1 += __shfl_xor(s1, 2, 64);
-                const float mean = s1 * (1.f / DH);
-                float q2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < E; ++i) { const float d = v[i] - mean; q2 += d * d; }
-                q2 += __shfl_xor(q2, 1, 64);
-                q2 += __shfl_xor(q2, 2, 64);
-                const float rstd = rsqrtf(q2 * (1.f / DH) + 1e-5f);
-#pragma unroll
-                for (int i = 0; i < E; ++i) v[i] = (v[i] - mean) * rstd * w[sub * E + i] + bb[sub * E + i];
-                if (hn.rope_cos) {
-                    const float* cs = hn.rope_cos + (long)l * (DH / 2) + (sub & 1) * E;
-                    const float* sn = hn.rope_sin + (long)l * (DH / 2) + (sub & 1) * E;
-                    const float sign = (sub & 2) ? 1.f : -1.f;
-#pragma unroll
-                    for (int i = 0; i < E; ++i) {
-                        const float other = __shfl_xor(v[i], 2, 64);
-                        v[i] = v[i] * cs[i] + sign * other * sn[i];
-                    }
-                }
-                if (a.epi_lds) {   // park the bf16 head in LDS: written out below as whole 16-byte chunks (a head is 9 or 8 of them)
-                    bf16_t* dst = qk_st + (r * 4 + hh) * DH + sub * E;
-#pragma unroll
-                    for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
-                } else if (ok) {
-                    bf16_t* dst = dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + sub * E;
-#pragma unroll
-                    for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
-                }
-            }
-            if (a.epi_lds) {
-                // the direct form writes 4 bytes per lane, 36 bytes apart: 64 separate segments per store instruction (~5000 line requests
-                // per tile); from LDS every lane moves 16 contiguous bytes of one (row, head)
-                __syncthreads();
-                constexpr int CP = DH * 2 / 16;
-                for (int q = tid; q < BM * 4 * CP; q += NT) {
-                    const int c8 = q % CP, hh = (q / CP) & 3, r = q / (CP * 4);
-                    const int m = row0 + r;
-                    if (m < a.M) {
-                        const int b = m / hn.L, l = m % hn.L;
-                        *reinterpret_cast<uint4*>(dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * DQK + c8 * 8) =
-                            *reinterpret_cast<const uint4*>(qk_st + (r * 4 + hh) * DH + c8 * 8);
-                    }
-                }
-            }
-        } else {
-            // V^T[b][h][d][l]: consecutive lanes take consecutive ROW PAIRS (l, l + 1) of one channel d -> contiguous 4-byte stores
-            // (row0, L and Lp are even, so a pair never straddles a batch element and is 4-byte aligned)
-            if ((hn.L & 1) == 0) {
-                for (int it = tid; it < (BM / 2) * BN; it += NT) {
-                    const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * DH + d
-                    const int m = row0 + r;
-                    if (m < a.M) {
-                        const int b = m / hn.L, l = m % hn.L;
-                        const int hh = cc / DH, d = cc % DH;
-                        *reinterpret_cast<uint32_t*>(hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l) =
-                            pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
-                    }
-                }
-            } else {
-                for (int it = tid; it < BM * BN; it += NT) {
-                    const int r = it % BM, cc = it / BM;
-                    const int m = row0 + r;
-                    if (m < a.M) {
-                        const int b = m / hn.L, l = m % hn.L;
-                        const int hh = cc / DH, d = cc % DH;
-                        hn.vt[(((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l] = f2bf(tile[r * PITCH + cc]);
-                    }
-                }
-            }
-        }
-    } else {
+    {
         constexpr bool lds_ok = (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) && BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE_BYTES;
         if constexpr (lds_ok) {
             if (a.epi_lds && (EPI == EPI_GEGLU || a.part_bf16)) {
@@ -520,6 +376,7 @@ int pick_boxes(GemmArgs& a, int BM, int BN) {
             if (pm == 1 && pn == 8) fp *= 0.9;               // near-ties keep the weight stream disjoint across XCDs
             if (fp < best) { best = fp; a.pm = pm; a.pn = pn; a.pz = pz; a.bm = bm; a.bn = bn; a.bz = bz; }
         }
+    a.mbm = ez_magic(a.bm); a.mbn = ez_magic(a.bn); a.msplit = ez_magic(a.splitk); a.mG = ez_magic(((a.N + BN - 1) / BN) * a.splitk);
     return 8 * a.bm * a.bn * a.bz;
 }
 
@@ -527,7 +384,6 @@ int pick_boxes(GemmArgs& a, int BM, int BN) {
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR = 0>
 int launch_pp(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
-    a.xcd_qkv = 0;
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
     if (EPI == EPI_PARTIAL && a.xcd_panel && BM == 128) grid.x = 8 * ((a.N + BN - 1) / BN) * a.splitk * (((a.M + BM - 1) / BM + 7) / 8);   // M tile tm -> XCD tm % 8 (gemm_pp.h)
     else a.xcd_panel = 0;
@@ -547,11 +403,31 @@ int launch_pp(const GemmArgs& a0, hipStream_t st) {
     return 0;
 }
 
+// co-resident kernel (gemm_co.h): 4-wave workgroups, two per CU
+template <int BM, int BN, int EPI, int VAR = 0>
+int launch_co(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    a.xcd_panel = 0;
+    dim3 grid(pick_boxes(a, BM, BN), 1, 1);
+    constexpr int SMEM = co_smem_bytes<BM, BN>();
+    static std::atomic<bool> attr_set[32];   // per (kernel, device)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 32) return 1;
+    if (!attr_set[dev].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_co<BM, BN, EPI, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
+        attr_set[dev].store(true, std::memory_order_release);
+    }
+    if (a.ts && (long)grid.x > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
+    hipLaunchKernelGGL((k_gemm_co<BM, BN, EPI, VAR>), grid, dim3(256), SMEM, st, a);
+    return 0;
+}
+
 // K-split-inside-the-workgroup kernel (gemm_ks.h): 8 waves, each with private LDS slots for its own K chunks, no barrier in the K loop
 template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, bool DUAL = false>
 int launch_ks(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
-    a.xcd_qkv = 0; a.xcd_panel = 0; a.splitk = 1;
+    a.xcd_panel = 0; a.splitk = 1;
     constexpr int BM = 16 * FM, BN = 16 * FN;
     (void)pick_boxes(a, BM, BN);   // pm x pn XCD boxes with the smallest operand footprint; the tiles of an N group are then dealt in equal runs (ks_tile_of_block)
     const int tilesM = (a.M + BM - 1) / BM, tilesN = (a.N + BN - 1) / BN;
@@ -595,17 +471,6 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
     dim3 grid(pick_boxes(a, BM, BN), 1, 1);
     if (EPI == EPI_PARTIAL && a.xcd_panel) grid.x = 8 * tilesN * S * ((tilesM + 7) / 8);   // M tile tm -> XCD tm % 8, see k_gemm
     else a.xcd_panel = 0;
-    if (EPI == EPI_QKV && a.xcd_qkv && a.hn.H % 4 == 0 && a.hn.B * (a.hn.H / 4) == 8 && tilesN == 3 * (a.hn.H / 4) && S == 1) {
-        int nmax = 0;   // M tiles per batch element (a tile belongs to the batch element of its first row)
-        for (int b = 0; b < a.hn.B; ++b) {
-            const int t0 = (b * a.hn.L + BM - 1) / BM, t1 = b + 1 < a.hn.B ? ((b + 1) * a.hn.L + BM - 1) / BM : tilesM;
-            nmax = t1 - t0 > nmax ? t1 - t0 : nmax;
-        }
-        a.bm = nmax;
-        grid.x = 8 * 3 * nmax;
-    } else {
-        a.xcd_qkv = 0;
-    }
     constexpr int SMEM = NS * (BM + BN) * 128;
     static_assert(SMEM <= 160 * 1024, "LDS budget of a CU");
     // > 64 KB of dynamic LDS needs the opt-in attribute once per (kernel, DEVICE): function attributes are per device
@@ -633,6 +498,7 @@ int launch_t(const GemmArgs& a0, hipStream_t st) {
 //   60  128x288  4x2 (32x144)         ring 3  156 KB  k_gemm_pp SCHED 1   GEGLU GEMM at M <= 2048
 //   61  128x144  4x1 per group        ring 4  144 KB  k_gemm_pp SCHED 2 (k-split); fused QKV GEMM (two heads of 72 per tile)
 //   62  128x128  4x2 (32x64)          ring 3   96 KB  k_gemm_pp SCHED 1
+//   66  128x144  4 waves (32x144)     ring 2   74 KB  k_gemm_co: TWO workgroups per CU; GEGLU GEMM (round 6)
 //   (63-65: ping-pong experiments 64x128 / 128x144 ring 3 / 128x128 2x2, deleted in round 5)
 //   70, 72, 73  k_gemm_ks (K split over the waves of a workgroup, no ring): see launch_ks_tile
 template <int EPI>
@@ -663,6 +529,12 @@ int launch_e(const GemmArgs& a, hipStream_t st) {
         case 60: EZ_PP(128, 288, 4, 2, 3, 1)
         case 61: EZ_PP(128, 144, 4, 1, 4, 2)
         case 62: EZ_PP(128, 128, 4, 2, 3, 1)
+        case 66:
+            if constexpr (EPI == EPI_GEGLU) {   // (debug >> 8: phase-offset experiments of the microbenchmark, gemm_co.h)
+                if ((a.debug >> 8) == 1) return launch_co<128, 144, EPI, 1>(a, st);
+                if ((a.debug >> 8) == 2) return launch_co<128, 144, EPI, 2>(a, st);
+            }
+            return launch_co<128, 144, EPI>(a, st);
         default: break;
     }
 #undef EZ_PP
@@ -676,15 +548,17 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (a.K <= 0 || a.K % BK) return 1;
     if (a.epi == EPI_QKV && a.tile >= 60) {   // ping-pong kernel, k-split schedule: 128 x (2 whole heads), ring 4
         if (a.zstat_in && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
+        if (a.tile == 66) {   // co-resident kernel (gemm_co.h): the register epilogue only
+            if (!a.hn.perm) return 1;
+            if (a.hn.dh == 72) return a.zstat_in ? launch_co<128, 144, EPI_QKV, 64>(a, st) : launch_co<128, 144, EPI_QKV, 0>(a, st);
+            if (a.hn.dh == 64) return a.zstat_in ? launch_co<128, 128, EPI_QKV, 64>(a, st) : launch_co<128, 128, EPI_QKV, 0>(a, st);
+            return 1;
+        }
         if (a.hn.dh == 72) return a.zstat_in ? launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2, 64>(a, st) : launch_pp<128, 144, 4, 1, 4, EPI_QKV, 2>(a, st);
         if (a.hn.dh == 64) return a.zstat_in ? launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2, 64>(a, st) : launch_pp<128, 128, 4, 1, 4, EPI_QKV, 2>(a, st);
         return 1;
     }
-    if (a.epi == EPI_QKV) {   // lockstep kernel, tiles that hold four whole heads: 64x288 (head_dim 72, 9 or 6 waves) or 64x256 (head_dim 64, 8 waves)
-        if (a.hn.dh == 72) return a.tile == 1 ? launch_t<64, 288, 1, 9, 3, EPI_QKV>(a, st) : launch_t<64, 288, 2, 3, 3, EPI_QKV>(a, st);
-        if (a.hn.dh == 64) return launch_t<64, 256, 2, 4, 3, EPI_QKV>(a, st);
-        return 1;
-    }
+    if (a.epi == EPI_QKV) return 1;   // (the lockstep kernel's 64 x four-head form was deleted in round 6: nothing but gemm_pp = 0 reached it)
     if (a.epi == EPI_RESID && a.tile >= 70) {   // K-split-inside-the-workgroup kernel: residual (optional) + gate (optional) + statistics + next operand
         if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.out || !a.bias || a.splitk != 1 || (a.gate && !a.resid)) return 1;
         if (a.zd) {   // DUAL form: 48 x 96 tiles only
@@ -711,7 +585,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_RESID) return 1;
     if (a.epi == EPI_GEGLU && a.zstat_in) {   // GEGLU GEMM that finishes the LayerNorm of its operand (LayerNorm algebra): ping-pong kernel only
-        if (a.tile != 60 || !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
+        if ((a.tile != 60 && a.tile != 66) || !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
+        if (a.tile == 66) return launch_co<128, 144, EPI_GEGLU, 64>(a, st);
         return launch_pp<128, 288, 4, 2, 3, EPI_GEGLU, 1, 64>(a, st);
     }
     if (a.epi == EPI_GEGLU) return launch_e<EPI_GEGLU>(a, st);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk = a.K / CK;
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
-    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }
+    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = ez_stamp_start(); }
 
     // epilogue thread layout: (row er, lane-in-row ej) of the first 8 BM threads
     const int er = tid >> 3, ej = tid & 7;

@@ -85,14 +85,31 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
 // XCD-aware tile map shared by the GEMM kernels: workgroup b runs on XCD b % 8; XCD x owns box (xm, xn, xz) of the
 // (M tiles x N tiles x K splits) grid, M tiles fastest inside.  Returns false for a padding slot of a ragged box.
 __device__ __forceinline__ bool tile_of_block(const GemmArgs& a, int tilesM, int tilesN, int& tm, int& tn, int& z) {
+    // division-free: pm, pn, pz are powers of two (pick_boxes), l / bm and (l / bm) / bn by magic numbers (common.h ez_div)
     const int xcd = blockIdx.x & 7;
     const int l = blockIdx.x >> 3;
-    const int xm = xcd % a.pm, xn = (xcd / a.pm) % a.pn, xz = xcd / (a.pm * a.pn);
-    const int lm = l % a.bm, ln = (l / a.bm) % a.bn, lz = l / (a.bm * a.bn);
+    const int lpm = __builtin_ctz(a.pm), lpn = __builtin_ctz(a.pn);
+    const int xm = xcd & (a.pm - 1), xn = (xcd >> lpm) & (a.pn - 1), xz = xcd >> (lpm + lpn);
+    const int t1 = ez_div(l, a.mbm), lm = l - t1 * a.bm;
+    const int lz = ez_div(t1, a.mbn), ln = t1 - lz * a.bn;
     tm = xm * a.bm + lm;
     tn = xn * a.bn + ln;
     z = xz * a.bz + lz;
     return tm < tilesM && tn < tilesN && z < a.splitk;
+}
+// panel placement of a split-K GEMM: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8)
+__device__ __forceinline__ void panel_of_block(const GemmArgs& a, int tilesN, int& tm, int& tn, int& z) {
+    const int G = tilesN * a.splitk, l = blockIdx.x >> 3;
+    const int lg = ez_div(l, a.mG), r = l - lg * G;
+    tm = (blockIdx.x & 7) + 8 * lg;
+    tn = ez_div(r, a.msplit);
+    z = r - tn * a.splitk;
+}
+// K tiles [kb, ke) of split z
+__device__ __forceinline__ void ksplit_range(const GemmArgs& a, int nk, int z, int& kb, int& ke) {
+    if (a.splitk == 1) { kb = 0; ke = nk; return; }
+    kb = ez_div(nk * z, a.msplit);
+    ke = ez_div(nk * (z + 1), a.msplit);
 }
 
 // ---- copy a bf16 tile parked in LDS ([rows][pitch]) out to global memory as whole 16-byte row chunks ----
@@ -361,13 +378,14 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
     copy_out_bf16<NT>(tile, PITCH, BM, BN, a.zu, a.ld_zu, row0, col0, a.M, a.N, a.wt, tid);
 }
 
-// fused q | k | v epilogue (what k_headnorm + k_vtranspose do on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile
-// holds NH = BN / head_dim WHOLE heads of q, of k or of v (D is a multiple of BN), parked in LDS as fp32 so that head boundaries need not
-// coincide with MFMA fragments; per-head LayerNorm + RoPE of q / k -> [B][H][Lp][DQK], V -> V^T [B][H][DV][Lp].
+// q / k epilogue through an fp32 park (what k_headnorm does on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile holds NH = BN / head_dim
+// WHOLE heads of q or of k in NATURAL channel order, parked in LDS as fp32 so that head boundaries need not coincide with MFMA fragments; per-head
+// LayerNorm (+ RoPE) -> [B][H][Lp][DQK].  Since round 6 only the stand-alone cross-attention q projection of large grids takes it (api.hip q2_pp: its
+// weight rows are in natural order, like the context K it meets); the fused q | k | v projection runs pp_store_qkv_reg below.
 template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT, bool ZC>
 __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid,
                                              const float2* zrow, const float* zgc, int slot0) {
-    constexpr int NH = BN / DH, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, PITCH = BN + 4;
+    constexpr int NH = BN / DH, DQK = DH == 72 ? 80 : 64, PITCH = BN + 4;
     static_assert(NH * DH == BN && DH % 4 == 0 && (DH * 2) % 16 == 0, "whole heads");
     float* tile = reinterpret_cast<float*>(smem);                        // [BM][PITCH] fp32, reuses the ring
     bf16_t* qk_st = reinterpret_cast<bf16_t*>(smem + BM * PITCH * 4);    // [BM][NH][DH] bf16: normalised q / k heads on their way out
@@ -526,35 +544,213 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
                 else *reinterpret_cast<uint4*>(dst) = v;
             }
         }
-    } else {
-        park();
-        __syncthreads();
-        // V^T[b][h][d][l]: consecutive lanes take consecutive ROW PAIRS (l, l + 1) of one channel d -> contiguous 4-byte stores
-        // (row0, L and Lp are even, so a pair never straddles a batch element and is 4-byte aligned)
-        if ((hn.L & 1) == 0) {
-            for (int it = tid; it < (BM / 2) * BN; it += NT) {
-                const int r = (it % (BM / 2)) * 2, cc = it / (BM / 2);      // cc = hh * DH + d
-                const int m = row0 + r;
-                if (m < a.M) {
-                    int b, l;
-                    divmod_rows(m, hn.L, rcpL, b, l);
-                    const int hh = cc / DH, d = cc % DH;
-                    bf16_t* dst = hn.vt + (((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l;
-                    const uint32_t v = pack_bf2(tile[r * PITCH + cc], tile[(r + 1) * PITCH + cc]);
-                    if (a.wt) st4_wt(dst, v); else *reinterpret_cast<uint32_t*>(dst) = v;
+    }
+}
+
+// channel permutation of the fused q | k projection (EZDIT_T_QKROPE, include/ezdit.h; the packer applies it to the q and k rows of `wqkv`).  Column c of a
+// two-head tile (c = 16 j + 4 cg + 2 e + s: fragment j, lane group cg, pair e, half s) holds channel  f + (dh / 2) s  of head hh, where the RoPE pair
+// index f = 8 jj + 2 cg + e runs over a head's full fragments jj and, for head_dim 72 (4.5 fragments per head), the middle fragment is split between the
+// heads by lane group: cg 0, 1 -> head 0, cg 2, 3 -> head 1, f = 32 + 2 (cg & 1) + e.  So in the 16x16 MFMA C layout (lane = row m_in + 16 cg, four consecutive
+// columns) a lane holds, per fragment, TWO COMPLETE RoPE PAIRS (c, c + 1) of ONE head: LayerNorm statistics are in-lane sums plus two lane-swap steps over cg,
+// RoPE is in-lane -- no fp32 park, no column-wise LDS reads.  Head hh owns the tile columns [dh hh, dh hh + dh): q and k are stored in that column order
+// ([B][H][Lp][DQK]; q . k^T does not care as long as both use the same order, and head h sits at the same tile position h % 2 in q and in k).
+__host__ __device__ inline void qkrope_col(int dh, int c, int& hh, int& ch) {
+    const int j = c >> 4, cg = (c >> 2) & 3, e = (c >> 1) & 1, s = c & 1, FH = dh / 16;
+    int f;
+    if (dh % 16 == 0) { hh = j / FH; f = 8 * (j % FH) + 2 * cg + e; }
+    else if (j < FH) { hh = 0; f = 8 * j + 2 * cg + e; }
+    else if (j == FH) { hh = cg >> 1; f = 8 * FH + 2 * (cg & 1) + e; }
+    else { hh = 1; f = 8 * (j - FH - 1) + 2 * cg + e; }
+    ch = f + (dh / 2) * s;
+}
+
+// sums over the four lanes m_in + 16 cg that share an output row: v_permlane16_swap / v_permlane32_swap (VALU; __shfl_xor would be two LDS-pipe round trips)
+__device__ __forceinline__ float row4_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// fused q | k | v epilogue IN REGISTERS (round 6; attention.py:137-142, rotary.py:6-18): the tile holds two whole heads of q, of k (columns permuted as above) or
+// of v (natural order).  q / k: [LayerNorm algebra] -> per-head LayerNorm -> RoPE on the accumulators; everything leaves as bf16 through a staging tile
+// (whole 16-byte row chunks): q, k -> [B][H][Lp][DQK], v -> [B][H][Lp][DV].
+// per-row global operands of the register epilogue of ONE lane: the RoPE table values of its FM rows at its pair indices (f = 8 jj + 2 cg + e for the full
+// fragments jj and 8 FH + 2 (cg & 1) + e for the split middle one; the same for both heads).  Requested by qkv_request() right behind the K loop --
+// unconditionally, clamped, v tiles included (one code path, no conditional requests) -- so that they land under the k-split exchange; the LayerNorm affine
+// of the lane's channels (L2-hot: one vector per block) is requested at the top of the epilogue proper and lands under its reduction passes
+template <int DH, int FM>
+struct QkvOperands {
+    static constexpr int FH = DH / 16, MID = (DH % 16) != 0, NF = FH + MID;
+    f32x2 cs[FM][NF], sn[FM][NF];   // (x, y) = the table values of the pair indices f, f + 1
+    float aff;                      // this THREAD's element of the workgroup's LayerNorm-affine table (threads < 32 NF; qkv_aff_*)
+};
+// LayerNorm affine of a q / k tile as the lanes need it, [4 lane groups cg][NF pieces q][8]: (w[f], w[f + 1], w[H + f], w[H + f + 1], b[f], b[f + 1], b[H + f], b[H + f + 1])
+// with f the pair index of (cg, q) and H = dh / 2 -- 32 NF floats per workgroup, parked in LDS behind the per-column vectors: held in registers they were 8 NF = 40 per lane
+template <int DH>
+__device__ __forceinline__ int qkv_aff_index(int t /* 0 .. 32 NF - 1 */) {   // element of the [dh] affine vector that table entry t holds (e >= 4: of the bias)
+    constexpr int FH = DH / 16, NF = FH + ((DH % 16) != 0);
+    const int e = t & 7, q = (t >> 3) % NF, cg = t / (8 * NF);
+    const int f = q < FH ? 8 * q + 2 * cg : 8 * FH + 2 * (cg & 1);
+    return ((e & 2) ? DH / 2 : 0) + f + (e & 1);
+}
+template <int DH, int FM>
+__device__ __forceinline__ void qkv_request(const GemmArgs& a, int col0, int first_row /* of this lane's fragment 0 */, int lane, int tid, QkvOperands<DH, FM>& op) {
+    constexpr int HALF = DH / 2, FH = DH / 16, NF = QkvOperands<DH, FM>::NF;
+    const HeadNormArgs& hn = a.hn;
+    const int cg = lane >> 4;
+    const int part = col0 / (hn.H * DH);
+    const bool rope = part < 2 && hn.rope_cos != nullptr;
+    const float* w = part == 1 ? hn.kn_w : hn.qn_w;
+    {
+        const int t = tid < 32 * NF ? tid : 0;
+        op.aff = ((t & 4) ? (part == 1 ? hn.kn_b : hn.qn_b) : w)[qkv_aff_index<DH>(t)];
+    }
+    const float rcpL = __builtin_amdgcn_rcpf((float)hn.L);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        int m = first_row + i * 16;
+        m = m < a.M ? m : a.M - 1;
+        int b_, l;
+        divmod_rows(m, hn.L, rcpL, b_, l);
+        const float* ct = (rope ? hn.rope_cos + (long)l * HALF : w);
+        const float* st = (rope ? hn.rope_sin + (long)l * HALF : w);
+#pragma unroll
+        for (int q = 0; q < NF; ++q) {
+            const int f = q < FH ? 8 * q + 2 * cg : 8 * FH + 2 * (cg & 1);
+            // (plain loads: hipcc tracks them; inline-asm loads into AGPRs were tried and are NOT safe here -- the allocator inserted v_accvgpr_mov copies of the
+            // destinations between issue and wait (stale data, xs64 golden off by 16 %): the hazard class ADVICE r05 warned about)
+            op.cs[i][q] = *reinterpret_cast<const f32x2*>(ct + f);
+            op.sn[i][q] = *reinterpret_cast<const f32x2*>(st + f);
+        }
+    }
+}
+
+template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT, bool ZC>
+__device__ __forceinline__ void pp_store_qkv_reg(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int lane, int tid,
+                                                 const float2* zrow, const float* zgc, float* aff_l, int slot0, const QkvOperands<DH, FM>& op, unsigned long long* ts = nullptr) {
+    constexpr int NH = 2, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, FH = DH / 16, MID = (DH % 16) != 0;
+    static_assert(NH * DH == BN && TN == BN && FN == 2 * FH + MID && (DH % 16 == 0 || DH % 16 == 8), "two whole heads per tile, a wave holds whole rows");
+    constexpr int PITCH = BN + 8;                                       // bf16 elements per staging row
+    bf16_t* tile = reinterpret_cast<bf16_t*>(smem);                     // [BM][PITCH] bf16, reuses the ring
+    if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();          // exchange done
+    const int m_in = lane & 15, cg = lane >> 4;
+    const HeadNormArgs& hn = a.hn;
+    const float rcpL = __builtin_amdgcn_rcpf((float)hn.L);
+    const int D = hn.H * DH;
+    const int part = col0 / D;                 // 0 q, 1 k, 2 v   (uniform over the workgroup)
+    const int head0 = (col0 % D) / DH;         // first head of this tile
+    const bool rope = part < 2 && hn.rope_cos != nullptr;
+    const auto& cs = op.cs; const auto& sn = op.sn;
+    constexpr int NF = QkvOperands<DH, FM>::NF;
+    static_assert(32 * NF <= NT, "one table element per thread");
+    if (tid < 32 * NF) aff_l[tid] = op.aff;   // (visible behind the barrier below)
+    const float4* aff4 = reinterpret_cast<const float4*>(aff_l) + cg * NF * 2;
+    // every wave is done with the ring (4-wave form) / has read its partner's partial sums (k-split form): the ring becomes the bf16 staging tile, and each
+    // fragment is stored there as soon as it is finished (no register array of packed results)
+    __syncthreads();
+    const bool mid0 = cg < 2;              // the split fragment's columns of this lane belong to head 0 (else head 1)
+    // ONE pass per 16-row fragment i (LayerNorm algebra -> per-head LayerNorm -> RoPE -> staging): only that fragment's FN accumulators are in VGPRs at a time
+    // (the 4-wave form has FM = 2: 72 accumulators + the 80 operand registers of both fragments spilled when the phases ran tile-wide)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        if constexpr (ZC) {   // LayerNorm algebra: the projection of LN(x) g + c is  r (acc - mu G') + C'
+            // G' / C' of the lane's four columns are re-read per fragment (LDS: parked behind the ring by z_finish; per-row timesteps: global, the slot differs
+            // between rows) instead of being held for the whole tile (2 x FN float4 = 72 registers)
+            const int ncl = a.N - 4;
+            const int rl = wm * TM + i * 16 + m_in;
+            const float2 mr = zrow[rl];
+            const float r = mr.y, rm = mr.y * mr.x;
+            if (!a.row_slot) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(zgc + (j * 16 + 4 * cg)), c4 = *reinterpret_cast<const float4*>(zgc + BN + (j * 16 + 4 * cg));
+                    acc[i][j][0] = fmaf(r, acc[i][j][0], fmaf(-rm, g4.x, c4.x));
+                    acc[i][j][1] = fmaf(r, acc[i][j][1], fmaf(-rm, g4.y, c4.y));
+                    acc[i][j][2] = fmaf(r, acc[i][j][2], fmaf(-rm, g4.z, c4.z));
+                    acc[i][j][3] = fmaf(r, acc[i][j][3], fmaf(-rm, g4.w, c4.w));
                 }
+            } else {
+                int row = row0 + rl;
+                row = row < a.M ? row : a.M - 1;
+                const long so = (long)z_slot(a, slot0, row) * a.zt_slot_stride;
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    int cp = col0 + j * 16 + 4 * cg;
+                    cp = cp < ncl ? cp : ncl;
+                    const float4 g4 = *reinterpret_cast<const float4*>(a.zG + so + cp), c4 = *reinterpret_cast<const float4*>(a.zC + so + cp);
+                    acc[i][j][0] = fmaf(r, acc[i][j][0], fmaf(-rm, g4.x, c4.x));
+                    acc[i][j][1] = fmaf(r, acc[i][j][1], fmaf(-rm, g4.y, c4.y));
+                    acc[i][j][2] = fmaf(r, acc[i][j][2], fmaf(-rm, g4.z, c4.z));
+                    acc[i][j][3] = fmaf(r, acc[i][j][3], fmaf(-rm, g4.w, c4.w));
+                }
+            }
+        }
+        bf16_t* trow = tile + (wm * TM + i * 16 + m_in) * PITCH + 4 * cg;
+        if (part < 2) {
+            // per-head LayerNorm: two passes (mean, then the centred second moment, as the row kernels do), each an in-lane sum + row4_sum
+            float s0 = 0.f, s1 = 0.f, sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < FH; ++j) {
+                s0 += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                s1 += (acc[i][FH + MID + j][0] + acc[i][FH + MID + j][1]) + (acc[i][FH + MID + j][2] + acc[i][FH + MID + j][3]);
+            }
+            if constexpr (MID) sm = (acc[i][FH][0] + acc[i][FH][1]) + (acc[i][FH][2] + acc[i][FH][3]);
+            const float mean0 = row4_sum(s0 + (mid0 ? sm : 0.f)) * (1.f / DH), mean1 = row4_sum(s1 + (mid0 ? 0.f : sm)) * (1.f / DH);
+            float q0 = 0.f, q1 = 0.f, qm = 0.f;
+            const float meanm = mid0 ? mean0 : mean1;
+#pragma unroll
+            for (int j = 0; j < FH; ++j)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float d0 = acc[i][j][x] - mean0, d1 = acc[i][FH + MID + j][x] - mean1;
+                    q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1);
+                }
+            if constexpr (MID) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { const float d = acc[i][FH][x] - meanm; qm = fmaf(d, d, qm); }
+            }
+            const float rstd0 = rsqrtf(row4_sum(q0 + (mid0 ? qm : 0.f)) * (1.f / DH) + 1e-5f), rstd1 = rsqrtf(row4_sum(q1 + (mid0 ? 0.f : qm)) * (1.f / DH) + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const bool is_mid = MID && j == FH;
+                const int q = is_mid ? FH : (j < FH ? j : j - FH - MID);          // index of the lane's affine / table piece (compile-time)
+                const float mean = is_mid ? meanm : (j < FH ? mean0 : mean1);
+                const float rstd = is_mid ? (mid0 ? rstd0 : rstd1) : (j < FH ? rstd0 : rstd1);
+                // columns 4 cg + {0, 1, 2, 3} = (pair f: first half, second half), (pair f + 1: first half, second half)
+                const float4 w4 = aff4[2 * q], b4 = aff4[2 * q + 1];   // (w[f], w[f + 1], w[H + f], w[H + f + 1]), the same of the bias
+                float y0 = (acc[i][j][0] - mean) * rstd * w4.x + b4.x, y1 = (acc[i][j][1] - mean) * rstd * w4.z + b4.z;
+                float y2 = (acc[i][j][2] - mean) * rstd * w4.y + b4.y, y3 = (acc[i][j][3] - mean) * rstd * w4.w + b4.w;
+                if (rope) {   // rotary.py:6-8 (half split): first half x1 c - x2 s, second half x2 c + x1 s
+                    const float o0 = y0 * cs[i][q][0] - y1 * sn[i][q][0], o1 = y1 * cs[i][q][0] + y0 * sn[i][q][0];
+                    const float o2 = y2 * cs[i][q][1] - y3 * sn[i][q][1], o3 = y3 * cs[i][q][1] + y2 * sn[i][q][1];
+                    y0 = o0; y1 = o1; y2 = o2; y3 = o3;
+                }
+                *reinterpret_cast<uint2*>(trow + j * 16) = make_uint2(pack_bf2(y0, y1), pack_bf2(y2, y3));
             }
         } else {
-            for (int it = tid; it < BM * BN; it += NT) {
-                const int r = it % BM, cc = it / BM;
-                const int m = row0 + r;
-                if (m < a.M) {
-                    int b, l;
-                    divmod_rows(m, hn.L, rcpL, b, l);
-                    const int hh = cc / DH, d = cc % DH;
-                    hn.vt[(((long)b * hn.H + head0 + hh) * DV + d) * hn.Lp + l] = f2bf(tile[r * PITCH + cc]);
-                }
-            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<uint2*>(trow + j * 16) = make_uint2(pack_bf2(acc[i][j][0], acc[i][j][1]), pack_bf2(acc[i][j][2], acc[i][j][3]));
+        }
+    }
+    if (ts && lane == 0) ts[5] = __builtin_readcyclecounter();   // arithmetic done, tile staged
+    __syncthreads();
+
+    // whole 16-byte chunks: head hh of row r = the DH / 8 chunks at tile columns [DH hh, DH hh + DH) -> one row of q / k ([.][DQK]) or of v ([.][DV])
+    constexpr int CP = DH / 8;
+    bf16_t* dstbase = part == 0 ? hn.q : part == 1 ? hn.k : hn.v;
+    const int pitch = part < 2 ? DQK : DV;
+    for (int q = tid; q < BM * NH * CP; q += NT) {
+        const int c8 = q % CP, hh = (q / CP) % NH, r = q / (CP * NH);
+        const int m = row0 + r;
+        if (m < a.M) {
+            int b, l;
+            divmod_rows(m, hn.L, rcpL, b, l);
+            bf16_t* dst = dstbase + (((long)b * hn.H + head0 + hh) * hn.Lp + l) * pitch + c8 * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(tile + r * PITCH + hh * DH + c8 * 8);
+            if (a.wt) st16_wt(dst, make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)));
+            else *reinterpret_cast<uint4*>(dst) = v;
         }
     }
 }
@@ -567,7 +763,7 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
 // dynamic LDS of k_gemm_pp: ring | (mu, r) per row | per-column vectors | EPI_QKV: 256 bytes per wave that the RoPE-table warm-up DMA lands in
 template <int BM, int BN, int NS, int EPI>
 constexpr int pp_smem_bytes() {
-    return NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 4 : 2) * BN * 4 + (EPI == EPI_QKV ? 8 * 256 : 0);
+    return NS * ((BM + BN + 31) / 32) * 4096 + BM * 8 + (EPI == EPI_RESID ? 4 : 2) * BN * 4 + (EPI == EPI_QKV ? 8 * 256 + 1024 : 0);   // EPI_QKV: + the RoPE warm-up sink + the LayerNorm-affine table (qkv_aff_*)
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int EPI, int SCHED, int VAR>
@@ -587,6 +783,10 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    // the kernel arguments the prologue needs, requested in ONE batch at the top: left alone, hipcc sinks each scalar load towards its first use and the prologue
+    // walks a chain of serialised kernarg round trips in front of the first LDS-DMA (ISA of the round-6 fused-QKV kernel: five more than round 5's, +1.1K cycles)
+    asm volatile("" ::"s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn),
+                 "s"(a.bz), "s"(a.cur_step), "s"(a.ts), "s"(a.xcd_panel), "s"(a.row_slot));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -599,18 +799,14 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     const int tilesN = (a.N + BN - 1) / BN;
     int tm, tn, z;
     if (EPI == EPI_PARTIAL && a.xcd_panel) {
-        // panel placement: ALL workgroups of an M tile (N tiles x K splits) are dealt to ONE XCD (M tile tm -> XCD tm % 8), so the tile's
-        // slabs and the row kernel that reduces them (row panel p on XCD p % 8) stay inside that XCD's L2
-        const int G = tilesN * a.splitk, l = blockIdx.x >> 3;
-        tm = (blockIdx.x & 7) + 8 * (l / G);
-        tn = (l % G) / a.splitk;
-        z = (l % G) % a.splitk;
+        // panel placement: the tile's slabs and the row kernel that reduces them (row panel p on XCD p % 8) stay inside one XCD's L2
+        panel_of_block(a, tilesN, tm, tn, z);
         if (tm >= tilesM) return;
     } else if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk = a.K / BK;
-    const int kb = nk * z / a.splitk;
-    const int ke = nk * (z + 1) / a.splitk;
+    int kb, ke;
+    ksplit_range(a, nk, z, kb, ke);
     const int nt = ke - kb;
 
     // VAR & 64 ("ZM"): EPI_GEGLU / EPI_QKV finish a LayerNorm in their epilogue (GemmArgs.z*, consumer side)
@@ -688,7 +884,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
     };
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
-    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = __builtin_amdgcn_s_memrealtime(); }   // [6], [7]: the 100 MHz device-wide clock (cycle counters are not comparable between workgroups)
+    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = ez_stamp_start(); }   // [6], [7]: the 100 MHz device-wide clock (cycle counters are not comparable between workgroups)
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -938,7 +1134,33 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
     if constexpr (SCHED == 2) {
-        // EPI_RESID: the residual rows this wave finishes after the exchange (16 rows x the tile's columns) are requested NOW and land under the exchange
+        // exchange the two groups' partial sums through the (dead) ring: group g keeps the row fragments [g * FM/2, (g + 1) * FM/2) of its
+        // wave tile and parks the others for its partner wave (same wg, other group); lane-linear 16-byte accesses
+        constexpr int HF = FM / 2;
+        static_assert(8 * HF * FN * 1024 <= NS * STAGE, "exchange area must fit the ring");
+        // RAW barriers around the exchange (LDS traffic ordered by explicit lgkmcnt waits): __syncthreads() makes hipcc drain vmcnt(0) first, i.e. wait for the
+        // epilogue operands requested just above (residual rows / LayerNorm affine + RoPE rows) BEFORE the exchange instead of under it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();   // every wave is past its last fragment read: the ring is dead
+        f32x4* xw = reinterpret_cast<f32x4*>(smem) + (long)(wave ^ 4) * (HF * FN * 64);   // what the partner will read
+        f32x4* xr = reinterpret_cast<f32x4*>(smem) + (long)wave * (HF * FN * 64);
+        // (compile-time register indices on both sides of a uniform branch: a runtime-indexed accumulator array would live in scratch)
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) xw[(i * FN + j) * 64 + lane] = acc[HF + i][j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < HF; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) xw[(i * FN + j) * 64 + lane] = acc[i][j];
+        }
+        // The epilogue's global operands are requested HERE -- behind the exchange's LDS writes, in front of its second barrier -- and land under the barrier,
+        // the partner's partial sums and the first arithmetic.  Not earlier: hipcc drains vmcnt(0) in front of the first LDS write that follows an LDS-DMA it
+        // cannot prove finished (the K loop's), so anything requested above the writes is waited for before the exchange even starts (round 5 had the residual
+        // rows there: the ISA shows `s_waitcnt vmcnt(0)` in front of the first barrier)
+        // EPI_RESID: the residual rows this wave finishes after the exchange (16 rows x the tile's columns)
         constexpr int RF = EPI == EPI_RESID ? FM / 2 : 1, RN = EPI == EPI_RESID ? FN : 1;
         float4 rres[RF][RN], dres[RDUAL ? RF : 1][RDUAL ? RN : 1];
         if constexpr (RRES) {
@@ -958,26 +1180,14 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
                 }
             }
         }
-        // exchange the two groups' partial sums through the (dead) ring: group g keeps the row fragments [g * FM/2, (g + 1) * FM/2) of its
-        // wave tile and parks the others for its partner wave (same wg, other group); lane-linear 16-byte accesses
-        constexpr int HF = FM / 2;
-        static_assert(8 * HF * FN * 1024 <= NS * STAGE, "exchange area must fit the ring");
-        __syncthreads();
-        f32x4* xw = reinterpret_cast<f32x4*>(smem) + (long)(wave ^ 4) * (HF * FN * 64);   // what the partner will read
-        f32x4* xr = reinterpret_cast<f32x4*>(smem) + (long)wave * (HF * FN * 64);
-        // (compile-time register indices on both sides of a uniform branch: a runtime-indexed accumulator array would live in scratch)
-        if (grp == 0) {
-#pragma unroll
-            for (int i = 0; i < HF; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) xw[(i * FN + j) * 64 + lane] = acc[HF + i][j];
-        } else {
-#pragma unroll
-            for (int i = 0; i < HF; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) xw[(i * FN + j) * 64 + lane] = acc[i][j];
+        // EPI_QKV, register epilogue: RoPE rows of the 16 rows this wave finishes
+        constexpr int QDH = EPI == EPI_QKV ? BN / 2 : 64;
+        QkvOperands<QDH, EPI == EPI_QKV ? FM / 2 : 1> qop;
+        if constexpr (EPI == EPI_QKV) {
+            if (a.hn.perm) qkv_request<QDH, FM / 2>(a, col0, row0 + (wm * 2 + grp) * (TM / 2) + (lane & 15), lane, tid, qop);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();
         f32x4 half[HF][FN];
         // group 0 (even K tiles) + group 1 (odd K tiles): IEEE addition is commutative, so the sum does not depend on which wave adds
         if (grp == 0) {
@@ -1002,7 +1212,9 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
             static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");
-            pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zrow, zgc, slot0);
+            static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "bf16 staging tile must fit the ring");
+            if (a.hn.perm) pp_store_qkv_reg<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, lane, tid, zrow, zgc, reinterpret_cast<float*>(smem + NS * STAGE + BM * 8 + 2 * BN * 4 + 8 * 256), slot0, qop, ts);
+            else pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zrow, zgc, slot0);
         }
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;

@@ -1,7 +1,7 @@
 // Row-wise, HBM/L2-bound kernels of the denoising step (everything that is not a GEMM or attention).
 //   k_row          residual / split-K reduce + LayerNorm (+FiLM) -> bf16 GEMM operand   blocks.py:124-156
 //   k_headnorm     per-head LayerNorm(q,k) + RoPE -> attention layouts                  attention.py:137-142, rotary.py:6-18
-//   k_vtranspose   V -> V^T (keys contiguous) for the P.V MFMA
+//   (k_headnorm, second part)  V -> bf16 [keys][DV] for the P.V MFMA
 //   k_assemble     MaskDiT input assembly [x | gt' | m] -> token-major bf16             conditioners.py:151-176
 //   k_final_conv   unpatchify + Conv1d(C,C,3,pad 1)                                     blocks.py:209-210
 //   k_linear_f32   tiny fp32 linears of the time path                                   modules.py:19-61, udit.py:305-316
@@ -171,13 +171,13 @@ __global__ __launch_bounds__(256) void k_row_w(RowArgs a) {   // rowbody.h: one 
 // 4 lanes per (row, head, q|k): each lane owns DH/4 contiguous channels; the LayerNorm reductions are two
 // xor-shuffles, and the RoPE partner channel (i +- DH/2, rotary.py:6-8 half split) lives in lane ^ 2 at the same
 // local index.  Consecutive 4-lane groups walk the heads of one row: fully coalesced fp32 reads.
-__device__ __forceinline__ void vtranspose_body(const HeadNormArgs& a, int DV, int idx);
+__device__ __forceinline__ void vcopy_body(const HeadNormArgs& a, int DV, int idx);
 
 template <int DH, int DQK, int DV>
 __global__ __launch_bounds__(256) void k_headnorm(HeadNormArgs a, int nb_qk) {
     constexpr int E = DH / 4;
-    if ((int)blockIdx.x >= nb_qk) {  // second part of the fused launch: V -> V^T
-        vtranspose_body(a, DV, ((int)blockIdx.x - nb_qk) * 256 + threadIdx.x);
+    if ((int)blockIdx.x >= nb_qk) {  // second part of the fused launch: V -> bf16 attention layout
+        vcopy_body(a, DV, ((int)blockIdx.x - nb_qk) * 256 + threadIdx.x);
         return;
     }
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -231,23 +231,20 @@ __global__ __launch_bounds__(256) void k_headnorm(HeadNormArgs a, int nb_qk) {
     for (int i = 0; i < E / 2; ++i) *reinterpret_cast<uint32_t*>(dst + 2 * i) = pack_bf2(v[2 * i], v[2 * i + 1]);
 }
 
-__device__ __forceinline__ void vtranspose_body(const HeadNormArgs& a, int DV, int idx) {
-    const int l8n = a.Lp >> 3;
-    const int total = a.B * a.H * a.dh * l8n;
+// V fp32 [M][ldx] (columns v_col + h dh + d) -> bf16 [B][H][Lp][DV]: one 16-byte chunk (8 channels) per thread; rows l >= L and channels d >= dh stay zero
+__device__ __forceinline__ void vcopy_body(const HeadNormArgs& a, int DV, int idx) {
+    const int c8n = a.dh >> 3;
+    const int total = a.B * a.L * a.H * c8n;
     if (idx >= total) return;
-    const int d = idx % a.dh;
-    const int l8 = (idx / a.dh) % l8n;
-    const int bh = idx / (a.dh * l8n);
-    const int b = bh / a.H, h = bh % a.H;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int l = l8 * 8 + e;
-        v[e] = l < a.L ? a.x[((long)b * a.L + l) * a.ldx + a.v_col + h * a.dh + d] : 0.f;
-    }
+    const int c8 = idx % c8n;
+    const int h = (idx / c8n) % a.H;
+    const int m = idx / (c8n * a.H);
+    const int b = m / a.L, l = m % a.L;
+    const float* src = a.x + (long)m * a.ldx + a.v_col + h * a.dh + c8 * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
     uint4 o;
-    o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); o.z = pack_bf2(v[4], v[5]); o.w = pack_bf2(v[6], v[7]);
-    *reinterpret_cast<uint4*>(a.vt + ((long)bh * DV + d) * a.Lp + l8 * 8) = o;
+    o.x = pack_bf2(lo.x, lo.y); o.y = pack_bf2(lo.z, lo.w); o.z = pack_bf2(hi.x, hi.y); o.w = pack_bf2(hi.z, hi.w);
+    *reinterpret_cast<uint4*>(a.v + (((long)b * a.H + h) * a.Lp + l) * DV + c8 * 8) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -538,11 +535,11 @@ void launch_row(const RowArgs& a, hipStream_t st) {
 }
 
 void launch_headnorm(const HeadNormArgs& a, hipStream_t st) {
-    // ONE launch: blocks [0, nb_qk) do the per-head LayerNorm (+RoPE) of q / k, blocks [nb_qk, nb_qk + nb_v) transpose V
+    // ONE launch: blocks [0, nb_qk) do the per-head LayerNorm (+RoPE) of q / k, blocks [nb_qk, nb_qk + nb_v) cast V
     const int M = a.B * a.L;
     const int nparts = (a.q_col >= 0 ? 1 : 0) + (a.k_col >= 0 ? 1 : 0);
     const int nb_qk = (M * a.H * 4 * nparts + 255) / 256;
-    const int nb_v = a.v_col >= 0 ? (a.B * a.H * a.dh * (a.Lp / 8) + 255) / 256 : 0;
+    const int nb_v = a.v_col >= 0 ? (a.B * a.L * a.H * (a.dh / 8) + 255) / 256 : 0;
     if (nb_qk + nb_v == 0) return;
     if (a.dh == 64) hipLaunchKernelGGL((k_headnorm<64, 64, 64>), dim3(nb_qk + nb_v), dim3(256), 0, st, a, nb_qk);
     else hipLaunchKernelGGL((k_headnorm<72, 80, 96>), dim3(nb_qk + nb_v), dim3(256), 0, st, a, nb_qk);

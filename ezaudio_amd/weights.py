@@ -38,13 +38,47 @@ def _geglu8(t):
     return torch.cat([val, gate], dim=1).reshape(two_i, cols)
 
 
+def qkrope_col(dh, c):
+    """(head within the pair, channel) that tile column c of a two-head q / k tile holds (EZDIT_T_QKROPE; csrc/gemm_pp.h qkrope_col)."""
+    j, g, e, s, fh = c >> 4, (c >> 2) & 3, (c >> 1) & 1, c & 1, dh // 16
+    if dh % 16 == 0:
+        hh, f = j // fh, 8 * (j % fh) + 2 * g + e
+    elif j < fh:
+        hh, f = 0, 8 * j + 2 * g + e
+    elif j == fh:
+        hh, f = g >> 1, 8 * fh + 2 * (g & 1) + e
+    else:
+        hh, f = 1, 8 * (j - fh - 1) + 2 * g + e
+    return hh, f + (dh // 2) * s
+
+
+def _qkrope(t, dh):
+    """[3D, D] fused to_q | to_k | to_v weight: the q and k rows of every pair of heads re-ordered into RoPE-pair order; v rows untouched."""
+    D = t.shape[0] // 3
+    if D % (2 * dh):
+        raise NotImplementedError(f'EZDIT_T_QKROPE needs an even head count (D={D}, head_dim={dh})')
+    src = []
+    for c in range(2 * dh):
+        hh, ch = qkrope_col(dh, c)
+        src.append(hh * dh + ch)
+    assert sorted(src) == list(range(2 * dh))
+    idx = torch.arange(3 * D)
+    pair = torch.tensor(src)
+    for part in range(2):
+        for p0 in range(0, D, 2 * dh):
+            idx[part * D + p0:part * D + p0 + 2 * dh] = part * D + p0 + pair
+    return t[idx]
+
+
 def pack_state_dict(handle, state_dict, strict=True):
     """Returns a CPU uint8 tensor holding the packed blob."""
     lib = _lib.load()
     total = lib.ezdit_param_bytes(handle)
     blob = torch.zeros(total, dtype=torch.uint8)
     used = set()
-    for p in param_table(handle):
+    table = param_table(handle)
+    head_dim = next(int(p['cols']) for p in table if p['name'].endswith('.a.qnw'))   # attn.norm_q.weight is [head_dim]
+    for p in table:
         parts = []
         for key in p['src']:
             if key not in state_dict:
@@ -57,6 +91,8 @@ def pack_state_dict(handle, state_dict, strict=True):
         t = torch.cat([x.reshape(1, -1) if vec else x.reshape(x.shape[0], -1) for x in parts], dim=1 if vec else 0)
         if p['transform'] == _lib.T_GEGLU8:
             t = _geglu8(t.reshape(-1, 1)).reshape(1, -1) if vec else _geglu8(t)
+        elif p['transform'] == _lib.T_QKROPE:
+            t = _qkrope(t, head_dim)
         if tuple(t.shape) != (p['rows'], p['cols']):
             raise ValueError(f"{p['name']}: checkpoint shape {tuple(t.shape)} != expected {(p['rows'], p['cols'])}")
         dt = torch.bfloat16 if p['dtype'] == _lib.P_BF16 else torch.float32

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EZDIT_ABI_VERSION 3
+#define EZDIT_ABI_VERSION 4   /* 4 (round 6): ezdit_test_attention takes V row-major [B][H][Lkp][DV] (was V^T [B][H][DV][Lkp]); the internal buffers "vt" / "vct" are "v" / "vc" */
 
 typedef struct ezdit_handle ezdit_handle;
 typedef void* ezdit_stream; /* hipStream_t */
@@ -73,7 +73,14 @@ enum {
 enum { EZDIT_P_F32 = 0, EZDIT_P_BF16 = 1 };
 enum {
     EZDIT_T_NONE = 0,
-    EZDIT_T_GEGLU8 = 1 /* rows re-ordered so each 16-row group = 8 value rows then their 8 gate rows */
+    EZDIT_T_GEGLU8 = 1, /* rows re-ordered so each 16-row group = 8 value rows then their 8 gate rows */
+    /* fused to_q | to_k | to_v weight [3D][D] of an even head count (round 6): within the q rows [0, D) and the k rows [D, 2D), the rows of every PAIR of
+     * heads (2 dh rows) are re-ordered so that stored row c = 16 j + 4 g + 2 e + s of the pair holds channel f + (dh / 2) s of head hh, with the RoPE pair
+     * index f = 8 (j mod dh/16) + 2 g + e for the dh/16 full 16-row groups of a head (hh = 0 for the first dh/16 groups, 1 for the last), and -- head_dim 72:
+     * 4.5 groups per head -- the middle group split by g: g < 2 -> head 0, g >= 2 -> head 1, f = 32 + 2 (g & 1) + e (csrc/gemm_pp.h qkrope_col).  A
+     * channel and its rotate-half partner then sit side by side, two pairs per lane of the 16x16 MFMA output: per-head LayerNorm + RoPE run on the
+     * accumulators.  The v rows [2D, 3D) keep their order.  q and k are stored in this channel order; q . k^T is invariant under it. */
+    EZDIT_T_QKROPE = 2
 };
 typedef struct {
     char    name[64];      /* our slot name, e.g. "blk3.wqkv" */
@@ -208,10 +215,11 @@ int ezdit_test_resid(int tile, const void* dev_a_bf16, int lda, const void* dev_
  * start, K-loop end, kernel end, then epilogue internals) into dev_buf ([capacity_workgroups][8] uint64; NULL switches it off).  A launch
  * whose grid exceeds capacity_workgroups writes no stamps.  Un-register (NULL) before freeing the buffer. */
 int ezdit_debug_gemm_timestamps(void* dev_buf, long capacity_workgroups);
-int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, const void* dev_vt,
+/* q, k bf16 [B][H][L*p][DQK], v bf16 [B][H][Lkp][DV] (DQK / DV = 64 / 64 or 80 / 96 for head_dim 64 / 72; padding zero), out bf16 [B*Lq][ldD] */
+int ezdit_test_attention(ezdit_handle* h, const void* dev_q, const void* dev_k, const void* dev_v,
                          const uint8_t* dev_kmask, void* dev_out, int B, int Lq, int Lk, int Lqp, int Lkp,
                          ezdit_stream stream);
-/* copy an internal fp32/bf16 buffer (by name, e.g. "h", "u", "q", "k", "vt", "mod") for debugging. */
+/* copy an internal fp32/bf16 buffer (by name, e.g. "h", "u", "q", "k", "v", "mod") for debugging. */
 int ezdit_debug_buffer(ezdit_handle* h, const char* name, void** dev_ptr, size_t* bytes);
 /* number of kernel launches issued by the last ezdit_forward (host counter). */
 int ezdit_last_launch_count(const ezdit_handle* h);
@@ -229,14 +237,16 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   xkey1 0/1, default 1 (single-key cross-attention shortcut, needs zfuse: a batch element whose context mask has ONE valid key -- every unconditional
  *     row of classifier-free guidance -- gets the constant W_o v_key + b_o from the attention-out projection instead of a cross-attention launch;
  *     cross-attention and its out-projection then run over the other batch elements only.  Exact (softmax over one key is 1); 0 = every row through k_attn)
- *   gemm_pp (ping-pong kernel k_gemm_pp: bit 0 GEGLU GEMM, bit 1 fused QKV GEMM; 0 = the round-1/2 lockstep kernels and no LayerNorm algebra)
+ *   geglu_co / qkv_co 0/1/2 (GEGLU GEMM / fused QKV GEMM on the co-resident kernel k_gemm_co (csrc/gemm_co.h): 4-wave workgroups, 128 x 144 tiles, TWO per CU, so that one
+ *     workgroup's prologue / epilogue runs under the other's K loop; 1 = above 2048 token rows (batched prompts), 2 = always, 0 = the ping-pong kernel's 128 x 288 tile)
+ *   gemm_pp (ping-pong kernel k_gemm_pp: bit 0 GEGLU GEMM; 0 = the round-1 lockstep kernel for it and no LayerNorm algebra.  Bit 1 -- the fused QKV GEMM -- is
+ *     retired: since round 6 that GEMM always runs on the ping-pong kernel, its weights are packed for it, EZDIT_T_QKROPE)
  *   tile_partial (tile id of the split-K residual GEMMs at M <= 2048 rows: 9 = lockstep 128 x 128, 62 = the same tile on the ping-pong kernel; csrc/gemm.hip table)
  *   wt 0/1/2 (write-through (sc1) output stores; 2 = default: on while B L <= 2048)
  *   fuse_q2 0/1/2 (cross-attention computes its own q projection; 2 = also for large grids), q2_pp 0/1 (cross-attention q projection at grids too large
  *     for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue; 0 = fp32 GEMM + normalisation inside k_attn)
  *   attn_nkh 0/2/4 (attention key sub-blocks per tile, 0 = by grid size), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
- *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), qkv_affine 0/1 (fused QKV GEMM: every tile on the XCD whose attention
- *     workgroups read it), gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of
+ *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of
  *     an M tile on XCD tm % 8) and row_affine 0/1 (the row kernel processes row panel p on XCD p % 8).  Placement only: bitwise identical results.
  *   row_variant 0/1 (row kernel: one workgroup / one wave per row), epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks)
  *   cn_overlap 0/1 (fused sampler: ControlNet branch on a side stream next to the backbone's in-blocks)

@@ -51,7 +51,7 @@ def t_(a, dev='cuda:0'):
 # kernel level
 # ---------------------------------------------------------------------------------------------------
 # variant = tile_config * 4 + epilogue; epilogue 0 = fp32 (+bias), 1 = split-K partial slabs, 2 = GEGLU
-# tile_config: the table in csrc/gemm.hip (6, 9, 13, 25 lockstep k_gemm; 60-62 ping-pong k_gemm_pp; 70, 72, 73 K-split k_gemm_ks)
+# tile_config: the table in csrc/gemm.hip (6, 9, 13, 25 lockstep k_gemm; 60-62 ping-pong k_gemm_pp; 66 co-resident k_gemm_co; 70, 72, 73 K-split k_gemm_ks)
 @pytest.mark.parametrize('M,N,K,variant,splitk', [
     (1000, 1152, 1152, 6 * 4 + 0, 1),   # 128x64, waves 4x1
     (1000, 1152, 1152, 9 * 4 + 1, 3),   # 128x128, 8 waves, ring 3
@@ -82,6 +82,17 @@ def t_(a, dev='cuda:0'):
     (500, 300, 256, 61 * 4 + 1, 1),            # four K tiles
     (500, 300, 320, 61 * 4 + 1, 1),            # five
     (1000, 1152, 1152, 61 * 4 + 1, 3),         # six per slice
+    # co-resident kernel (k_gemm_co, 66: 128x144, 4 waves, ring 2, two workgroups per CU): every K-tile count from 1 up (prologue-only, the two tail
+    # forms, the steady loop), ragged M / N, K splits
+    (1000, 3456, 1152, 66 * 4 + 0, 1),
+    (4000, 9216, 1152, 66 * 4 + 0, 1),
+    (130, 144, 64, 66 * 4 + 0, 1),             # one K tile
+    (200, 288, 128, 66 * 4 + 0, 1),            # two
+    (77, 144, 192, 66 * 4 + 0, 1),             # three
+    (500, 300, 256, 66 * 4 + 1, 1),            # four, ragged N
+    (500, 300, 320, 66 * 4 + 1, 1),            # five
+    (1000, 1152, 1152, 66 * 4 + 1, 3),         # six per slice
+    (300, 200, 192, 16000 + 8000 + 66 * 4 + 1, 2),   # bf16 slabs through LDS, uneven split
     # K-split-inside-the-workgroup kernel (k_gemm_ks; 70: 48x96, 72: 32x96, 73: 48x64): K chunk counts below, at and
     # above the eight waves (idle waves, uneven shares), ragged M / N
     (1000, 1152, 1152, 70 * 4 + 0, 1),
@@ -190,7 +201,7 @@ def _resid_case(lib, dev, M, N, K, tile, mode, hmean=0.7, var_rtol=2e-5, mean_at
     assert (zu.float().cpu()[:, N:] == 0).all()
 
 
-@pytest.mark.parametrize('tile', [6, 13, 2013, 2060, 2061, 2062])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel
+@pytest.mark.parametrize('tile', [6, 13, 2013, 2060, 2061, 2062, 2066])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel; 66: co-resident kernel
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
     g = torch.Generator().manual_seed(7)
@@ -237,11 +248,11 @@ def test_attention_against_softmax_reference(lib, dev, size, Lq, Lk, masked, nkh
         mask[1, 1:] = False
     qp = torch.zeros(B, H, Lqp, DQK, dtype=torch.bfloat16); qp[:, :, :Lq, :dh] = q
     kp = torch.zeros(B, H, Lkp, DQK, dtype=torch.bfloat16); kp[:, :, :Lk, :dh] = k
-    vt = torch.zeros(B, H, DV, Lkp, dtype=torch.bfloat16); vt[:, :, :dh, :Lk] = v.transpose(2, 3)
+    vp = torch.zeros(B, H, Lkp, DV, dtype=torch.bfloat16); vp[:, :, :Lk, :dh] = v   # row-major: keys x channels
     ldD = (D + 63) // 64 * 64
     out = torch.zeros(B * Lq, ldD, dtype=torch.bfloat16, device=dev)
     md = mask.to(torch.uint8).to(dev)
-    qd, kd, vd = qp.to(dev), kp.to(dev), vt.to(dev)   # keep the device tensors alive across the launch
+    qd, kd, vd = qp.to(dev), kp.to(dev), vp.to(dev)   # keep the device tensors alive across the launch
     s = (q.double() @ k.double().transpose(2, 3)) * dh ** -0.5
     s = s.masked_fill(~mask[:, None, None, :], float('-inf'))
     ref = (torch.softmax(s, -1) @ v.double()).transpose(1, 2).reshape(B * Lq, D)
@@ -607,11 +618,11 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, qkv_affine=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=0)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
-                                        ('epi_lds', (0, 1)), ('qkv_affine', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1)),
+                                        ('epi_lds', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('geglu_co', (0, 2)), ('qkv_co', (0, 2)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1)),
                                         ('fuse_q2', (1, 0)), ('q2_pp', (1, 0)), ('xkey1', (1, 0))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
@@ -633,13 +644,33 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
             outs.append(_forward(m, inp, 499, kw).cpu().numpy())
         assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0
         assert lib.ezdit_set_option(m._h, b'fuse_q2', 1) == 0
-    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1'):   # placement / issue order / launch structure only: bitwise identical
+    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1', 'geglu_co', 'qkv_co'):   # placement / issue order / launch structure only: bitwise identical
         for o in outs[1:]:
             np.testing.assert_array_equal(outs[0], o)
     else:   # row_variant: same math, different rounding points; gemm_pp / tile_partial: another kernel (other MFMA shape, other fp32 summation order over K)
         assert rel_l2(outs[0], outs[1]) < 1e-2
         for o in outs:
             assert rel_l2(o, g['pred_t499']) < REL_TOL
+
+
+@pytest.mark.parametrize('name', ['xs64', 's64', 'xl', 'xl_b8'])
+def test_co_resident_gemm_kernels_match_reference_golden(lib, dev, name):
+    """geglu_co = qkv_co = 2: the GEGLU GEMM and the fused QKV GEMM on the 4-wave co-resident kernel (csrc/gemm_co.h; the QKV epilogue in registers without the
+    k-split exchange, head_dim 64 and 72) against the reference goldens, at the gate of the default path."""
+    cfg, sd, inp, kw, g, meta = golden_case(name)
+    m = get_model(meta['size'], meta['seed_w'])
+    try:
+        for o in (b'geglu_co', b'qkv_co'):
+            assert lib.ezdit_set_option(m._h, o, 2) == 0
+        for t in meta['timesteps']:
+            ref = g[f'pred_t{t}']
+            pred = _forward(m, inp, t, kw).cpu().numpy()
+            r, a = rel_l2(pred, ref), float(np.abs(pred - ref).max())
+            record(f'{name} t={t} co-resident GEGLU + QKV: rel-L2 {r:.3e} max-abs {a:.3e}')
+            assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
+    finally:
+        for o in (b'geglu_co', b'qkv_co'):
+            assert lib.ezdit_set_option(m._h, o, 0) == 0
 
 
 def test_unsupported_kernel_configuration_is_an_error_not_a_silent_skip(lib, dev):

@@ -30,7 +30,7 @@ def test_library_exports_every_symbol_the_header_declares(lib):
     exported = set(re.findall(r' T (ez(?:dit|vae)_[a-z_0-9]+)', out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     assert set(declared) == set(_lib.PROTOTYPES), sorted(set(declared) ^ set(_lib.PROTOTYPES))
-    assert lib.ezdit_abi_version() == 3
+    assert lib.ezdit_abi_version() == 4
 
 
 def test_no_oracle_import_in_product():
@@ -71,9 +71,10 @@ def test_param_layout_covers_state_dict_exactly_once(lib, size):
     lib.ezdit_destroy(h)
 
 
-def test_pack_roundtrip_and_geglu_interleave(lib):
+@pytest.mark.parametrize('size', ['xs', 'xs64'])
+def test_pack_roundtrip_and_geglu_interleave(lib, size):
     from ezaudio_amd.weights import pack_state_dict, param_table
-    cfg, h = _handle(lib, 'xs')
+    cfg, h = _handle(lib, size)
     sd = make_state_dict(cfg, 5)
     blob = pack_state_dict(h, sd)
     D, inner = cfg['embed_dim'], 4 * cfg['embed_dim']
@@ -91,6 +92,28 @@ def test_pack_roundtrip_and_geglu_interleave(lib):
                                    for g in range(inner // 8)])
             w2 = w2[perm]
             want = w2.reshape(1, -1) if p['rows'] == 1 else w2
+        if p['transform'] == 2:  # QKROPE (include/ezdit.h): restated here from the header's words, not from the packer
+            dh = D // cfg['num_heads']
+            perm = np.arange(3 * D)
+            for part in range(2):
+                for p0 in range(0, D, 2 * dh):
+                    for c in range(2 * dh):
+                        j, g, e, sft = c // 16, (c // 4) % 4, (c // 2) % 2, c % 2
+                        full = dh // 16
+                        if dh % 16 == 0:
+                            hh, f = j // full, 8 * (j % full) + 2 * g + e
+                        elif j < full:
+                            hh, f = 0, 8 * j + 2 * g + e
+                        elif j == full:
+                            hh, f = g // 2, 32 + 2 * (g % 2) + e
+                        else:
+                            hh, f = 1, 8 * (j - full - 1) + 2 * g + e
+                        perm[part * D + p0 + c] = part * D + p0 + hh * dh + f + (dh // 2) * sft
+            assert sorted(perm) == list(range(3 * D))
+            want = want[perm]
+            # what the permutation is for: every aligned row pair (2 k, 2 k + 1) of q and k is a rotate-half pair (channel, channel + dh / 2) of ONE head
+            qk = perm[:2 * D].reshape(-1, 2)
+            assert ((qk[:, 1] - qk[:, 0]) == dh // 2).all() and ((qk[:, 0] % D) // dh == (qk[:, 1] % D) // dh).all()
         tol = 0 if p['dtype'] == 0 else 2 ** -8
         np.testing.assert_allclose(got, want, rtol=tol, atol=1e-30, err_msg=p['name'])
     with pytest.raises(KeyError):
@@ -175,7 +198,7 @@ def test_product_scheduler_agrees_with_oracle_restatement():
         DDIMScheduler(**dict(DIFF, prediction_type='epsilon'))
 
 
-OPTION_NAMES = ['zfuse', 'xkey1', 'wt', 'gemm_pp', 'tile_partial', 'attn_xcd', 'row_variant', 'gemm_panel', 'row_affine', 'epi_lds', 'qkv_affine', 'attn_xk2',
+OPTION_NAMES = ['zfuse', 'xkey1', 'geglu_co', 'qkv_co', 'wt', 'gemm_pp', 'tile_partial', 'attn_xcd', 'row_variant', 'gemm_panel', 'row_affine', 'epi_lds', 'attn_xk2',
                 'attn_nkh', 'cn_overlap', 'fuse_q2', 'q2_pp', 'stamp_launch', 'trace_launches']
 
 
@@ -188,7 +211,7 @@ def test_tuning_knobs_named_in_the_header_exist(lib):
     for n in OPTION_NAMES:
         assert re.search(r'\b%s\b' % n, src), n
         assert lib.ezdit_set_option(h, n.encode(), 0) == 0, n
-    for n in ('no_such_knob', 'prefetch', 'geglu_tile', 'ztile', 'zfake', 'gemm_debug', 'fuse_resid', 'tile_p18', 'pp_max_m'):
+    for n in ('no_such_knob', 'qkv_affine', 'prefetch', 'geglu_tile', 'ztile', 'zfake', 'gemm_debug', 'fuse_resid', 'tile_p18', 'pp_max_m'):
         assert lib.ezdit_set_option(h, n.encode(), 1) == -1, n
         assert n.encode() in lib.ezdit_last_error()
     api = open(os.path.join(ROOT, 'ezaudio_amd', 'csrc', 'api.hip')).read()

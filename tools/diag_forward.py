@@ -79,10 +79,10 @@ def main(size='xs', L=96, Lc=20, t=499):
     run(6)
     q = b16('q', (B, H, Lp, DQK))[:, :, :L, :dh]
     k = b16('k', (B, H, Lp, DQK))[:, :, :L, :dh]
-    vt = b16('vt', (B, H, DV, Lp))[:, :, :dh, :L]
+    vt = b16('v', (B, H, Lp, DV))[:, :, :L, :dh]
     rows.append(('q (headLN+rope)', rel(q, T[f'{pfx}:sq'])))
     rows.append(('k (headLN+rope)', rel(k, T[f'{pfx}:sk'])))
-    rows.append(('v^T', rel(vt, T[f'{pfx}:sv'].transpose(0, 1, 3, 2))))
+    rows.append(('v', rel(vt, T[f'{pfx}:sv'])))
     run(7)
     ao = b16('ao', (M, ldD))[:, :D]
     rows.append(('self-attn out', rel(ao, T[f'{pfx}:so'].reshape(M, D))))
@@ -95,9 +95,9 @@ def main(size='xs', L=96, Lc=20, t=499):
     rows.append(('cross q', rel(q2, T[f'{pfx}:xq'])))
     Lcp = (Lc + 63) // 64 * 64
     kc = b16('kc', (cfg['depth'] + 1, B, H, Lcp, DQK))[0, :, :, :Lc, :dh]
-    vct = b16('vct', (cfg['depth'] + 1, B, H, DV, Lcp))[0, :, :, :dh, :Lc]
+    vct = b16('vc', (cfg['depth'] + 1, B, H, Lcp, DV))[0, :, :, :Lc, :dh]
     rows.append(('cross k (ctx path)', rel(kc, T[f'{pfx}:xk'])))
-    rows.append(('cross v^T', rel(vct, T[f'{pfx}:xv'].transpose(0, 1, 3, 2))))
+    rows.append(('cross v', rel(vct, T[f'{pfx}:xv'])))
     run(12)
     ao = b16('ao', (M, ldD))[:, :D]
     rows.append(('cross-attn out', rel(ao, T[f'{pfx}:xo'].reshape(M, D))))

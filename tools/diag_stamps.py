@@ -91,7 +91,7 @@ def main(size='xl'):
             if not okr.any():
                 break
             # cycle counters are per workgroup-local clock domain; [6] / [7] hold the 100 MHz device-wide clock at the start and the end
-            rt0, rt1 = raw[okr, 6], raw[okr, 7]
+            rt0, rt1 = raw[okr, 6] & ((1 << 48) - 1), raw[okr, 7]   # ([6]'s top 16 bits name the CU: common.h ez_stamp_start)
             span = float(rt1.max() - rt0.min()) * 10.0      # ns: first workgroup start -> last workgroup end
             skew = float(rt0.max() - rt0.min()) * 10.0      # ns: first -> last workgroup start
             mine = float((rt1 - rt0).mean()) * 10.0         # ns: mean lifetime of a workgroup
@@ -105,6 +105,9 @@ def main(size='xl'):
             else:
                 row = [a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2]]
                 lab = ['prologue', 'K loop', 'epilogue + stores']
+                if (raw[okr, 4] > 0).all() and (raw[okr, 5] > 0).all():   # epilogue marks ([4], [5]): GEGLU: ring dead / parked; fused QKV: exchange done / arithmetic done
+                    row += [a[:, 4] - a[:, 2], a[:, 5] - a[:, 4], a[:, 3] - a[:, 5]]
+                    lab += ['(epilogue: -> mark 4', 'mark 4 -> 5', 'mark 5 -> end)']
             if not names[i].startswith('k_attn') and _ == 0:
                 e = np.sort(row[2])
                 print(f'    epilogue over workgroups: min {e[0]:.0f} p25 {e[len(e) // 4]:.0f} median {e[len(e) // 2]:.0f} p75 {e[3 * len(e) // 4]:.0f} max {e[-1]:.0f}; '

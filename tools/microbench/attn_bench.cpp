@@ -20,7 +20,7 @@ int main() {
     struct Case { int Lq, Lk; } cases[] = {{500, 500}, {500, 100}};
     for (auto cs : cases) {
         const int Lqp = (cs.Lq + 127) / 128 * 128, Lkp = (cs.Lk + 127) / 128 * 128;
-        std::vector<uint16_t> q((size_t)B * H * Lqp * DQK), k((size_t)B * H * Lkp * DQK), v((size_t)B * H * DV * Lkp);
+        std::vector<uint16_t> q((size_t)B * H * Lqp * DQK), k((size_t)B * H * Lkp * DQK), v((size_t)B * H * Lkp * DV);   // V row-major [keys][DV]
         for (auto& x : q) x = rbf(); for (auto& x : k) x = rbf(); for (auto& x : v) x = rbf();
         uint16_t *dq, *dk, *dv, *dout; 
         CHECK(hipMalloc(&dq, q.size() * 2)); CHECK(hipMalloc(&dk, k.size() * 2)); CHECK(hipMalloc(&dv, v.size() * 2)); CHECK(hipMalloc(&dout, (size_t)B * cs.Lq * D * 2));

@@ -13,6 +13,7 @@
 #include <string.h>
 #include <math.h>
 #include <vector>
+#include <algorithm>
 #include <string>
 
 #include "ezdit.h"
@@ -64,28 +65,24 @@ int main(int argc, char** argv) {
     const int iters = 40;
     const Shape shapes[] = {
         {"geglu", 1000, 9216, 1152}, {"geglu4k", 1000, 9216, 4608}, {"qkv", 1000, 3456, 1152}, {"dxd", 1000, 1152, 1152},
-        {"skip", 1000, 1152, 2304}, {"mlpout", 1000, 1152, 4608}, {"dxd_b4", 4000, 1152, 1152}, {"mlpout_b4", 4000, 1152, 4608}, {"geglu_b4", 4000, 9216, 1152}, {"odd", 77, 288, 192}, {"odd1", 130, 576, 64}, {"odd2", 200, 432, 128}, {"odd5", 1000, 288, 320},
+        {"skip", 1000, 1152, 2304}, {"mlpout", 1000, 1152, 4608}, {"dxd_b4", 4000, 1152, 1152}, {"mlpout_b4", 4000, 1152, 4608}, {"geglu_b4", 4000, 9216, 1152}, {"qkv_b4", 4000, 3456, 1152}, {"odd", 77, 288, 192}, {"odd1", 130, 576, 64}, {"odd2", 200, 432, 128}, {"odd5", 1000, 288, 320},
     };
     // which configurations run on which shape
     std::vector<Cfg> wide = {   // N >= 3456
-        {"old 128x288 12w r3 (13)", 13, 2, 1, 0, 1}, {"pp 128x288 s1 r3 (60)", 60, 2, 1, 0, 1}, {"pp60 LN-algebra epilogue", 60, 2, 1, 0, 9}, 
-        {"pp 128x144 s2 r4 (61) geglu", 61, 2, 1, 0, 1}, {"pp 128x144 s2 r3 (64) geglu", 64, 2, 1, 0, 1},
-        {"pp 128x128 s1 r3 (62) geglu", 62, 2, 1, 0, 1}, {"pp 128x128 s2 r4 (65) geglu", 65, 2, 1, 0, 1},
+        {"old 128x288 12w r3 (13)", 13, 2, 1, 0, 1}, {"pp 128x288 s1 r3 (60)", 60, 2, 1, 0, 1}, {"pp60 LN-algebra epilogue", 60, 2, 1, 0, 9},
+        {"co 128x144 4w r2 x2/CU (66)", 66, 2, 1, 0, 1}, {"co66 LN-algebra epilogue", 66, 2, 1, 0, 9}, {"co66 half-tile phase offset", 66, 2, 1, 1, 1}, {"co66 half-lifetime offset", 66, 2, 1, 2, 1},
+        {"pp 128x144 s2 r4 (61) geglu", 61, 2, 1, 0, 1}, {"pp 128x128 s1 r3 (62) geglu", 62, 2, 1, 0, 1},
         {"pp60 abl8 noMFMA", 60, 2, 1, 8, 1}, {"pp60 abl16 noReads", 60, 2, 1, 16, 1}, {"pp60 abl32 noDMA", 60, 2, 1, 32, 1},
         {"pp60 abl24 noMFMA noReads", 60, 2, 1, 24, 1}, {"pp60 abl40 noMFMA noDMA", 60, 2, 1, 40, 1}, {"pp60 abl48 noReads noDMA", 60, 2, 1, 48, 1}, {"pp60 abl56 barriers only", 60, 2, 1, 56, 1},
-        {"pp61 abl8 noMFMA", 61, 2, 1, 8, 1}, {"pp61 abl16 noReads", 61, 2, 1, 16, 1}, {"pp61 abl32 noDMA", 61, 2, 1, 32, 1}, {"pp61 abl56 barriers only", 61, 2, 1, 56, 1},
-        {"old 128x288 f32 (13)", 13, 0, 1, 0, 0}, {"pp60 f32", 60, 0, 1, 0, 0}, {"pp61 f32", 61, 0, 1, 0, 0}, {"pp61 var1 f32", 61, 0, 1, 1, 0}, {"pp61 var2 f32", 61, 0, 1, 2, 0},
-        {"pp64 f32", 64, 0, 1, 0, 0}, {"pp62 f32", 62, 0, 1, 0, 0}, {"pp65 f32", 65, 0, 1, 0, 0}, {"old 128x128 8w r3 f32 (9)", 9, 0, 1, 0, 0},
+        {"old 128x288 f32 (13)", 13, 0, 1, 0, 0}, {"pp60 f32", 60, 0, 1, 0, 0}, {"pp61 f32", 61, 0, 1, 0, 0}, {"co66 f32", 66, 0, 1, 0, 0},
+        {"pp62 f32", 62, 0, 1, 0, 0}, {"old 128x128 8w r3 f32 (9)", 9, 0, 1, 0, 0},
     };
     std::vector<Cfg> narrow = {   // N = 1152
         {"old 128x128 8w r3 split3 (9)", 9, 1, 3, 0, 0}, {"old 9 split1", 9, 1, 1, 0, 0},
         {"pp62 s1 split3", 62, 1, 3, 0, 0}, {"pp62 split2", 62, 1, 2, 0, 0}, {"pp62 split1", 62, 1, 1, 0, 0},
-        {"pp65 s2 split3", 65, 1, 3, 0, 0}, {"pp65 split2", 65, 1, 2, 0, 0}, {"pp65 split1", 65, 1, 1, 0, 0},
-        {"pp63 64x128 s2 split1", 63, 1, 1, 0, 0}, {"pp63 split2", 63, 1, 2, 0, 0}, {"pp63 split3", 63, 1, 3, 0, 0}, {"pp63 var1 split1", 63, 1, 1, 1, 0},
-        {"pp64 128x144 s2 split1", 64, 1, 1, 0, 0}, {"pp64 split2", 64, 1, 2, 0, 0}, {"pp64 split3", 64, 1, 3, 0, 0},
         {"pp61 128x144 r4 split3", 61, 1, 3, 0, 0}, {"pp61 split4", 61, 1, 4, 0, 0},
-        {"pp63 f32 bias", 63, 0, 1, 0, 0}, {"pp65 f32 bias", 65, 0, 1, 0, 0},
-        {"ks 48x96 f32 bias (70)", 70, 0, 1, 0, 0}, {"ks 64x64 f32 bias (71)", 71, 0, 1, 0, 0}, {"ks 32x96 f32 bias (72)", 72, 0, 1, 0, 0}, {"ks 48x64 f32 bias (73)", 73, 0, 1, 0, 0}, {"ks 32x128 f32 bias (75)", 75, 0, 1, 0, 0},
+        {"co66 128x144 split1", 66, 1, 1, 0, 0}, {"co66 split2", 66, 1, 2, 0, 0}, {"co66 split3", 66, 1, 3, 0, 0},
+        {"ks 48x96 f32 bias (70)", 70, 0, 1, 0, 0}, {"ks 32x96 f32 bias (72)", 72, 0, 1, 0, 0}, {"ks 48x64 f32 bias (73)", 73, 0, 1, 0, 0},
     };
     hipStream_t st;
     CHECK(hipStreamCreate(&st));
@@ -199,6 +196,31 @@ int main(int argc, char** argv) {
                 }
                 if (n) printf("      stamps (ticks; %d WGs): span %llu | prologue avg %.0f max %.0f | loop avg %.0f max %.0f (%.1f per K tile) | epilogue avg %.0f max %.0f | last start +%.0f\n",
                               n, t_last - t_first, pro / n, pro_max, loop / n, loop_max, loop / n / ((K / 64) / c.splitk), epi / n, epi_max, start_max);
+                {   // per-CU timeline from the 100 MHz device clock ([6] start, tagged with the CU id; [7] end): how many workgroups share a CU at a time, how long a CU idles between them
+                    struct Ev { unsigned long long t0, t1; };
+                    std::vector<std::vector<Ev>> cu(4096);
+                    unsigned long long r0 = ~0ull, r1 = 0; double life = 0; int m = 0;
+                    for (int w = 0; w < NWG; ++w) {
+                        const unsigned long long* t = &hts[8 * w];
+                        if (!t[0] || !t[3] || !t[7]) continue;
+                        const unsigned long long a0 = t[6] & 0xffffffffffffull, a1 = t[7] & 0xffffffffffffull;
+                        cu[(t[6] >> 48) & 4095].push_back({a0, a1});
+                        if (a0 < r0) r0 = a0; if (a1 > r1) r1 = a1; life += (double)(a1 - a0); ++m;
+                    }
+                    int ncu = 0, maxper = 0, maxconc = 0; double busy1 = 0, busy2 = 0;
+                    for (auto& v : cu) {
+                        if (v.empty()) continue;
+                        ++ncu; if ((int)v.size() > maxper) maxper = (int)v.size();
+                        // sweep: time with >= 1 and with >= 2 workgroups resident
+                        std::vector<std::pair<unsigned long long, int>> ev;
+                        for (auto& e : v) { ev.push_back({e.t0, 1}); ev.push_back({e.t1, -1}); }
+                        std::sort(ev.begin(), ev.end());
+                        int c = 0; unsigned long long last = 0;
+                        for (auto& e : ev) { if (c >= 1) busy1 += (double)(e.first - last); if (c >= 2) busy2 += (double)(e.first - last); c += e.second; if (c > maxconc) maxconc = c; last = e.first; }
+                    }
+                    if (m) printf("      timeline (10 ns ticks): first start -> last end %.2f us | %d CUs, <= %d workgroups per CU, <= %d resident at once | mean lifetime %.2f us | a CU has >= 1 workgroup %.0f %% and >= 2 %.0f %% of the span\n",
+                                  (r1 - r0) * 0.01, ncu, maxper, maxconc, life / m * 0.01, 100.0 * busy1 / ncu / (double)(r1 - r0), 100.0 * busy2 / ncu / (double)(r1 - r0));
+                }
                 if (n && e2s > 0) printf("      epilogue parts: math + wait + barrier %.0f | park %.0f | barrier + copy-out %.0f\n", e1s / n, e2s / n, e4s / n);
             }
             if (bad) printf("      %ld elements out of tolerance\n", bad);
@@ -213,7 +235,7 @@ int main(int argc, char** argv) {
             static char* dflush = nullptr;
             const size_t FLUSH = (size_t)768 << 20;   // > L2 + Infinity Cache
             if (!dflush) CHECK(hipMalloc(&dflush, FLUSH));
-            const int tiles[] = {70, 73, 76};
+            const int tiles[] = {70, 72, 73};
             for (int tile : tiles) {
                 auto run = [&]() { return ezdit_test_resid(tile, dA, K, dW, K, db, dh, dg, dz, dout, dzu, N, dzs, M, N, K, st); };
                 char name[64]; snprintf(name, sizeof name, "EPI_RESID un-split tile %d", tile);
