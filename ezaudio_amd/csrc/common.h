@@ -60,6 +60,13 @@ __device__ __forceinline__ unsigned long long ez_stamp_start() {
 inline unsigned ez_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 __device__ __forceinline__ int ez_div(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
 
+// Kernel-argument batch of a GEMM prologue (k_gemm_pp, k_gemm_co, k_gemm_ks):  int lda = a.lda;  asm("" : "+s"(lda) : "s"(a.A), "s"(a.W), ...);  makes hipcc
+// request every listed argument BEFORE the first use of `lda` (a non-volatile asm that "modifies" it and reads the others).  Left alone, hipcc sinks each scalar load towards its first use and the prologue
+// walks a chain of serialised kernarg round trips in front of its first LDS-DMA.  NOT `asm volatile`: hipcc treats that as a possible store, and the device
+// step counter's load behind it (GemmArgs.cur_step: global memory) turned from a scalar load into a VECTOR load with `s_waitcnt vmcnt(0)` right behind it
+// (ISA of the first round-6 build); an inline-asm s_load for the counter is no way out either -- the allocator copied its destination before the tied wait
+// (`s_mov_b32 s20, s53`: tests/test_host.py::test_step_counter_scalar_load_is_not_touched_before_its_wait was written for it and caught it).
+
 int ez_fail(int code, const char* fmt, ...);   // api.hip: record the message behind ezdit_last_error(), return code
 
 // ------------------------------------------------------------------------------------------

@@ -40,15 +40,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
     static_assert(NP < 32, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // (kernel arguments of the prologue in one batch: see k_gemm_pp)
-    asm volatile("" ::"s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn),
-                 "s"(a.bz), "s"(a.cur_step), "s"(a.ts), "s"(a.row_slot));
+    // (kernel arguments of the prologue in one batch, then the step counter as a plain scalar load: see k_gemm_pp)
+    int M_ = a.M;
+    asm("" : "+s"(M_) : "s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn), "s"(a.bz),
+        "s"(a.cur_step), "s"(a.ts), "s"(a.row_slot), "s"(a.mbm), "s"(a.mbn), "s"(a.msplit));
+    const int slot0 = a.cur_step ? *a.cur_step : 0;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave;
 
-    const int tilesM = (a.M + BM - 1) / BM;
+    const int tilesM = (M_ + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     int tm, tn, z;
     if (!tile_of_block(a, tilesM, tilesN, tm, tn, z)) return;
@@ -59,7 +61,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
     const int nt = ke - kb;
 
     constexpr bool ZM = (VAR & 64) != 0 && (EPI == EPI_GEGLU || EPI == EPI_QKV);
-    const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed for the G' / C' address below
     float2* zrow = reinterpret_cast<float2*>(smem + 2 * STAGE);           // [BM] (mu, r) of this tile's rows
     float* zgc = reinterpret_cast<float*>(smem + 2 * STAGE + BM * 8);     // [2][BN]: G' | C' of this tile's columns (shared modulation slot only)
     // LayerNorm algebra, consumer side (as in k_gemm_pp): partial statistics of the tile's rows (four threads per row, part-major table; a thread serves

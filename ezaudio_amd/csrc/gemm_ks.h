@@ -111,13 +111,15 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // device step counter (selects the modulation slot of gate / gain): ONE SCALAR load, issued first thing and waited for (lgkmcnt) right
-    // in front of the operand requests -- as a vector load it shared the vmcnt queue with the LDS-DMA and drained it
+    // the kernel arguments the prologue needs in ONE batch (common.h "Kernel-argument batch"), then the device step counter (selects the modulation slot of
+    // gate / gain) as a plain scalar load: used right in front of the operand requests, behind the first chunk's LDS-DMA.  (Round 5 issued it by inline asm
+    // under `if (a.cur_step)`: ADVICE r05 -- a phi with 0 may become a copy of a register that has not been written yet.)
+    int M_ = a.M;
+    asm("" : "+s"(M_) : "s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.N), "s"(a.K), "s"(a.pm), "s"(a.bn), "s"(a.cur_step), "s"(a.ts), "s"(a.ts_cap),
+        "s"(a.row_slot), "s"(a.bias), "s"(a.resid), "s"(a.ldr), "s"(a.gate), "s"(a.zg));
     int slot0 = 0;
-    if constexpr (EPI == EPI_RESID) {
-        if (a.cur_step) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(slot0) : "s"(a.cur_step) : "memory");
-    }
-    const int tilesM = (a.M + BM - 1) / BM;
+    if constexpr (EPI == EPI_RESID) slot0 = a.cur_step ? *a.cur_step : 0;
+    const int tilesM = (M_ + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     int tm, tn;
     if (!ks_tile_of_block(a, tilesM, tilesN, tm, tn)) return;
@@ -197,7 +199,6 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     int brow = 0;              // ... its batch element
     __builtin_amdgcn_sched_barrier(0);
     {
-        if constexpr (EPI == EPI_RESID) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(slot0));
         const float* bsrc = a.bias ? a.bias : reinterpret_cast<const float*>(a.W);   // null bias: any valid address, the value is dropped below
         const float* gsrc = nullptr;
         const float* zsrc = nullptr;

@@ -783,10 +783,13 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     constexpr int P0 = SCHED == 1 ? (NP + 1) / 2 : NP;   // group 0's pieces of a tile: [0, P0); group 1: [P0, NP) (SCHED 2: the issuing group takes all)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    // the kernel arguments the prologue needs, requested in ONE batch at the top: left alone, hipcc sinks each scalar load towards its first use and the prologue
-    // walks a chain of serialised kernarg round trips in front of the first LDS-DMA (ISA of the round-6 fused-QKV kernel: five more than round 5's, +1.1K cycles)
-    asm volatile("" ::"s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn),
-                 "s"(a.bz), "s"(a.cur_step), "s"(a.ts), "s"(a.xcd_panel), "s"(a.row_slot));
+    // the kernel arguments the prologue needs, requested in ONE batch in front of the tile map (common.h "Kernel-argument batch"), then the device step
+    // counter as a plain (scalar) load: nothing in front of the first LDS-DMA waits on the scalar-memory counter again, so its round trip runs under the
+    // tile map, the address arithmetic and the first K tile
+    int M_ = a.M;
+    asm("" : "+s"(M_) : "s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn), "s"(a.bz),
+        "s"(a.cur_step), "s"(a.ts), "s"(a.xcd_panel), "s"(a.row_slot), "s"(a.mbm), "s"(a.mbn), "s"(a.msplit), "s"(a.mG));
+    const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: needed from z_late_load on
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -795,7 +798,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     const int wt = SCHED == 1 ? wave : wg;     // position among the waves that tile the block
     const int wm = wt / WN, wn = wt % WN;
 
-    const int tilesM = (a.M + BM - 1) / BM;
+    const int tilesM = (M_ + BM - 1) / BM;
     const int tilesN = (a.N + BN - 1) / BN;
     int tm, tn, z;
     if (EPI == EPI_PARTIAL && a.xcd_panel) {
@@ -811,7 +814,6 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 
     // VAR & 64 ("ZM"): EPI_GEGLU / EPI_QKV finish a LayerNorm in their epilogue (GemmArgs.z*, consumer side)
     constexpr bool ZM = (VAR & 64) != 0;
-    const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: scalar load, needed in the epilogue only
     float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
     // LayerNorm algebra, consumer side: the partial statistics of the tile's rows (four threads per row, part-major table) and the G' / C'
     // slices of the tile's columns (one float4 per thread) are requested right BEHIND the first K tile's LDS-DMA (z_late_load), waited for together

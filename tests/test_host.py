@@ -515,6 +515,57 @@ def test_k_split_kernel_counts_exactly_its_operand_loads_behind_the_prologue_dma
     assert checked >= 8, checked
 
 
+def test_step_counter_scalar_load_is_not_touched_before_its_wait():
+    """The device step counter must be ONE SCALAR load (`s_load_dword`, base not the kernarg pointer s[0:1]) whose destination nothing names before an
+    `s_waitcnt` with lgkmcnt(0) -- along every path (control-flow aware).  History: round 5 requested it by inline asm under `if (a.cur_step)` (the
+    compiler believes an asm output to be defined at once, so a copy the allocator inserts moves a value that has not arrived); the first round-6 build made
+    the request unconditional and this test caught `s_mov_b32 s20, s53` between request and wait; since then it is a plain C++ load behind a NON-volatile
+    kernel-argument batch (common.h) -- behind an `asm volatile` hipcc turns it into a vector load with `s_waitcnt vmcnt(0)` in front of the first LDS-DMA."""
+    import re
+    funcs = _gfx950_isa('gemm.hip')
+    checked = 0
+    for name, f in funcs.items():
+        if not re.search(r'k_gemm_(pp|ks|co)I', name):
+            continue
+        lines = [l.strip().split(';')[0].strip() for l in f.splitlines()]
+        lines = [l for l in lines if l and not l.startswith(('.p2align', '.long', '.byte', '.section', '.set', '.size', '.type', '.globl', '.amdhsa', '.end_amdhsa', '.text'))]
+        req = [(i, m.group(1)) for i, l in enumerate(lines) if (m := re.match(r's_load_dword (s\d+), s\[(?!0:1\])\d+:\d+\], 0x0$', l))]
+        if not req:   # instantiations that do not use the modulation slot: the load is dead code
+            continue
+        assert len(req) == 1, (name, req)
+        start, reg = req[0]
+        pat = re.compile(r'\b%s\b' % reg)
+        pending_in = {}
+        for _ in range(8):
+            pending, new_in = False, {}
+            for i, ins in enumerate(lines):
+                m = re.match(r'(\.LBB\d+_\d+):', ins)
+                if m:
+                    pending = pending or pending_in.get(m.group(1), False)
+                    continue
+                if i == start:
+                    pending = True
+                    continue
+                op = ins.split()[0]
+                if op == 's_waitcnt' and 'lgkmcnt(0)' in ins:
+                    pending = False
+                    continue
+                if pending:
+                    assert not pat.search(ins.split(None, 1)[1] if ' ' in ins else ''), f'{name}: {ins!r} touches {reg} before its wait'
+                if op == 's_branch' or op.startswith('s_cbranch'):
+                    tgt = ins.split()[-1]
+                    new_in[tgt] = new_in.get(tgt, False) or pending
+                    if op == 's_branch':
+                        pending = False
+                if op == 's_endpgm':
+                    pending = False
+            if new_in == pending_in:
+                break
+            pending_in = new_in
+        checked += 1
+    assert checked >= 12, checked
+
+
 def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     """k_gemm_pp, k_gemm_ks and k_attn issue their MFMAs from inline asm, so hipcc's hazard recogniser neither sees them nor pads behind them
     (round-3 ADVICE): the wait states between the LAST MFMA of an accumulation chain and the first non-MFMA read of its accumulator are
