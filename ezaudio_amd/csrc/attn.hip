@@ -86,6 +86,11 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     constexpr int ZX = ZQ ? 64 * 8 + 2 * DQK * 4 : 0;   // fused projection with the LayerNorm algebra: (mu, r) of the 64 query rows + G' | C' of the head
     __shared__ __attribute__((aligned(16))) char smem[SMEM + ZX];
 
+    // kernel arguments in ONE batch (common.h "Kernel-argument batch": left alone, hipcc requests them in four dependent groups in front of the first load)
+    int Lq_ = a.Lq;
+    asm("" : "+s"(Lq_) : "s"(a.q), "s"(a.k), "s"(a.v), "s"(a.kmask), "s"(a.out), "s"(a.ldo), "s"(a.B), "s"(a.H), "s"(a.Lk), "s"(a.Lqp), "s"(a.Lkp), "s"(a.xu), "s"(a.ldu),
+        "s"(a.xw), "s"(a.ldw), "s"(a.xw_rows), "s"(a.xK), "s"(a.xcd_map), "s"(a.nq), "s"(a.ppx), "s"(a.mnq), "s"(a.mH), "s"(a.q_raw), "s"(a.ts), "s"(a.xk2), "s"(a.zstat_in),
+        "s"(a.zs_stride), "s"(a.zparts));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
