@@ -175,6 +175,9 @@ struct ezdit_handle {
     // cross-attention q projection: two K tiles per ring slot, barrier and counted wait (a wave's work per K tile is 3 MFMAs: the loop is its
     // fixed cost per iteration).  Bit-identical; XL 4.319 -> 4.285 ms/step (+0.8 %), L +1.1 %.
     int opt_attn_xk2 = 1;
+    // fused cross-attention with the LayerNorm algebra: query rows per workgroup (attn.hip k_attn QT): 0 = 32 when the 64-row grid is <= 128 workgroups (one prompt with the
+    // single-key shortcut: 256 workgroups of 32 rows instead of 128 of 64), 64 / 32 = always
+    int opt_attn_qtile = 0;
     int opt_cn_overlap = 1;                                                               // fused sampler: ControlNet branch on a side stream, concurrent with the backbone's in-blocks
     hipStream_t cn_stream = nullptr; hipEvent_t cn_fork = nullptr, cn_join = nullptr;
     int opt_row_variant = 1;                                                              // row kernel: 0 = one workgroup per row, 1 = one wave per row
@@ -973,7 +976,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     const bool zf = h->z_tables_ready && h->zfuse_usable();
     // eb0 / enb: the launch covers the batch elements [eb0, eb0 + enb) only (enb < 0: all); dual_blk >= 0: DUAL form for block dual_blk (GemmArgs.zd)
     auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
-                       const float* zg, long zg_stride, int eb0 = 0, int enb = -1, int dual_blk = -1) {
+                       const float* zg, long zg_stride, const char* what, int eb0 = 0, int enb = -1, int dual_blk = -1) {
         const long r0 = (long)eb0 * h->L;
         const int Ms = enb < 0 ? M : enb * h->L;
         GemmArgs g;
@@ -993,7 +996,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             g.act_row0 = h->act_b0 * h->L; g.act_row1 = h->act_b1 * h->L;
         }
         g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
-        c.launched("k_gemm (un-split residual)", launch_gemm(g, st));
+        c.launched(what, launch_gemm(g, st));
         u_is_z = true;
     };
     // single-key shortcut (opt_xkey1): cross-attention + its out-projection cover the batch elements [xb0, xb0 + xnb) only
@@ -1017,7 +1020,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            if (zf) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot);
+            if (zf) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot, "k_gemm (un-split residual: skip_linear)");
             else resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
@@ -1056,7 +1059,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         STOPCHK();
         // x += (1 - gate_msa) * (proj + bias); then norm2 (plain affine LN) for cross-attention q
         if (zf) {
-            resid_z(at.out, h->ldD, w.wo, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, 0, 0, -1, x1 ? b : -1);
+            resid_z(at.out, h->ldD, w.wo, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, 0, x1 ? "k_gemm (un-split residual: attention-out DUAL)" : "k_gemm (un-split residual: attention-out)", 0, -1, x1 ? b : -1);
         } else {
             resid(at.out, h->ldD, w.wo, 1, hcur, hA, w.bo, modv(b, 2), mod_slot, w.n2w, w.n2b, 0, nullptr, nullptr, h->ldD);
         }
@@ -1080,7 +1083,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             if (fuse_q2) {
                 at.xu = u; at.ldu = h->ldD; at.xw = w.wq2.W; at.ldw = w.wq2.ld;
                 at.xw_rows = w.wq2.rows; at.xK = at.ldw;
-                at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2;
+                at.qn_w = hn.qn_w; at.qn_b = hn.qn_b; at.nkh = 4; at.xk2 = h->opt_attn_xk2; at.qtile = h->opt_attn_qtile;
 #ifdef EZ_DIAG
                 if (!u_is_z && h->opt_zfake && (D + h->zwidth() - 1) / h->zwidth() <= Z_MAXP) {
                     at.zw = h->zwidth(); at.zstat_in = h->buf<float2>("zneutral"); at.zs_stride = h->Mp; at.zparts = (D + at.zw - 1) / at.zw; at.zD = D; at.zeps = 1e-5f;
@@ -1114,7 +1117,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             STOPCHK();
             if (zf) {
                 at.zstat_in = nullptr;
-                resid_z(at.out, h->ldD, w.wo2, hA, hA, w.bo2, nullptr, 0, modv(b, 3), mod_slot, xb0, x1 ? xnb : -1);
+                resid_z(at.out, h->ldD, w.wo2, hA, hA, w.bo2, nullptr, 0, modv(b, 3), mod_slot, "k_gemm (un-split residual: cross-out)", xb0, x1 ? xnb : -1);
             } else {
                 resid(at.out, h->ldD, w.wo2, 1, hA, hA, w.bo2, nullptr, 0, modv(b, 3), modv(b, 4), mod_slot, nullptr, nullptr, h->ldD);
             }
@@ -1140,7 +1143,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
-            if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot);
+            if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot, "k_gemm (un-split residual: MLP-out)");
             else resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
@@ -1497,6 +1500,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     else if (!strcmp(name, "epi_lds")) h->opt_epi_lds = value;
     else if (!strcmp(name, "attn_xk2")) h->opt_attn_xk2 = value;
     else if (!strcmp(name, "attn_nkh")) h->opt_attn_nkh = value;
+    else if (!strcmp(name, "attn_qtile")) h->opt_attn_qtile = value;
     else if (!strcmp(name, "cn_overlap")) h->opt_cn_overlap = value;
     else if (!strcmp(name, "fuse_q2")) h->opt_fuse_q2 = value;
     else if (!strcmp(name, "q2_pp")) h->opt_q2_pp = value;

@@ -56,8 +56,14 @@ struct HeadGeom<72> { static constexpr int DQK = 80, DV = 96; };
 // softmax VALU work never overlaps MFMAs) and half the tile-loop trips; needs Lkp % 128 == 0.
 // ZQ: the fused projection finishes a LayerNorm in its epilogue (LayerNorm algebra, AttnArgs.z*): a template switch so that the plain kernel
 // carries neither the registers nor the code
-template <int DH, int NKH, bool ZQ = false>
+// QT = query rows per workgroup: 64, or 32 (the fused-projection form only, round 6): the projection is what a cross-attention launch spends its time on, and
+// it is bound by what ONE CU can keep in flight -- 32-row tiles give every CU a workgroup at one prompt (256 instead of 128), 22 % fewer operand bytes
+// per workgroup ((32 + 80) instead of (64 + 80) rows per K tile) and a ring of FOUR double stages (six K tiles in flight instead of four).  All eight
+// waves split K in the projection (one 16-wide k-step of a double stage each); the attention proper runs on waves 0 - 3 (one query sub-block x 4 key sub-blocks)
+template <int DH, int NKH, bool ZQ = false, int QT = 64>
 __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
+    static_assert(QT == 64 || (QT == 32 && NKH == 4), "32-query tiles: the 8-wave fused-projection form only");
+    constexpr int NQS = QT / 32;   // query sub-blocks (of 32 rows) per workgroup
     constexpr int NT = 128 * NKH;
     constexpr int TK = 32 * NKH;   // keys per staged tile
     constexpr int DQK = HeadGeom<DH>::DQK;
@@ -80,10 +86,11 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                                               // below, so their LDS rows may hold anything (an MFMA output column depends on its own W row only) --
                                               // 10 instead of 12 DMA pieces per K tile at head_dim 72
     constexpr int DS = DQK;                   // columns kept of each partial
-    constexpr int PSTAGE = (64 + DN) * 128, PRING = 6 * PSTAGE;   // 3 ring slots of TWO K tiles each (a.xk2) or 3 of one
-    constexpr int PRED = 4 * 64 * DS * 4, PQS = 64 * DQK * 2;
+    constexpr int NRS = QT == 64 ? 3 : 4;                                   // ring slots of the projection
+    constexpr int PSTAGE = (QT + DN) * 128, PRING = 2 * NRS * PSTAGE;       // ring slots of TWO K tiles each (a.xk2; QT = 64 without it: 3 of one)
+    constexpr int PRED = 4 * 64 * DS * 4, PQS = QT * DQK * 2;               // partial tiles: [4][64][DS] or [8][32][DS] fp32
     constexpr int SMEM = NKH == 4 ? (2 * BUF > PRED + PQS ? (2 * BUF > PRING ? 2 * BUF : PRING) : (PRED + PQS > PRING ? PRED + PQS : PRING)) : 2 * BUF;
-    constexpr int ZX = ZQ ? 64 * 8 + 2 * DQK * 4 : 0;   // fused projection with the LayerNorm algebra: (mu, r) of the 64 query rows + G' | C' of the head
+    constexpr int ZX = ZQ ? QT * 8 + 2 * DQK * 4 : 0;   // fused projection with the LayerNorm algebra: (mu, r) of the 64 query rows + G' | C' of the head
     __shared__ __attribute__((aligned(16))) char smem[SMEM + ZX];
 
     // kernel arguments in ONE batch (common.h "Kernel-argument batch": left alone, hipcc requests them in four dependent groups in front of the first load)
@@ -94,7 +101,8 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int qs = wave & 1, kh = wave >> 1;   // kh in [0, NKH)
+    const int qs = QT == 64 ? (wave & 1) : 0, kh = QT == 64 ? (wave >> 1) : (wave & 3);   // kh in [0, NKH)
+    const bool active = QT == 64 || __builtin_amdgcn_readfirstlane(wave) < 4;                   // 32-query tiles: waves 4 - 7 only project, stage and merge
     const int r32 = lane & 31, hi = lane >> 5;
     // workgroup -> (query tile, head, batch).  XCD-aware form: the dispatcher deals workgroup i to XCD i % 8, so XCD x gets the
     // ppx consecutive (batch, head) pairs [x * ppx, (x + 1) * ppx) with ALL their query tiles: a pair's K / V^T (and, in the fused
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     } else {
         qt = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
     }
-    const int q0 = qt * 64 + qs * 32;
+    const int q0 = qt * QT + qs * 32;
     const long bh = (long)b * a.H + h;
     unsigned long long* ts = (a.ts && tid < 64) ? a.ts + 8 * (long)blockIdx.x : nullptr;
     if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = ez_stamp_start(); }   // [6], [7]: 100 MHz device-wide clock
@@ -123,24 +131,113 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     bf16x8 qf[NKS];
     if (NKH == 4 && a.xu) {
         if constexpr (NKH == 4) {
-            // ---- phase 1: Q_raw[64][dh] = X[64 rows][K] . W_h[dh][K]^T.  wave = (mh, kq): rows 32 mh.., k-step kq of every K tile
+            // ---- phase 1: Q_raw[QT][dh] = X[QT rows][K] . W_h[dh][K]^T.  QT = 64: wave = (mh, kq): rows 32 mh.., k-step kq of every K tile;
+            // QT = 32: wave = k-step (wave & 3) of K tile (wave >> 2) of every double stage
             constexpr int FN = DN / 32;
-            const int mh = wave & 1, kq = wave >> 1;
+            constexpr int NPART = QT == 64 ? 4 : 8;   // partial tiles summed in phase 1b
             const int rowb = b * a.Lq;
-            // LayerNorm algebra: the partial statistics of the 64 operand rows of this tile (the first 256 threads: FOUR threads per row, thread pg takes the
+            // LayerNorm algebra: the partial statistics of the QT operand rows of this tile (the first 4 QT threads: FOUR threads per row, thread pg takes the
             // parts pg, pg + 4, pg + 8 of the part-major table: a wave's load covers 16 rows x 4 parts = four contiguous 128-byte runs) and G' | C' of this head's columns (one float4 per thread of wave 1) are requested right behind
             // the first two K tiles, land under the projection's K loop, and are merged / parked in LDS behind the loop's last barrier; used in phase 1b
-            float2* zrow_l = reinterpret_cast<float2*>(smem + SMEM);            // [64] (mu, r)
-            float* zgc_l = reinterpret_cast<float*>(smem + SMEM + 64 * 8);      // [2][DQK] G' | C'
+            float2* zrow_l = reinterpret_cast<float2*>(smem + SMEM);            // [QT] (mu, r)
+            float* zgc_l = reinterpret_cast<float*>(smem + SMEM + QT * 8);      // [2][DQK] G' | C'
             ZStatRegs zst;
             float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
-            uint32_t aoff[1], boff[(DW * 8 + NT - 1) / NT];
-            stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
-            stage_offsets<DW, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
             const char* gA = reinterpret_cast<const char*>(a.xu);
             const char* gW = reinterpret_cast<const char*>(a.xw);
             const int nt = a.xK / 64;
+            auto z_request = [&]() {
+                if constexpr (ZQ) {
+                    if (tid < 4 * QT) {   // four threads per row
+                        int qr = qt * QT + (tid >> 2);
+                        qr = qr < a.Lq ? qr : a.Lq - 1;
+                        z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, tid & 3, zst);
+                    }
+                    if (tid < 2 * (DH / 4)) {
+                        const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
+                        zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + h * DH + 4 * t4);
+                    }
+                }
+            };
+            f32x16 acc[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            if constexpr (QT == 32) {
+                // a K tile's LDS image: rows [32 of x | DW of W_h], 128 B each, as ONE run of (32 + DW) x 8 16-byte chunks dealt to the threads in two passes:
+                // pass 0 = chunks [0, 512) (waves 0 - 3: the x rows, waves 4 - 7: W rows 0 .. 31), pass 1 = chunks [512, (32 + DW) 8) (W rows 32 ..; waves 0 .. NW1 - 1)
+                constexpr int NCH = (32 + DW) * 8, NW1 = (NCH - NT) / 64;   // waves with a second piece per K tile
+                static_assert(NCH > NT && NCH <= 2 * NT && (NCH - NT) % 64 == 0, "two passes, whole waves");
+                uint32_t off0, off1;
+                {
+                    const int row = tid >> 3, c = tid & 7;   // chunk tid: row [0, 64)
+                    if (row < 32) {
+                        int grow = rowb + qt * 32 + row;
+                        grow = grow < rowb + a.Lq - 1 ? grow : rowb + a.Lq - 1;
+                        off0 = (uint32_t)(grow * a.ldu + ((c ^ ((row >> 1) & 7)) << 3)) * 2u;
+                    } else {
+                        const int r2 = row - 32;
+                        int gr = h * DH + r2;
+                        gr = gr < a.xw_rows - 1 ? gr : a.xw_rows - 1;
+                        off0 = (uint32_t)(gr * a.ldw + ((c ^ ((r2 >> 1) & 7)) << 3)) * 2u;
+                    }
+                    const int r2 = (tid >> 3) + 32;           // chunk 512 + tid: W row 32 + (tid >> 3)
+                    int gr = h * DH + r2;
+                    gr = gr < a.xw_rows - 1 ? gr : a.xw_rows - 1;
+                    off1 = (uint32_t)(gr * a.ldw + ((c ^ ((r2 >> 1) & 7)) << 3)) * 2u;
+                }
+                const char* g0 = wave_u < 4 ? gA : gW;      // wave-uniform base of pass 0
+                const bool two = wave_u < NW1;
+                auto stage2 = [&](int sidx) {                // double stage sidx = K tiles 2 sidx, 2 sidx + 1 -> ring slot sidx % NRS
+                    char* dst = smem + (sidx % NRS) * 2 * PSTAGE + wave_u * 1024;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub) {
+                        const long ko = (long)(2 * sidx + sub) * 128;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g0 + ko + off0),
+                                                         (__attribute__((address_space(3))) void*)(dst + sub * PSTAGE), 16, 0, 0);
+                        if (two)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gW + ko + off1),
+                                                             (__attribute__((address_space(3))) void*)(dst + sub * PSTAGE + NT * 16), 16, 0, 0);
+                    }
+                };
+                const int ns = nt >> 1;                      // (launch_attention: the 32-query form needs an even number of K tiles)
+                stage2(0);
+                z_request();   // behind the first double stage: the first counted wait below covers them
+                if (ns > 1) stage2(1);
+                if (ns > 2) stage2(2);
+                const int sub = wave_u >> 2, kq = wave_u & 3;
+                const uint32_t fo = r32 * 128 + (((2 * kq + hi) ^ ((r32 >> 1) & 7)) << 4);
+                for (int sidx = 0; sidx < ns; ++sidx) {
+                    // stage sidx landed: at most the (up to two) younger stages of this wave stay in flight, 2 or 4 pieces each
+                    const int younger = ns - 1 - sidx < NRS - 2 ? ns - 1 - sidx : NRS - 2;
+                    if (two) {
+                        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        if (younger >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else if (younger == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    if (sidx + NRS - 1 < ns) stage2(sidx + NRS - 1);   // into the slot read in iteration sidx - 1: every wave is past those reads (its MFMAs consumed them before this barrier)
+                    const char* cT = smem + (sidx % NRS) * 2 * PSTAGE + sub * PSTAGE;
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(cT + fo);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(cT + 32 * 128 + fo + j * 4096);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr, af, acc[j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[j]));
+                }
+            } else {
+            const int mh = wave & 1, kq = wave >> 1;
+            uint32_t aoff[1], boff[(DW * 8 + NT - 1) / NT];
+            stage_offsets<64, NT>(aoff, a.ldu, rowb + qt * 64, rowb + a.Lq - 1, tid);
+            stage_offsets<DW, NT>(boff, a.ldw, h * DH, a.xw_rows - 1, tid);
             auto stage = [&](int t) {
                 char* dst = smem + (t % 3) * PSTAGE + wave_u * 1024;
                 stage_tile<64, NT>(gA + (long)t * 128, aoff, dst, tid);
@@ -151,22 +248,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
             stage(0);
             if (nt > 1) stage(1);
             // (behind the first two tiles: the requests overlap the first tile's wait; they only make the first counted wait below marginally stricter)
-            if constexpr (ZQ) {
-                if (tid < 256) {   // four threads per row
-                    int qr = qt * 64 + (tid >> 2);
-                    qr = qr < a.Lq ? qr : a.Lq - 1;
-                    z_row_stats_load(a.zstat_in + (rowb + qr), a.zs_stride, a.zparts, tid & 3, zst);
-                }
-                if (tid < 2 * (DH / 4)) {
-                    const int which = tid >= DH / 4, t4 = tid - which * (DH / 4);
-                    zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + h * DH + 4 * t4);
-                }
-            }
-            f32x16 acc[FN];
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+            z_request();
             const uint32_t fo = r32 * 128 + (((2 * kq + hi) ^ ((r32 >> 1) & 7)) << 4);
             if (a.xk2 && (nt & 1) == 0) {
                 // double-width stages: one barrier and one counted wait per TWO K tiles (128 of K).  The per-tile work of a wave is 3 MFMAs, so
@@ -221,10 +303,11 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[j]));
             }
+            }
 #pragma unroll
             for (int j = 0; j < FN; ++j) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[j]));
             if constexpr (ZQ) {   // behind the two barriers below: read in phase 1b
-                if (tid < 256) {
+                if (tid < 4 * QT) {
                     const float2 mr = z_row_stats_finish(zst, a.zparts, tid & 3, a.zD, a.zeps);
                     if ((tid & 3) == 0) zrow_l[tid >> 2] = mr;
                 }
@@ -234,20 +317,23 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
                 }
             }
             __syncthreads();   // the ring is dead: it becomes the reduction area
-            // lane owns row 32 mh + r32 and columns 32 j + 8 g + 4 hi + {0..3}
-            float* red = reinterpret_cast<float*>(smem);   // [kq][64][DS]
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int col = 32 * j + 8 * g + 4 * hi;
-                    if (col < DS)
-                        *reinterpret_cast<float4*>(red + ((kq * 64 + 32 * mh + r32) * DS + col)) =
-                            make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
-                }
-            __syncthreads();
-            // ---- phase 1b: sum the 4 partials, per-head LayerNorm (attention.py:141), bf16 -> Qs[64][DQK]; 8 threads per row
+            // lane owns row prow and columns 32 j + 8 g + 4 hi + {0..3} of partial pw
+            float* red = reinterpret_cast<float*>(smem);   // [NPART][QT][DS]
             {
+                const int pw = QT == 64 ? (wave >> 1) : wave, prow = QT == 64 ? 32 * (wave & 1) + r32 : r32;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = 32 * j + 8 * g + 4 * hi;
+                        if (col < DS)
+                            *reinterpret_cast<float4*>(red + ((pw * QT + prow) * DS + col)) =
+                                make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+                    }
+            }
+            __syncthreads();
+            // ---- phase 1b: sum the NPART partials (fixed order), per-head LayerNorm (attention.py:141), bf16 -> Qs[QT][DQK]; 8 threads per row
+            if (QT == 64 || tid < 8 * QT) {
                 constexpr int CP = DH / 8;   // columns per thread
                 bf16_t* qs_l = reinterpret_cast<bf16_t*>(smem + PRED);
                 const int row = tid >> 3, part = tid & 7;
@@ -258,8 +344,15 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < CP; ++e) {
                     const int col = part * CP + e;
-                    v[e] = red[(0 * 64 + row) * DS + col] + red[(1 * 64 + row) * DS + col] + red[(2 * 64 + row) * DS + col] +
-                           red[(3 * 64 + row) * DS + col];
+                    if constexpr (QT == 64) {
+                        v[e] = red[(0 * 64 + row) * DS + col] + red[(1 * 64 + row) * DS + col] + red[(2 * 64 + row) * DS + col] +
+                               red[(3 * 64 + row) * DS + col];
+                    } else {
+                        float t = red[row * DS + col];
+#pragma unroll
+                        for (int w = 1; w < NPART; ++w) t += red[(w * QT + row) * DS + col];
+                        v[e] = t;
+                    }
                     if constexpr (ZQ) v[e] = fmaf(zr, v[e], fmaf(-zr * zmu, zgc_l[col], zgc_l[DQK + col]));
                     s1 += v[e];
                 }
@@ -411,7 +504,7 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
         const char* vb = kb + KBYTES;
         const char* vtr = vb + (32 * kh + 4 * hi + ((lane & 15) >> 2)) * VSTR + ((lane & 16) + 4 * (lane & 3)) * 2;   // this lane's corner of the transposing reads
         const int key0 = t * TK + kh * 32;
-        if (key0 < a.Lk) {  // wave-uniform: the whole 32-key sub-tile may lie beyond Lk
+        if (active && key0 < a.Lk) {  // wave-uniform: the whole 32-key sub-tile may lie beyond Lk (32-query tiles: waves 4 - 7 only stage)
             // validity of this wave's 32 keys as one bit mask (bit j <-> key0 + j), built BEFORE the MFMAs
             const int kidx = key0 + r32;
             bool kv = kidx < a.Lk;
@@ -524,16 +617,18 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
 #pragma unroll
     for (int tt = 0; tt < NDT; ++tt) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(o[tt]));
     constexpr int NG = DH / 8;                                        // column groups: G <-> d = 8 G + 4 hi + {0..3} = (tt = G / 4, g = G % 4)
-    constexpr int NW = 2 * NKH;
-    float4* xo = reinterpret_cast<float4*>(smem);                      // [NKH][qs][NG][64 lanes]
-    float* xml = reinterpret_cast<float*>(smem + NKH * 2 * NG * 64 * 16);   // [NKH][qs][2][32]
-    static_assert(SMEM >= NKH * 2 * NG * 64 * 16 + NKH * 2 * 2 * 32 * 4, "exchange area must fit the staging buffers");
+    constexpr int NW = 2 * NKH;                                        // waves of the workgroup: all of them merge and store
+    float4* xo = reinterpret_cast<float4*>(smem);                      // [NKH][NQS][NG][64 lanes]
+    float* xml = reinterpret_cast<float*>(smem + NKH * NQS * NG * 64 * 16);   // [NKH][NQS][2][32]
+    static_assert(SMEM >= NKH * NQS * NG * 64 * 16 + NKH * NQS * 2 * 32 * 4, "exchange area must fit the staging buffers");
+    if (active) {
 #pragma unroll
-    for (int G = 0; G < NG; ++G)
-        xo[((kh * 2 + qs) * NG + G) * 64 + lane] = make_float4(o[G / 4][4 * (G % 4)], o[G / 4][4 * (G % 4) + 1], o[G / 4][4 * (G % 4) + 2], o[G / 4][4 * (G % 4) + 3]);
-    if (hi == 0) {
-        xml[((kh * 2 + qs) * 2 + 0) * 32 + r32] = m;
-        xml[((kh * 2 + qs) * 2 + 1) * 32 + r32] = lsum;
+        for (int G = 0; G < NG; ++G)
+            xo[((kh * NQS + qs) * NG + G) * 64 + lane] = make_float4(o[G / 4][4 * (G % 4)], o[G / 4][4 * (G % 4) + 1], o[G / 4][4 * (G % 4) + 2], o[G / 4][4 * (G % 4) + 3]);
+        if (hi == 0) {
+            xml[((kh * NQS + qs) * 2 + 0) * 32 + r32] = m;
+            xml[((kh * NQS + qs) * 2 + 1) * 32 + r32] = lsum;
+        }
     }
     __syncthreads();
     if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
@@ -542,10 +637,10 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     {
         float mk[NKH], mm = -1e30f;
 #pragma unroll
-        for (int k = 0; k < NKH; ++k) { mk[k] = xml[((k * 2 + qs) * 2 + 0) * 32 + r32]; mm = fmaxf(mm, mk[k]); }
+        for (int k = 0; k < NKH; ++k) { mk[k] = xml[((k * NQS + qs) * 2 + 0) * 32 + r32]; mm = fmaxf(mm, mk[k]); }
         float l = 0.f;
 #pragma unroll
-        for (int k = 0; k < NKH; ++k) { wgt[k] = __builtin_amdgcn_exp2f(mk[k] - mm); l = fmaf(xml[((k * 2 + qs) * 2 + 1) * 32 + r32], wgt[k], l); }
+        for (int k = 0; k < NKH; ++k) { wgt[k] = __builtin_amdgcn_exp2f(mk[k] - mm); l = fmaf(xml[((k * NQS + qs) * 2 + 1) * 32 + r32], wgt[k], l); }
         const float inv = 1.f / l;
 #pragma unroll
         for (int k = 0; k < NKH; ++k) wgt[k] *= inv;
@@ -553,13 +648,13 @@ __global__ __launch_bounds__(128 * NKH) void k_attn(AttnArgs a) {
     const int qrow = q0 + r32;
     bf16_t* orow = a.out + ((long)b * a.Lq + (qrow < a.Lq ? qrow : a.Lq - 1)) * a.ldo + h * DH + 4 * hi;
 #pragma unroll
-    for (int i = 0; i < (2 * NG + NW - 1) / NW; ++i) {
-        const int G = (wave + i * NW) >> 1;   // item = wave + i NW = 2 G + qs
+    for (int i = 0; i < (NQS * NG + NW - 1) / NW; ++i) {
+        const int G = (wave + i * NW) / NQS;   // item = wave + i NW = NQS G + qs
         if (G < NG) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < NKH; ++k) {
-                const float4 v = xo[((k * 2 + qs) * NG + G) * 64 + lane];
+                const float4 v = xo[((k * NQS + qs) * NG + G) * 64 + lane];
                 acc.x = fmaf(v.x, wgt[k], acc.x); acc.y = fmaf(v.y, wgt[k], acc.y); acc.z = fmaf(v.z, wgt[k], acc.z); acc.w = fmaf(v.w, wgt[k], acc.w);
             }
             if (qrow < a.Lq) {
@@ -593,20 +688,29 @@ int launch_attention(const AttnArgs& a0, hipStream_t st) {
         if (a.zstat_in) a.zstat_in += b0 * a.Lq;
         a.b0 = 0;
     }
-    a.nq = (a.Lq + 63) / 64;
-    a.ppx = (a.B * a.H + 7) / 8;
-    a.mnq = ez_magic(a.nq); a.mH = ez_magic(a.H);
-    const long nwg = (long)a.nq * a.H * a.B;
-    dim3 grid(a.nq, a.H, a.B);
-    if (a.xcd_map) grid = dim3(8 * a.ppx * a.nq, 1, 1);
+    const long nwg64 = (long)((a.Lq + 63) / 64) * a.H * a.B;
     int nkh = a.nkh;
-    if (nkh != 2 && nkh != 4) nkh = nwg <= 512 ? 4 : 2;   // 0 = choose by grid size
+    if (nkh != 2 && nkh != 4) nkh = nwg64 <= 512 ? 4 : 2;   // 0 = choose by grid size
     if (a.Lkp % 128) nkh = 2;
     if (a.xu && nkh != 4) return 1;   // the fused projection exists in the 8-wave form only (needs Lkp % 128 == 0)
     if (a.dh != 64 && a.dh != 72) return 1;
-    if (a.ts && (long)grid.x * grid.y * grid.z > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
     const bool zq = a.xu && a.zstat_in;
     if (zq && !(a.zG && a.zC && a.zparts > 0 && a.zparts <= Z_MAXP && a.zs_stride > 0 && a.zw > 0)) return 1;
+    // 32-query tiles (fused projection with the LayerNorm algebra, an even number of K tiles): when the 64-row grid leaves half the CUs without a workgroup
+    // (one prompt with the single-key shortcut: 128), or when asked for (qtile = 32)
+    const bool q32 = zq && nkh == 4 && (a.xK / 64) % 2 == 0 && a.xcd_map && (a.qtile == 32 || (a.qtile == 0 && nwg64 <= 128));
+    const int QT = q32 ? 32 : 64;
+    a.nq = (a.Lq + QT - 1) / QT;
+    a.ppx = (a.B * a.H + 7) / 8;
+    a.mnq = ez_magic(a.nq); a.mH = ez_magic(a.H);
+    dim3 grid(a.nq, a.H, a.B);
+    if (a.xcd_map) grid = dim3(8 * a.ppx * a.nq, 1, 1);
+    if (a.ts && (long)grid.x * grid.y * grid.z > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
+    if (q32) {
+        if (a.dh == 64) hipLaunchKernelGGL((k_attn<64, 4, true, 32>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((k_attn<72, 4, true, 32>), grid, dim3(512), 0, st, a);
+        return 0;
+    }
     if (a.dh == 64) {
         if (nkh == 4 && zq) hipLaunchKernelGGL((k_attn<64, 4, true>), grid, dim3(512), 0, st, a);
         else if (nkh == 4) hipLaunchKernelGGL((k_attn<64, 4>), grid, dim3(512), 0, st, a);

@@ -278,6 +278,7 @@ struct AttnArgs {
     unsigned mnq, mH;           // ez_magic(nq), ez_magic(H): filled by launch_attention
     int wt;                     // output stores are write-through (sc1)
     int xk2;                    // fused projection: ring slots of TWO K tiles (one barrier + one counted wait per 128 of K)
+    int qtile;                  // fused projection with the LayerNorm algebra: query rows per workgroup: 64, 32, 0 = 32 when the 64-row grid is <= 128 workgroups (attn.hip k_attn QT)
     // fused projection with the LayerNorm algebra (GemmArgs.z*): xu holds A' = bf16(x g); q_raw := r (acc - mu G'[col]) + C'[col] with (mu, r)
     // from the partial statistics of row (b * Lq + query row); G', C' [H * dh] of this block (the LayerNorm in front of to_q is static)
     const float2* zstat_in; long zs_stride; int zparts; int zD; int zw; const float* zG; const float* zC; float zeps;   // zstat_in [zparts][zs_stride], part-major

@@ -126,7 +126,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     const int row0 = tm * BM, col0 = tn * BN;
     const int nk = a.K / CK;
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
-    if (ts && lane == 0) { ts[0] = __builtin_readcyclecounter(); ts[6] = ez_stamp_start(); }
+    unsigned long long t_start = 0, t_sum = 0;   // test hook: [5] packs two epilogue marks relative to [0]: low 32 bits = partial sums complete, high 32 = stores issued
+    if (ts && lane == 0) { t_start = __builtin_readcyclecounter(); ts[0] = t_start; ts[6] = ez_stamp_start(); }
 
     // epilogue thread layout: (row er, lane-in-row ej) of the first 8 BM threads
     const int er = tid >> 3, ej = tid & 7;
@@ -329,6 +330,10 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         }
         v[q] = t;
     }
+    if (ts && lane == 0) {   // the sums are complete when their last value is: tie the stamp to it
+        asm volatile("" :: "v"(v[SL - 1].w));
+        t_sum = __builtin_readcyclecounter();
+    }
     float* out = reinterpret_cast<float*>(a.out);
     if constexpr (DUAL) {   // the asm loads of dv have landed; ties the registers to the wait
 #pragma unroll
@@ -401,7 +406,12 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             if ((ej & 1) == 0) store8(col0 + 4 * ks_slot_of<SL>(SL - 1, ej), mine, other);
         }
     }
-    if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
+    if (ts && lane == 0) {
+        const unsigned long long t_iss = __builtin_readcyclecounter();   // every store of this wave is issued; below: landed (write-through: acknowledged by the memory side)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime();
+        ts[5] = ((t_iss - t_start) << 32) | ((t_sum - t_start) & 0xffffffffull);
+    }
 }
 
 }  // namespace

@@ -246,6 +246,7 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   fuse_q2 0/1/2 (cross-attention computes its own q projection; 2 = also for large grids), q2_pp 0/1 (cross-attention q projection at grids too large
  *     for fuse_q2: ping-pong GEMM with the per-head LayerNorm in its epilogue; 0 = fp32 GEMM + normalisation inside k_attn)
  *   attn_nkh 0/2/4 (attention key sub-blocks per tile, 0 = by grid size), attn_xk2 0/1 (cross-attention q projection: two K tiles per ring slot and barrier)
+ *   attn_qtile 0/32/64 (fused cross-attention: query rows per workgroup; 0 = 32 when the 64-row grid has <= 128 workgroups -- one prompt with the single-key shortcut)
  *   attn_xcd 0/1 (attention: all query tiles of a (batch, head) pair on one XCD), gemm_panel (bit mask over 1 D x D projections, 2 skip_linear, 4 MLP-out; M <= 1024: the split-K GEMM puts all workgroups of
  *     an M tile on XCD tm % 8) and row_affine 0/1 (the row kernel processes row panel p on XCD p % 8).  Placement only: bitwise identical results.
  *   row_variant 0/1 (row kernel: one workgroup / one wave per row), epi_lds 0/1 (bf16 GEMM epilogues staged through LDS and written as 16-byte row chunks)

@@ -618,10 +618,10 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=0)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=0, attn_qtile=0)
 
 
-@pytest.mark.parametrize('opt,values', [('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
+@pytest.mark.parametrize('opt,values', [('attn_qtile', (64, 32)), ('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
                                         ('epi_lds', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('geglu_co', (0, 2)), ('qkv_co', (0, 2)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1)),
                                         ('fuse_q2', (1, 0)), ('q2_pp', (1, 0)), ('xkey1', (1, 0))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
@@ -644,7 +644,7 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
             outs.append(_forward(m, inp, 499, kw).cpu().numpy())
         assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0
         assert lib.ezdit_set_option(m._h, b'fuse_q2', 1) == 0
-    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1', 'geglu_co', 'qkv_co'):   # placement / issue order / launch structure only: bitwise identical
+    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1', 'geglu_co', 'qkv_co', 'attn_qtile'):   # placement / issue order / launch structure only: bitwise identical
         for o in outs[1:]:
             np.testing.assert_array_equal(outs[0], o)
     else:   # row_variant: same math, different rounding points; gemm_pp / tile_partial: another kernel (other MFMA shape, other fp32 summation order over K)

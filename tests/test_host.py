@@ -199,7 +199,7 @@ def test_product_scheduler_agrees_with_oracle_restatement():
 
 
 OPTION_NAMES = ['zfuse', 'xkey1', 'geglu_co', 'qkv_co', 'wt', 'gemm_pp', 'tile_partial', 'attn_xcd', 'row_variant', 'gemm_panel', 'row_affine', 'epi_lds', 'attn_xk2',
-                'attn_nkh', 'cn_overlap', 'fuse_q2', 'q2_pp', 'stamp_launch', 'trace_launches']
+                'attn_nkh', 'attn_qtile', 'cn_overlap', 'fuse_q2', 'q2_pp', 'stamp_launch', 'trace_launches']
 
 
 def test_tuning_knobs_named_in_the_header_exist(lib):

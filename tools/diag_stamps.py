@@ -105,7 +105,13 @@ def main(size='xl'):
             else:
                 row = [a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2]]
                 lab = ['prologue', 'K loop', 'epilogue + stores']
-                if (raw[okr, 4] > 0).all() and (raw[okr, 5] > 0).all():   # epilogue marks ([4], [5]): GEGLU: ring dead / parked; fused QKV: exchange done / arithmetic done
+                if 'un-split' in names[i] and (raw[okr, 4] > 0).all() and (raw[okr, 5] > 0).all():   # k_gemm_ks: [4] = partials parked + barrier, [5] packs (sums complete, stores issued) relative to [0]
+                    base0 = raw[okr, 0].astype(np.float64) - float(raw[okr, 0].min())
+                    t_sum = base0 + (raw[okr, 5] & 0xffffffff).astype(np.float64)
+                    t_iss = base0 + (raw[okr, 5] >> 32).astype(np.float64)
+                    row += [a[:, 4] - a[:, 2], t_sum - a[:, 4], t_iss - t_sum, a[:, 3] - t_iss]
+                    lab += ['(epilogue: operand wait + park + barrier', 'partial sums', 'arithmetic + store issue', 'stores landed)']
+                elif (raw[okr, 4] > 0).all() and (raw[okr, 5] > 0).all():   # epilogue marks ([4], [5]): GEGLU: ring dead / parked; fused QKV: exchange done / arithmetic done
                     row += [a[:, 4] - a[:, 2], a[:, 5] - a[:, 4], a[:, 3] - a[:, 5]]
                     lab += ['(epilogue: -> mark 4', 'mark 4 -> 5', 'mark 5 -> end)']
             if not names[i].startswith('k_attn') and _ == 0:
