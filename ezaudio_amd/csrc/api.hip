@@ -122,7 +122,8 @@ struct ezdit_handle {
     // GEGLU GEMM on the co-resident kernel (k_gemm_co, gemm_co.h: 4-wave workgroups with a 128 x 144 tile, TWO per CU, so that a workgroup's prologue and
     // epilogue run under its neighbour's K loop): 0 = never, 1 = above kCoM rows (batched prompts: the ping-pong kernel runs 4 rounds of workgroups there), 2 = always
     int opt_geglu_co = 0;
-    int opt_qkv_co = 0;   // the same choice for the fused QKV GEMM (no k-split exchange in the 4-wave form)
+    int opt_qkv_co = 1;   // the same choice for the fused QKV GEMM (no k-split exchange in the 4-wave form).  Default 1 since round 6: four prompts per GPU 10.25 -> 10.07 ... 10.11 ms per step (-1.5 %),
+                          // 768 workgroups = three per CU, two of them resident; at one prompt (192 workgroups, one per CU: nothing to overlap with) the 4-wave form loses 1.3 %
     int qkv_tile() const { return (opt_qkv_co == 2 || (opt_qkv_co == 1 && M > kCoM)) ? 66 : 61; }
     static constexpr int kCoM = 2048;
     int geglu_tile() const { return !(opt_gemm_pp & 1) ? 13 : (opt_geglu_co == 2 || (opt_geglu_co == 1 && M > kCoM)) ? 66 : 60; }

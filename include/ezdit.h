@@ -238,7 +238,8 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *     row of classifier-free guidance -- gets the constant W_o v_key + b_o from the attention-out projection instead of a cross-attention launch;
  *     cross-attention and its out-projection then run over the other batch elements only.  Exact (softmax over one key is 1); 0 = every row through k_attn)
  *   geglu_co / qkv_co 0/1/2 (GEGLU GEMM / fused QKV GEMM on the co-resident kernel k_gemm_co (csrc/gemm_co.h): 4-wave workgroups, 128 x 144 tiles, TWO per CU, so that one
- *     workgroup's prologue / epilogue runs under the other's K loop; 1 = above 2048 token rows (batched prompts), 2 = always, 0 = the ping-pong kernel's 128 x 288 tile)
+ *     workgroup's prologue / epilogue runs under the other's K loop; 1 = above 2048 token rows (batched prompts), 2 = always, 0 = the ping-pong kernel's 128 x 288 tile.
+ *     Defaults: geglu_co 0, qkv_co 1 -- four prompts per GPU -1.5 % per step, one prompt untouched)
  *   gemm_pp (ping-pong kernel k_gemm_pp: bit 0 GEGLU GEMM; 0 = the round-1 lockstep kernel for it and no LayerNorm algebra.  Bit 1 -- the fused QKV GEMM -- is
  *     retired: since round 6 that GEMM always runs on the ping-pong kernel, its weights are packed for it, EZDIT_T_QKROPE)
  *   tile_partial (tile id of the split-K residual GEMMs at M <= 2048 rows: 9 = lockstep 128 x 128, 62 = the same tile on the ping-pong kernel; csrc/gemm.hip table)

@@ -618,7 +618,7 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=0, attn_qtile=0)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=1, attn_qtile=0)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_qtile', (64, 32)), ('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
@@ -670,7 +670,7 @@ def test_co_resident_gemm_kernels_match_reference_golden(lib, dev, name):
             assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
     finally:
         for o in (b'geglu_co', b'qkv_co'):
-            assert lib.ezdit_set_option(m._h, o, 0) == 0
+            assert lib.ezdit_set_option(m._h, o, DEFAULT_OPTS[o.decode()]) == 0
 
 
 def test_unsupported_kernel_configuration_is_an_error_not_a_silent_skip(lib, dev):
