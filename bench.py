@@ -129,6 +129,8 @@ def shard4_measure(unet, params, cfg, dev, n_ddim, use_graph, steps=100, warmup=
     return {'workload': 'same sampler, 4 prompts/GPU = 8 denoiser rows (the per-GPU shard of BASELINE config #4: 32 prompts over 8 GPUs)',
             'prompts_per_gpu': P, 'steps': steps, 'warmup': warmup, 'ms_per_step': dt * 1e3 / steps, 'sample_steps_per_s': steps / dt * P,
             'flops_per_step': fl, 'achieved_tflops': ach, 'roofline_frac': ach / PEAK_BF16_TFLOPS,
+            # executed: the single-key shortcut skips 2 L D^2 + 2 L Lc D MACs per block and unconditional row (see the headline line's flops_note)
+            'roofline_frac_executed': ach * (1.0 - 2.0 * P * (cfg['depth'] + 1) * (2 * L * cfg['embed_dim'] ** 2 + 2 * L * Lc * cfg['embed_dim']) / fl) / PEAK_BF16_TFLOPS,
             'kernel_launches_per_step': unet.last_launch_count}
 
 
@@ -401,6 +403,12 @@ def main():
         if a.controlnet:  # + depth/2 ControlNet blocks, its patch embed and depth/2 zero-Linears (2.29 TFLOP for XL)
             D_, nh = cfg['embed_dim'], cfg['depth'] // 2
             fl += 2.0 * B * (nh * (18 * L * D_ * D_ + 2 * L * L * D_ + 2 * L * Lc * D_) + L * D_ * cfg['in_chans'] + nh * L * D_ * D_)
+        # FLOPs actually EXECUTED: the single-key shortcut (xkey1, default on) skips the cross-attention q projection, attention and out-projection of the P unconditional rows
+        # (their context mask has one valid key): 2 L D^2 + 2 L Lc D MACs per block and row (report both, so that MFU comparisons across rounds stay meaningful)
+        D_ = cfg['embed_dim']
+        xkey1_on = not any(kv.replace(' ', '') in ('xkey1=0', 'zfuse=0') for kv in a.opt)
+        nblk_x = (cfg['depth'] + 1) + (cfg['depth'] // 2 if a.controlnet else 0)
+        fl_exec = fl - (2.0 * P * nblk_x * (2 * L * D_ * D_ + 2 * L * Lc * D_) if xkey1_on else 0.0)
         steps_per_s = a.steps / dt                       # loop iterations per second (per GPU)
         value = steps_per_s * P * world                  # sample-steps/s over the whole job
         ach = fl * (a.steps / (ev_ms * 1e-3)) / 1e12     # TFLOP/s from HIP events around the timed loop
@@ -422,6 +430,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'whole denoising step (all kernels of the DiT forward + CFG/DDIM)',
                          'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / PEAK_BF16_TFLOPS,
                          'flops_per_step': fl, 'event_ms_per_step': ev_ms / a.steps, 'traffic': None,
+                         'executed_flops_per_step': fl_exec, 'achieved_executed': ach * fl_exec / fl, 'frac_executed': ach * fl_exec / fl / PEAK_BF16_TFLOPS,
                          'flops_note': 'algorithmic FLOPs of the FULL step: NOT reduced for the exact single-key shortcut (the unconditional rows have one valid context key, '
                                        'so their cross-attention + out-projection is the constant W_o v + b_o added by the attention-out projection; the cross-attention q projection, '
                                        'attention and out-projection of those rows -- 2 L D^2 + 2 L Lc D of the 18 L D^2 + ... MACs per block and unconditional row, 5.4 % of flops_per_step -- are not executed)'},

@@ -566,6 +566,39 @@ def test_step_counter_scalar_load_is_not_touched_before_its_wait():
     assert checked >= 12, checked
 
 
+def test_dual_form_constant_vector_registers_are_not_touched_before_their_wait():
+    """the DUAL form of k_gemm_ks requests the constant cross-attention-out vector by inline asm (`global_load_dwordx4 v[..]` between the park and the
+    barrier) -- the compiler believes the outputs defined at once.  Straight-line check on the generated gfx950 code: between each of those loads (the vector
+    loads into VGPRs behind the last MFMA) and the first `s_waitcnt vmcnt(0)` that follows them, no instruction names a destination register."""
+    import re
+    funcs = _gfx950_isa('gemm.hip')
+    checked = 0
+    for name, f in funcs.items():
+        m = re.search(r'k_gemm_ksI((?:L[ib]\d+E)+)', name)
+        if not m or [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(1))][6] != 1:
+            continue
+        lines = [l.strip().split(';')[0].strip() for l in f.splitlines()]
+        lines = [l for l in lines if l and not l.startswith('.')]
+        last_mfma = max(i for i, l in enumerate(lines) if l.startswith('v_mfma'))
+        loads = [(i, int(mm.group(1)), int(mm.group(2))) for i, l in enumerate(lines) if i > last_mfma and (mm := re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', l))]
+        assert len(loads) == 3, (name, loads)   # SL = FN / 2 = 3 column slots per thread
+        wait = next(i for i in range(loads[-1][0], len(lines)) if lines[i].startswith('s_waitcnt') and 'vmcnt(0)' in lines[i])
+        dest = {i: set(range(a, b + 1)) for i, a, b in loads}
+        regs = set()   # destinations of the loads issued so far
+        for i in range(loads[0][0], wait):
+            if i in dest:
+                regs |= dest[i]
+                continue
+            ins = lines[i]
+            ops = ins.split(None, 1)[1] if ' ' in ins else ''
+            named = {int(x) for x in re.findall(r'\bv(\d+)\b', ops)}
+            for a, b in re.findall(r'\bv\[(\d+):(\d+)\]', ops):
+                named |= set(range(int(a), int(b) + 1))
+            assert not (named & regs), (name, ins)
+        checked += 1
+    assert checked >= 1, checked
+
+
 def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     """k_gemm_pp, k_gemm_ks and k_attn issue their MFMAs from inline asm, so hipcc's hazard recogniser neither sees them nor pads behind them
     (round-3 ADVICE): the wait states between the LAST MFMA of an accumulation chain and the first non-MFMA read of its accumulator are
