@@ -45,6 +45,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
     asm("" : "+s"(M_) : "s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn), "s"(a.bz),
         "s"(a.cur_step), "s"(a.ts), "s"(a.row_slot), "s"(a.mbm), "s"(a.mbn), "s"(a.msplit));
     const int slot0 = a.cur_step ? *a.cur_step : 0;
+    // G' / C' table bases PINNED in SGPRs: the per-thread choice between them (z_late_load) must be a select on two scalars -- left to hipcc it became a vector load of the chosen
+    // pointer from the argument segment, and its `s_waitcnt vmcnt(0)` drained the first K tile's LDS-DMA in front of the G' / C' request (ISA of the first blind-load build of k_gemm_co)
+    const float *zG_ = a.zG, *zC_ = a.zC;
+    asm("" : "+s"(M_), "+s"(zG_), "+s"(zC_));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,34 +72,52 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
     // with it, merged / parked in LDS in front of the barrier that opens the K loop: nothing rides through the loop
     constexpr int ZR = ZM ? (4 * BM + NT - 1) / NT : 1;   // rows per thread
     ZStatRegs zst[ZR];
-    float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    // requested by BLIND loads and parked by blind LDS stores (gemm_pp.h ld8_blind ...: as C++ hipcc drained vmcnt(0) in front of the merge and of each LDS store, i.e. the K loop
+    // started behind BOTH prologue tiles); every thread issues every load, no branch
+    f32x2 zs_b[ZR][Z_PT];
     const bool z_shared_slot = a.row_slot == nullptr;
+    constexpr int ZNV = 2 * (BN / 4);   // threads that fetch one float4 of G' | C' by LDS-DMA straight into zgc[tid] (gemm_pp.h wait_younger_x)
+    const bool zx = ZM && z_shared_slot && wave * 64 < ZNV && nt >= 2;   // this wave issued that DMA: the counted wait in front of the loop leaves it in flight
     auto z_late_load = [&]() {
         if constexpr (ZM) {
-            static_assert(2 * (BN / 4) <= NT, "one float4 of G' or C' per thread");
+            static_assert(2 * (BN / 4) <= NT && ZR * NT == 4 * BM, "one float4 of G' or C' per thread; every thread serves ZR whole rows' quarter");
+            if (z_shared_slot && tid < ZNV) {
+                const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
+                int cp = col0 + 4 * t4;
+                cp = cp < a.N - 4 ? cp : a.N - 4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((which ? zC_ : zG_) + (long)slot0 * a.zt_slot_stride + cp),
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(zgc) + wave * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto z_early_load = [&]() {   // the row statistics, in FRONT of the first K tile's LDS-DMA (gemm_pp.h z_early_load)
+        if constexpr (ZM) {
 #pragma unroll
             for (int i = 0; i < ZR; ++i) {
                 int row = row0 + (tid >> 2) + i * (NT / 4);
                 row = row < a.M ? row : a.M - 1;
-                z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, tid & 3, zst[i]);
-            }
-            if (z_shared_slot && tid < 2 * (BN / 4)) {
-                const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
-                int cp = col0 + 4 * t4;
-                cp = cp < a.N - 4 ? cp : a.N - 4;
-                zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + (long)slot0 * a.zt_slot_stride + cp);
+                const float2* st = a.zstat_in + row;
+#pragma unroll
+                for (int k = 0; k < Z_PT; ++k) {
+                    const int p = (tid & 3) + 4 * k;
+                    zs_b[i][k] = ld8_blind(st + (p < a.zparts ? p : a.zparts - 1) * a.zs_stride);
+                }
             }
         }
     };
-    auto z_finish = [&]() {
+    auto z_finish = [&]() {   // behind the caller's counted wait
         if constexpr (ZM) {
+#pragma unroll
+            for (int i = 0; i < ZR; ++i)
+#pragma unroll
+                for (int k = 0; k < Z_PT; ++k) { asm volatile("" : "+v"(zs_b[i][k])); zst[i].v[k] = make_float2(zs_b[i][k][0], zs_b[i][k][1]); }
 #pragma unroll
             for (int i = 0; i < ZR; ++i) {
                 const int rl = (tid >> 2) + i * (NT / 4);
                 const float2 mr = z_row_stats_finish(zst[i], a.zparts, tid & 3, a.zD, a.zeps);
-                if ((tid & 3) == 0 && rl < BM) zrow[rl] = mr;
+                if ((tid & 3) == 0 && rl < BM) lds_st8_blind(lds_offset_of(zrow + rl), f32x2{mr.x, mr.y});
             }
-            if (z_shared_slot && tid < 2 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
@@ -158,10 +180,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
         }
     }
     // ---- prologue: tiles 0 and 1 in flight, the z requests between them; tile 0 (and the z loads) must have landed before the loop
+    z_early_load();
     issue(0);
     z_late_load();
     if (nt > 1) issue(1);
-    if (nt > 1) wait_vmcnt<NP>(); else wait_vmcnt<0>();
+    if (nt > 1) { if (zx) wait_vmcnt<NP + 1>(); else wait_vmcnt<NP>(); } else wait_vmcnt<0>();   // (zx: the G' | C' DMA, issued between tile 0 and tile 1, stays in flight)
     z_finish();
     barrier();
     if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();

@@ -50,6 +50,31 @@ __device__ __forceinline__ void wait_younger(int younger) {
     wait_vmcnt<EXTRA>();
 }
 
+// "Blind" vector loads and LDS stores (inline asm: hipcc's waitcnt bookkeeping neither counts them nor waits for them).  Why: z_finish below runs between the
+// prologue's LDS-DMA and the K loop.  As C++ it cost every LayerNorm-algebra consumer ~3K cycles (2.4 % of the XL step, profiles/r06_experiments.txt r06r): hipcc put
+// `s_waitcnt vmcnt(0)` in front of the merge (its bookkeeping is path-insensitive behind the `tid <` branches) and in front of each LDS store (a store next to an LDS-DMA it
+// cannot prove finished), so the loop started when EVERY prologue tile had landed instead of the first.  The caller's counted wait (everything but the younger tiles' pieces)
+// already covers these loads -- they are issued in front of those pieces and vmcnt retires in order.  Rules that keep the asm outputs safe (the compiler believes an
+// asm output defined at once): every thread issues every load (clamped address, no branch: a phi at a join may become a copy of a register whose data has not arrived), the
+// outputs are first named by an empty asm BEHIND the wait (z_finish), and tests/test_host.py checks on the generated code that nothing names them in between.
+__device__ __forceinline__ f32x2 ld8_blind(const void* p) {
+    f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st8_blind(uint32_t lds_byte_offset, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(lds_byte_offset), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t lds_offset_of(const void* generic_lds_pointer) {   // the low half of a flat LDS-aperture address is the LDS byte offset
+    return (uint32_t)(uintptr_t)generic_lds_pointer;
+}
+
+// ... and the per-column vectors of an epilogue (G' | C' of a consumer, bias | gate | gain of a producer) go STRAIGHT into their LDS table by one 16-byte LDS-DMA per thread of the
+// first waves: no register, no park, and the K loop does not wait for them at all -- they are older than every K tile but the first, so whatever wait covers tile 1 covers them.
+// `extra` = this wave issued that one DMA between tile 0 and the younger tiles (wave-uniform): the counted wait in front of the loop leaves it in flight.
+template <int PER, int MAXY>
+__device__ __forceinline__ void wait_younger_x(int younger, bool extra) {
+    if (extra) wait_younger<PER, MAXY, 1>(younger); else wait_younger<PER, MAXY, 0>(younger);
+}
+
 // exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
 // fp32-rounding class and far below the bf16 rounding of the result): ~14 VALU instead of ~40 for erff
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -790,6 +815,12 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     asm("" : "+s"(M_) : "s"(a.A), "s"(a.W), "s"(a.lda), "s"(a.ldw), "s"(a.wrows), "s"(a.N), "s"(a.K), "s"(a.splitk), "s"(a.pm), "s"(a.pn), "s"(a.bm), "s"(a.bn), "s"(a.bz),
         "s"(a.cur_step), "s"(a.ts), "s"(a.xcd_panel), "s"(a.row_slot), "s"(a.mbm), "s"(a.mbn), "s"(a.msplit), "s"(a.mG));
     const int slot0 = a.cur_step ? *a.cur_step : 0;   // device step counter: needed from z_late_load on
+    // G' / C' table bases PINNED in SGPRs: the per-thread choice between them (z_late_load) must be a select on two scalars -- left to hipcc it became a vector load of the chosen
+    // pointer from the argument segment, and its `s_waitcnt vmcnt(0)` drained the first K tile's LDS-DMA in front of the G' / C' request (ISA of the first blind-load build of k_gemm_co)
+    const float *zG_ = a.zG, *zC_ = a.zC;
+    asm("" : "+s"(M_), "+s"(zG_), "+s"(zC_));
+    const float *rb_ = a.bias, *rg_ = a.gate, *rz_ = a.zg, *rz2_ = a.zg2;   // the same for the producer's per-column vectors (EPI_RESID)
+    if constexpr (EPI == EPI_RESID) asm("" : "+s"(M_), "+s"(rb_), "+s"(rg_), "+s"(rz_), "+s"(rz2_));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -822,8 +853,12 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // rides through the loop and the epilogue needs no extra barrier (so the GEGLU math still overlaps the other group's last MFMA phase).  Ledger of the alternatives: profiles/r04_experiments.txt.
     float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only); EPI_RESID: [4][BN] bias | gate | LayerNorm gain | DUAL: the alternative gain
     ZStatRegs zst;
-    float4 zgc_reg = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x2 zs_b[Z_PT];   // the row statistics of this thread's row quarter, requested by blind loads (ld8_blind above)
     const bool z_shared_slot = a.row_slot == nullptr;
+    // threads that fetch one float4 of the epilogue's per-column vectors (LDS-DMA in z_late_load), and whether THIS wave is one of theirs: its counted wait in front of the
+    // K loop then leaves that one DMA in flight (nt >= 2: the wait for K tile 1, which is younger, covers it)
+    constexpr int ZNV = EPI == EPI_RESID ? ((VAR & 256) ? 4 : 3) * (BN / 4) : 2 * (BN / 4);
+    const bool zx = ((ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV) && z_shared_slot) || EPI == EPI_RESID) && wave * 64 < ZNV && nt >= 2;
     constexpr bool ZP = (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) || EPI == EPI_RESID;   // this instantiation parks per-row / per-column vectors behind the ring
     // G' / C' live in the table of the CURRENT modulation slot: their address needs the device step counter (slot0, a scalar load issued at
     // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
@@ -849,40 +884,51 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         }
         if constexpr (EPI == EPI_RESID) {   // producer side: bias | gate | gain of the tile's columns, one float4 per thread (the modulation slot is shared: launch_gemm checks)
             static_assert(4 * (BN / 4) <= NT, "one float4 per thread");
-            if (tid < (RDUAL ? 4 : 3) * (BN / 4)) {
+            if (tid < ZNV) {   // one 16-byte LDS-DMA per thread, straight into zgc[tid] (wave w's 64 lanes fill the KB at zgc + 1024 w)
                 const int which = tid / (BN / 4), t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
                 cp = cp < a.N - 4 ? cp : a.N - 4;
-                const float* src = which == 0 ? a.bias : which == 1 ? (RGATE ? a.gate + (long)slot0 * a.gate_slot_stride : a.bias) : which == 2 ? a.zg + (long)slot0 * a.zg_slot_stride
-                                   : (RDUAL ? a.zg2 + (long)slot0 * a.zg2_slot_stride : a.bias);
-                zgc_reg = *reinterpret_cast<const float4*>(src + cp);
+                const float* src = which == 0 ? rb_ : which == 1 ? (RGATE ? rg_ + (long)slot0 * a.gate_slot_stride : rb_) : which == 2 ? rz_ + (long)slot0 * a.zg_slot_stride
+                                   : (RDUAL ? rz2_ + (long)slot0 * a.zg2_slot_stride : rb_);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + cp),
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(zgc) + wave * 1024), 16, 0, 0);
             }
         }
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            static_assert(4 * BM <= NT && 2 * (BN / 4) <= NT, "four threads per row / one float4 of G' or C' per thread");
-            if (tid < 4 * BM) {
-                int row = row0 + (tid >> 2);
-                row = row < a.M ? row : a.M - 1;
-                z_row_stats_load(a.zstat_in + row, a.zs_stride, a.zparts, tid & 3, zst);
-            }
-            if (z_shared_slot && tid < 2 * (BN / 4)) {
+            static_assert(2 * (BN / 4) <= NT, "one float4 of G' or C' per thread");
+            if (z_shared_slot && tid < ZNV) {   // G' | C' of the tile's columns: one 16-byte LDS-DMA per thread, straight into zgc[tid] (per-row timesteps: the epilogue reads them per row from global memory)
                 const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
                 cp = cp < a.N - 4 ? cp : a.N - 4;
-                zgc_reg = *reinterpret_cast<const float4*>((which ? a.zC : a.zG) + (long)slot0 * a.zt_slot_stride + cp);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((which ? zC_ : zG_) + (long)slot0 * a.zt_slot_stride + cp),
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(zgc) + wave * 1024), 16, 0, 0);
             }
         }
     };
-    auto z_finish = [&]() {   // behind a wait for the loads of z_late_load; the caller puts a workgroup barrier between this and the first reader
-        if constexpr (EPI == EPI_RESID) {
-            if (tid < (RDUAL ? 4 : 3) * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
-        }
+    // the row statistics (no step counter in their address) go out in FRONT of the first K tile's LDS-DMA: they were written by the launch before this one and are as cold as the
+    // tile, so behind it they landed behind it -- and the merge below is what the K loop's first barrier waits for
+    auto z_early_load = [&]() {
         if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            if (tid < 4 * BM) {
-                const float2 mr = z_row_stats_finish(zst, a.zparts, tid & 3, a.zD, a.zeps);
-                if ((tid & 3) == 0) zrow[tid >> 2] = mr;
+            static_assert(4 * BM == NT, "four threads per row: EVERY thread loads, no branch (ld8_blind)");
+            int row = row0 + (tid >> 2);
+            row = row < a.M ? row : a.M - 1;
+            const float2* st = a.zstat_in + row;
+            const int pg = tid & 3;
+#pragma unroll
+            for (int k = 0; k < Z_PT; ++k) {   // (z_row_stats_load, common.h, as blind loads)
+                const int p = pg + 4 * k;
+                zs_b[k] = ld8_blind(st + (p < a.zparts ? p : a.zparts - 1) * a.zs_stride);
             }
-            if (z_shared_slot && tid < 2 * (BN / 4)) reinterpret_cast<float4*>(zgc)[tid] = zgc_reg;
+        }
+    };
+    auto z_finish = [&]() {   // behind a wait for the loads of z_early_load; the caller puts a workgroup barrier between this and the first reader
+        if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
+            // the blind loads' outputs are named HERE first, behind the caller's counted wait (volatile asm statements keep their order)
+#pragma unroll
+            for (int k = 0; k < Z_PT; ++k) { asm volatile("" : "+v"(zs_b[k])); zst.v[k] = make_float2(zs_b[k][0], zs_b[k][1]); }
+            const float2 mr = z_row_stats_finish(zst, a.zparts, tid & 3, a.zD, a.zeps);
+            if ((tid & 3) == 0) lds_st8_blind(lds_offset_of(zrow + (tid >> 2)), f32x2{mr.x, mr.y});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stores have reached the LDS before the caller's barrier lets the readers go
         }
     };
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
@@ -1019,12 +1065,13 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             using IB = std::integral_constant<int, PB>;
             using IE = std::integral_constant<int, PE>;
             // prologue: tiles 0 .. PD-1; tile 0 must be complete (every wave's share) before interval 0
+            z_early_load();
 #pragma unroll
             for (int t = 0; t < PD; ++t) {
                 if (t < nt) issue(t, IB{}, IE{});
                 if (t == 0) z_late_load();   // right behind tile 0: the wait for tile 0 below (everything but the YOUNGER tiles' pieces) covers these loads too
             }
-            wait_younger<PG, PD - 1>((nt < PD ? nt : PD) - 1);
+            wait_younger_x<PG, PD - 1>((nt < PD ? nt : PD) - 1, zx);
             z_finish();
             barrier();
             if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
@@ -1071,6 +1118,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             constexpr int G = decltype(G_)::value;
             // the z loads go out right behind tile 0 in the group that owns it, in front of its first tile in the other group: in both, the
             // counted wait for "everything but my younger tiles" covers them
+            z_early_load();
             if constexpr ((PD & 1) != G) z_late_load();
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
@@ -1079,8 +1127,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             }
             {
                 const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
-                if constexpr ((PD & 1) == G) wait_younger<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0);      // owner of tile 0: own younger tiles 2, 4, ...
-                else if constexpr (ZP) wait_younger<NP, PD / 2>((last + 1) / 2);                            // the other group: own tiles 1, 3, ... stay in flight
+                if constexpr ((PD & 1) == G) wait_younger_x<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0, zx);      // owner of tile 0: own younger tiles 2, 4, ...
+                else if constexpr (ZP) wait_younger_x<NP, PD / 2>((last + 1) / 2, zx);                            // the other group: own tiles 1, 3, ... stay in flight
             }
             z_finish();
             barrier();

@@ -599,6 +599,69 @@ def test_dual_form_constant_vector_registers_are_not_touched_before_their_wait()
     assert checked >= 1, checked
 
 
+def test_blind_loads_of_the_layernorm_algebra_consumers_are_not_touched_before_the_counted_wait():
+    """The LayerNorm-algebra consumers (k_gemm_pp, k_gemm_co) request the row statistics by inline-asm loads (gemm_pp.h ld8_blind) and park (mu, r) by an inline-asm LDS store, so
+    that hipcc does not drain vmcnt(0) in front of the K loop (G' / C' go straight into the LDS by LDS-DMA); the compiler believes an asm output defined at once.  On
+    the generated gfx950 code of every consumer instantiation: in front of the first MFMA hipcc itself neither waits on vmcnt nor loads a vector from global memory (everything of
+    that kind sits inside an inline-asm block); the `global_load_dwordx2 v[..]` there are not named by any instruction until a counted `s_waitcnt vmcnt(N)` follows them; and the
+    only LDS stores in front of the loop are the blind ds_write_b64 of (mu, r)."""
+    import re
+    funcs = _gfx950_isa('gemm.hip')
+    checked = 0
+    for name, f in funcs.items():
+        m = re.search(r'k_gemm_(pp|co)I((?:L[ib]\d+E)+)', name)
+        if not m:
+            continue
+        targs = [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(2))]
+        epi, var = (targs[5], targs[7]) if m.group(1) == 'pp' else (targs[2], targs[3])
+        if not (var & 64) or epi not in (2, 3):   # EPI_GEGLU = 2, EPI_QKV = 3 with the LayerNorm algebra
+            continue
+        # in front of the first MFMA, hipcc itself must neither wait on vmcnt nor load a vector from global memory: everything of that kind sits inside an inline-asm block
+        raw = f.splitlines()
+        first_mfma_raw = next(i for i, l in enumerate(raw) if l.strip().startswith('v_mfma'))
+        inasm = False
+        for l in raw[:first_mfma_raw]:
+            t = l.strip()
+            if t.startswith(';;#ASMSTART'):
+                inasm = True
+            elif t.startswith(';;#ASMEND'):
+                inasm = False
+            elif not inasm:
+                assert not (t.startswith('s_waitcnt') and 'vmcnt' in t), (name, t)
+                assert not re.match(r'global_load_dword\w* v', t), (name, t)
+        lines = [l.strip().split(';')[0].strip() for l in f.splitlines()]
+        lines = [l for l in lines if l and not l.startswith('.') or re.match(r'\.LBB\d+_\d+:', l or '')]
+        first_mfma = next(i for i, l in enumerate(lines) if l.startswith('v_mfma'))
+        pro = lines[:first_mfma]
+        ld2 = [(i, int(mm.group(1)), int(mm.group(2))) for i, l in enumerate(pro) if (mm := re.match(r'global_load_dwordx2 v\[(\d+):(\d+)\]', l))]
+        assert len(ld2) >= 3, (name, len(ld2))   # Z_PT per row quarter (SCHED 2 emits the prologue once per wave group; k_gemm_co serves two rows per thread)
+        loads = sorted(ld2)
+        # every load: walk forward until the first ds_write (the parks of z_finish); a counted vmcnt wait must come first, and nothing may name the destination before it
+        for i, a, b in loads:
+            regs = set(range(a, b + 1))
+            waited = False
+            for j in range(i + 1, first_mfma):
+                ins = pro[j]
+                if ins.startswith('s_waitcnt') and 'vmcnt(' in ins:
+                    waited = True
+                if ins.startswith('ds_write'):
+                    assert waited, (name, pro[i], ins)
+                    break
+                if waited:
+                    continue
+                ops = ins.split(None, 1)[1] if ' ' in ins else ''
+                named = {int(x) for x in re.findall(r'\bv(\d+)\b', ops)}
+                for x, y in re.findall(r'\bv\[(\d+):(\d+)\]', ops):
+                    named |= set(range(int(x), int(y) + 1))
+                if re.match(r'\.LBB|s_cbranch|s_branch', ins):
+                    continue
+                assert not (named & regs), (name, pro[i], ins)
+        stores = [l for l in pro if l.startswith('ds_write')]
+        assert stores and all(l.startswith('ds_write_b64') for l in stores), (name, stores)
+        checked += 1
+    assert checked >= 3, checked
+
+
 def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
     """k_gemm_pp, k_gemm_ks and k_attn issue their MFMAs from inline asm, so hipcc's hazard recogniser neither sees them nor pads behind them
     (round-3 ADVICE): the wait states between the LAST MFMA of an accumulation chain and the first non-MFMA read of its accumulator are
@@ -615,6 +678,19 @@ def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
             if not any(k in name for k in kernels) or 'v_mfma' not in f:
                 continue
             lines = [l.strip() for l in f.splitlines() if (l.startswith('\t') or re.match(r'\.LBB\d+_\d+:', l)) and not l.strip().startswith((';', '.p2align', '.long', '.byte'))]
+            # the accumulators = the AGPRs some MFMA of this kernel writes; hipcc also parks spilled VGPRs in the AGPRs above them (v_accvgpr_write / _read around the loops:
+            # no matrix-pipe hazard on those)
+            acc_regs = set()
+            for ins in lines:
+                mm = re.match(r'v_mfma\S* a\[(\d+):(\d+)\]', ins)
+                if mm:
+                    acc_regs |= set(range(int(mm.group(1)), int(mm.group(2)) + 1))
+
+            def names_acc(ops):
+                named = {int(x) for x in re.findall(r'\ba(\d+)\b', ops)}
+                for x, y in re.findall(r'\ba\[(\d+):(\d+)\]', ops):
+                    named |= set(range(int(x), int(y) + 1))
+                return bool(named & acc_regs)
             # dist = issue slots since the last MFMA on ANY path into this point: a label takes the minimum over its fall-through and every branch that
             # targets it (round 5: the register allocator put accumulator copies on a loop-exit EDGE, which a purely textual scan -- whose predecessor
             # was an unrelated block -- did not see); iterated to a fixed point because loop back-edges come textually after their header
@@ -636,7 +712,11 @@ def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
                         new_in[tgt] = min(new_in.get(tgt, INF), dist + 1)
                         dist = INF if op == 's_branch' else dist + 1
                         continue
-                    reads_acc = (op == 'v_accvgpr_read_b32') or (op == 'v_accvgpr_mov_b32') or (op.startswith(('ds_write', 'global_store', 'v_')) and not op.startswith('v_accvgpr_write') and re.search(r'\ba\[?\d', ins.split(None, 1)[1] if ' ' in ins else ''))
+                    opnds = ins.split(None, 1)[1] if ' ' in ins else ''
+                    if op in ('v_accvgpr_read_b32', 'v_accvgpr_mov_b32'):
+                        reads_acc = names_acc(opnds.split(',', 1)[1] if ',' in opnds else opnds)   # (the source operand)
+                    else:
+                        reads_acc = op.startswith(('ds_write', 'global_store', 'v_')) and not op.startswith('v_accvgpr_write') and names_acc(opnds)
                     if reads_acc and dist < INF:
                         reads.append((ins, dist))
                         dist = INF          # chain consumed; the next MFMA re-arms the check
