@@ -65,22 +65,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
     const int nt = ke - kb;
 
     constexpr bool ZM = (VAR & 64) != 0 && (EPI == EPI_GEGLU || EPI == EPI_QKV);
-    float2* zrow = reinterpret_cast<float2*>(smem + 2 * STAGE);           // [BM] (mu, r) of this tile's rows
     float* zgc = reinterpret_cast<float*>(smem + 2 * STAGE + BM * 8);     // [2][BN]: G' | C' of this tile's columns (shared modulation slot only)
-    // LayerNorm algebra, consumer side (as in k_gemm_pp): partial statistics of the tile's rows (four threads per row, part-major table; a thread serves
-    // the rows tid / 4 and tid / 4 + 64) and the G' / C' slices of the tile's columns are requested right behind the first K tile's LDS-DMA, waited for
-    // with it, merged / parked in LDS in front of the barrier that opens the K loop: nothing rides through the loop
-    constexpr int ZR = ZM ? (4 * BM + NT - 1) / NT : 1;   // rows per thread
-    ZStatRegs zst[ZR];
-    // requested by BLIND loads and parked by blind LDS stores (gemm_pp.h ld8_blind ...: as C++ hipcc drained vmcnt(0) in front of the merge and of each LDS store, i.e. the K loop
-    // started behind BOTH prologue tiles); every thread issues every load, no branch
-    f32x2 zs_b[ZR][Z_PT];
+    // LayerNorm algebra, consumer side (as in k_gemm_pp): the G' / C' slices of the tile's columns go straight into `zgc` by LDS-DMA right behind the first K tile and are not
+    // waited for in front of the loop; the partial statistics of the rows a lane finishes are requested by that lane in front of the loop's last two tiles and merged behind
+    // the loop (gemm_pp.h z_lane_load / z_lane_finish): nothing of the algebra sits between the prologue and the loop's first barrier
+    constexpr int NZT = ZM ? FM * Z_PT : 0;   // blind statistics loads per lane (into AGPRs), issued by z_late_load
+    ZLaneRegs<FM> zlr;
     const bool z_shared_slot = a.row_slot == nullptr;
     constexpr int ZNV = 2 * (BN / 4);   // threads that fetch one float4 of G' | C' by LDS-DMA straight into zgc[tid] (gemm_pp.h wait_younger_x)
-    const bool zx = ZM && z_shared_slot && wave * 64 < ZNV && nt >= 2;   // this wave issued that DMA: the counted wait in front of the loop leaves it in flight
+    const bool zx = ZM && z_shared_slot && wave * 64 < ZNV;   // this wave issued that DMA: the counted wait in front of the loop leaves it (and the NZT statistics loads) in flight
     auto z_late_load = [&]() {
         if constexpr (ZM) {
-            static_assert(2 * (BN / 4) <= NT && ZR * NT == 4 * BM, "one float4 of G' or C' per thread; every thread serves ZR whole rows' quarter");
+            static_assert(2 * (BN / 4) <= NT, "one float4 of G' or C' per thread");
             if (z_shared_slot && tid < ZNV) {
                 const int which = tid >= BN / 4, t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
@@ -88,36 +84,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((which ? zC_ : zG_) + (long)slot0 * a.zt_slot_stride + cp),
                                                  (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(zgc) + wave * 1024), 16, 0, 0);
             }
-        }
-    };
-    auto z_early_load = [&]() {   // the row statistics, in FRONT of the first K tile's LDS-DMA (gemm_pp.h z_early_load)
-        if constexpr (ZM) {
-#pragma unroll
-            for (int i = 0; i < ZR; ++i) {
-                int row = row0 + (tid >> 2) + i * (NT / 4);
-                row = row < a.M ? row : a.M - 1;
-                const float2* st = a.zstat_in + row;
-#pragma unroll
-                for (int k = 0; k < Z_PT; ++k) {
-                    const int p = (tid & 3) + 4 * k;
-                    zs_b[i][k] = ld8_blind(st + (p < a.zparts ? p : a.zparts - 1) * a.zs_stride);
-                }
-            }
-        }
-    };
-    auto z_finish = [&]() {   // behind the caller's counted wait
-        if constexpr (ZM) {
-#pragma unroll
-            for (int i = 0; i < ZR; ++i)
-#pragma unroll
-                for (int k = 0; k < Z_PT; ++k) { asm volatile("" : "+v"(zs_b[i][k])); zst[i].v[k] = make_float2(zs_b[i][k][0], zs_b[i][k][1]); }
-#pragma unroll
-            for (int i = 0; i < ZR; ++i) {
-                const int rl = (tid >> 2) + i * (NT / 4);
-                const float2 mr = z_row_stats_finish(zst[i], a.zparts, tid & 3, a.zD, a.zeps);
-                if ((tid & 3) == 0 && rl < BM) lds_st8_blind(lds_offset_of(zrow + rl), f32x2{mr.x, mr.y});
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            z_lane_load<FM>(a.zstat_in, a.zs_stride, a.zparts, row0 + wm * TM + (lane & 15), a.M - 1, lane >> 4, zlr);   // blind loads into AGPRs, every lane
         }
     };
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
@@ -180,12 +147,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
         }
     }
     // ---- prologue: tiles 0 and 1 in flight, the z requests between them; tile 0 (and the z loads) must have landed before the loop
-    z_early_load();
     issue(0);
     z_late_load();
     if (nt > 1) issue(1);
-    if (nt > 1) { if (zx) wait_vmcnt<NP + 1>(); else wait_vmcnt<NP>(); } else wait_vmcnt<0>();   // (zx: the G' | C' DMA, issued between tile 0 and tile 1, stays in flight)
-    z_finish();
+    if (nt > 1) { if (zx) wait_vmcnt<NP + NZT + 1>(); else wait_vmcnt<NP + NZT>(); } else wait_vmcnt<0>();   // (the statistics loads and, zx, the G' | C' DMA -- issued between tile 0 and tile 1 -- stay in flight)
     barrier();
     if (ts && lane == 0) ts[1] = __builtin_readcyclecounter();
     // one K tile.  MODE 2: steady state (tile t + 2 exists and is issued here); 1: the last but one tile; 0: the last tile.  Compile-time, so that the
@@ -240,19 +205,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_co(GemmArgs a) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    float2 zmr[FM];   // LayerNorm algebra: (mu, r) of the rows this lane finishes
+    if constexpr (ZM) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        z_lane_finish<FM>(zlr, a.zparts, lane >> 4, a.zD, a.zeps, zmr);
+    }
     if constexpr (EPI == EPI_QKV) {
         // fused q | k | v projection, epilogue in registers (gemm_pp.h pp_store_qkv_reg): no k-split exchange here -- a wave holds its 32 rows x two whole heads
         static_assert(BM * (BN + 8) * 2 <= 2 * STAGE, "bf16 staging tile must fit the ring");
         QkvOperands<BN / 2, FM> qop;
         qkv_request<BN / 2, FM>(a, col0, row0 + wm * TM + (lane & 15), lane, tid, qop);
-        pp_store_qkv_reg<BM, BN, BN / 2, FM, FN, TM, TN, NT, ZM>(a, acc, smem, row0, col0, wm, lane, tid, zrow, zgc, reinterpret_cast<float*>(smem + 2 * STAGE + BM * 8 + 2 * BN * 4), slot0, qop, ts);
+        pp_store_qkv_reg<BM, BN, BN / 2, FM, FN, TM, TN, NT, ZM>(a, acc, smem, row0, col0, wm, lane, tid, zmr, zgc, reinterpret_cast<float*>(smem + 2 * STAGE + BM * 8 + 2 * BN * 4), slot0, qop, ts);
         if (ts && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
     if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
         static_assert(BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= 2 * STAGE, "output tile must fit the ring");
         if (EPI == EPI_GEGLU || a.part_bf16) {
-            pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, 0, lane, tid, z, zrow, zgc, slot0, ts);
+            pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, 0, lane, tid, z, zmr, zgc, slot0, ts);
             if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
             return;
         }

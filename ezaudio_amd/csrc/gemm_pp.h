@@ -50,29 +50,26 @@ __device__ __forceinline__ void wait_younger(int younger) {
     wait_vmcnt<EXTRA>();
 }
 
-// "Blind" vector loads and LDS stores (inline asm: hipcc's waitcnt bookkeeping neither counts them nor waits for them).  Why: z_finish below runs between the
-// prologue's LDS-DMA and the K loop.  As C++ it cost every LayerNorm-algebra consumer ~3K cycles (2.4 % of the XL step, profiles/r06_experiments.txt r06r): hipcc put
-// `s_waitcnt vmcnt(0)` in front of the merge (its bookkeeping is path-insensitive behind the `tid <` branches) and in front of each LDS store (a store next to an LDS-DMA it
-// cannot prove finished), so the loop started when EVERY prologue tile had landed instead of the first.  The caller's counted wait (everything but the younger tiles' pieces)
-// already covers these loads -- they are issued in front of those pieces and vmcnt retires in order.  Rules that keep the asm outputs safe (the compiler believes an
-// asm output defined at once): every thread issues every load (clamped address, no branch: a phi at a join may become a copy of a register whose data has not arrived), the
-// outputs are first named by an empty asm BEHIND the wait (z_finish), and tests/test_host.py checks on the generated code that nothing names them in between.
-__device__ __forceinline__ f32x2 ld8_blind(const void* p) {
+// "Blind" vector loads (inline asm: hipcc's waitcnt bookkeeping neither counts them nor waits for them): the row statistics of the LayerNorm algebra (z_lane_load below).
+// History of why: as C++ loads, merged per workgroup by `z_finish` between the prologue's LDS-DMA and the K loop, they cost every consumer ~3K cycles (2.4 % of the XL step,
+// profiles/r06_experiments.txt r06r): hipcc put `s_waitcnt vmcnt(0)` in front of the merge (its bookkeeping is path-insensitive behind `tid <` branches) and in front of each
+// LDS store (a store next to an LDS-DMA it cannot prove finished), so the loop started when EVERY prologue tile had landed instead of the first.  Rules that keep an asm output
+// safe (the compiler believes it defined at once): every lane issues every load (clamped address, no branch: a phi at a join may become a copy of a register whose data
+// has not arrived), the outputs are first named by an empty asm BEHIND the wait (z_lane_finish), and tests/test_host.py checks on the generated code that nothing reads them in between.
+__device__ __forceinline__ f32x2 ld8_blind(const void* p) {   // into an AGPR pair: the value rides through the K loop next to the accumulators, where registers are free
     f32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(v) : "v"(p) : "memory");
     return v;
 }
-__device__ __forceinline__ void lds_st8_blind(uint32_t lds_byte_offset, f32x2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(lds_byte_offset), "v"(v) : "memory"); }
-__device__ __forceinline__ uint32_t lds_offset_of(const void* generic_lds_pointer) {   // the low half of a flat LDS-aperture address is the LDS byte offset
-    return (uint32_t)(uintptr_t)generic_lds_pointer;
-}
 
-// ... and the per-column vectors of an epilogue (G' | C' of a consumer, bias | gate | gain of a producer) go STRAIGHT into their LDS table by one 16-byte LDS-DMA per thread of the
+// The per-column vectors of an epilogue (G' | C' of a consumer, bias | gate | gain of a producer) go STRAIGHT into their LDS table by one 16-byte LDS-DMA per thread of the
 // first waves: no register, no park, and the K loop does not wait for them at all -- they are older than every K tile but the first, so whatever wait covers tile 1 covers them.
 // `extra` = this wave issued that one DMA between tile 0 and the younger tiles (wave-uniform): the counted wait in front of the loop leaves it in flight.
-template <int PER, int MAXY>
-__device__ __forceinline__ void wait_younger_x(int younger, bool extra) {
-    if (extra) wait_younger<PER, MAXY, 1>(younger); else wait_younger<PER, MAXY, 0>(younger);
+template <int PER, int MAXY, int BASE>
+__device__ __forceinline__ void wait_younger_x(int younger, int extra /* 0 .. 2, wave-uniform */) {
+    if (extra >= 2) wait_younger<PER, MAXY, BASE + 2>(younger);
+    else if (extra == 1) wait_younger<PER, MAXY, BASE + 1>(younger);
+    else wait_younger<PER, MAXY, BASE>(younger);
 }
 
 // exact-erf GELU (F.gelu default, modules.py:268-272) with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e.
@@ -243,7 +240,7 @@ __device__ __forceinline__ void pp_store_direct(const GemmArgs& a, f32x4 (&acc)[
 // (branch-free: both lanes evaluate  mul * gelu(arg)  with their own selection of mul / arg).
 template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, int EPI, bool ZC>
 __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid, int z,
-                                             const float2* zrow, const float* zgc, int slot0, unsigned long long* ts = nullptr) {
+                                             const float2* zmr /* (mu, r) of this lane's row fragments: z_lane_finish */, const float* zgc, int slot0, unsigned long long* ts = nullptr) {
     static_assert(EPI == EPI_GEGLU || EPI == EPI_PARTIAL, "bf16 outputs only");
     constexpr int OC = EPI == EPI_GEGLU ? BN / 2 : BN;   // output columns of the tile
     static_assert(OC % 8 == 0, "16-byte row chunks");
@@ -269,7 +266,7 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
             for (int j = 0; j < FN; ++j) {
                 int cp = col0 + wn * TN + j * 16 + 4 * cg;
                 cp = cp < ncl ? cp : ncl;
-                if constexpr (ZC) {   // parked behind the ring after the K loop (k_gemm_pp, z_finish)
+                if constexpr (ZC) {   // parked behind the ring by LDS-DMA (k_gemm_pp, z_late_load)
                     (void)so;
                     g4[j] = *reinterpret_cast<const float4*>(zgc + (wn * TN + j * 16 + 4 * cg));
                     c4[j] = *reinterpret_cast<const float4*>(zgc + BN + (wn * TN + j * 16 + 4 * cg));
@@ -296,7 +293,7 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
                         c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
                     }
                 }
-                const float2 mr = zrow[rl];
+                const float2 mr = zmr[i];
                 mu = mr.x; r = mr.y;
             }
             const float rm = r * mu;
@@ -409,7 +406,7 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
 // weight rows are in natural order, like the context K it meets); the fused q | k | v projection runs pp_store_qkv_reg below.
 template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT, bool ZC>
 __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int wn, int lane, int tid,
-                                             const float2* zrow, const float* zgc, int slot0) {
+                                             const float2* zmr, const float* zgc, int slot0) {
     constexpr int NH = BN / DH, DQK = DH == 72 ? 80 : 64, PITCH = BN + 4;
     static_assert(NH * DH == BN && DH % 4 == 0 && (DH * 2) % 16 == 0, "whole heads");
     float* tile = reinterpret_cast<float*>(smem);                        // [BM][PITCH] fp32, reuses the ring
@@ -419,7 +416,7 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
     if constexpr (ZC) {   // LayerNorm algebra: the projection of LN(x) g + c is  r (acc - mu G') + C'
         const int ncl = a.N - 4;
         float4 c4[FN], g4[FN];
-        // shared modulation slot: G' / C' of the tile's columns were parked behind the ring (k_gemm_pp, z_finish).  The LDS and the global
+        // shared modulation slot: G' / C' of the tile's columns were parked behind the ring by LDS-DMA (k_gemm_pp, z_late_load).  The LDS and the global
         // variant are two separate loops on purpose: as one loop with a per-element choice hipcc merged them into FLAT loads of a selected
         // address (18 flat_load_dwordx4 in the epilogue: +2.5 us per launch)
         if (!a.row_slot) {
@@ -444,7 +441,7 @@ __device__ __forceinline__ void pp_store_qkv(const GemmArgs& a, f32x4 (&acc)[FM]
                     c4[j] = *reinterpret_cast<const float4*>(a.zC + so + cp);
                 }
             }
-            const float2 mr = zrow[rl];
+            const float2 mr = zmr[i];
             const float r = mr.y, rm = mr.y * mr.x;
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
@@ -597,6 +594,50 @@ __device__ __forceinline__ float row4_sum(float x) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// ---- LayerNorm algebra, consumer side: (mu, r) of the rows a LANE finishes in the 16x16 C layout (lane = row m_in + 16 cg of every 16-row fragment), computed by the lane itself.
+// The four lanes cg = 0 .. 3 of a row each fetch its parts cg, cg + 4, cg + 8 of the part-major statistics table (blind loads: ld8_blind) and add them up in the order of
+// z_row_stats_finish (common.h): own parts in index order, then the lane pairs (cg, cg ^ 1), then the two pairs -- bit-identical to the table-per-workgroup form it replaces.
+// Why per lane: the epilogue is the only reader of (mu, r).  Merged per workgroup in front of the K loop (rounds 4 - 6a) they sat between the prologue's LDS-DMA and the loop's
+// first barrier -- the statistics' cold fetch, ~40 VALU instructions and an LDS store that every wave waited for: 2.3K cycles per consumer launch (profiles/r06_experiments.txt,
+// r06r: bound -2.4 % of the step).  Now they are requested when the K loop enters its last PD tiles (the counted waits of those steps leave them in flight) and merged behind the loop.
+template <int FMR>
+struct ZLaneRegs { f32x2 v[FMR][Z_PT]; };
+template <int FMR>
+__device__ __forceinline__ void z_lane_load(const float2* zstat_in, long stride, int parts, int first_row /* of fragment 0, this lane */, int max_row, int cg, ZLaneRegs<FMR>& z) {
+#pragma unroll
+    for (int i = 0; i < FMR; ++i) {
+        int row = first_row + 16 * i;
+        row = row < max_row ? row : max_row;
+#pragma unroll
+        for (int k = 0; k < Z_PT; ++k) {
+            const int p = cg + 4 * k;
+            z.v[i][k] = ld8_blind(zstat_in + row + (p < parts ? p : parts - 1) * stride);
+        }
+    }
+}
+// behind `s_waitcnt vmcnt(0)` (the caller's): the registers are first named here
+template <int FMR>
+__device__ __forceinline__ void z_lane_finish(ZLaneRegs<FMR>& z, int parts, int cg, int D, float eps, float2 (&mr)[FMR]) {
+    const float inv_d = __builtin_amdgcn_rcpf((float)D);
+#pragma unroll
+    for (int i = 0; i < FMR; ++i) {
+#pragma unroll
+        for (int k = 0; k < Z_PT; ++k) asm volatile("" : "+a"(z.v[i][k]));
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < Z_PT; ++k) {   // fixed order: bit-reproducible
+            const bool on = cg + 4 * k < parts;
+            s += on ? z.v[i][k][0] : 0.f;
+            q += on ? z.v[i][k][1] : 0.f;
+        }
+        s = row4_sum(s);
+        q = row4_sum(q);
+        const float mu = s * inv_d;
+        const float var = fmaxf(fmaf(q, inv_d, -mu * mu), 0.f);
+        mr[i] = make_float2(mu, rsqrtf(var + eps));
+    }
+}
+
 // fused q | k | v epilogue IN REGISTERS (round 6; attention.py:137-142, rotary.py:6-18): the tile holds two whole heads of q, of k (columns permuted as above) or
 // of v (natural order).  q / k: [LayerNorm algebra] -> per-head LayerNorm -> RoPE on the accumulators; everything leaves as bf16 through a staging tile
 // (whole 16-byte row chunks): q, k -> [B][H][Lp][DQK], v -> [B][H][Lp][DV].
@@ -653,7 +694,7 @@ __device__ __forceinline__ void qkv_request(const GemmArgs& a, int col0, int fir
 
 template <int BM, int BN, int DH, int FM, int FN, int TM, int TN, int NT, bool ZC>
 __device__ __forceinline__ void pp_store_qkv_reg(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int lane, int tid,
-                                                 const float2* zrow, const float* zgc, float* aff_l, int slot0, const QkvOperands<DH, FM>& op, unsigned long long* ts = nullptr) {
+                                                 const float2* zmr, const float* zgc, float* aff_l, int slot0, const QkvOperands<DH, FM>& op, unsigned long long* ts = nullptr) {
     constexpr int NH = 2, DQK = DH == 72 ? 80 : 64, DV = DH == 72 ? 96 : 64, FH = DH / 16, MID = (DH % 16) != 0;
     static_assert(NH * DH == BN && TN == BN && FN == 2 * FH + MID && (DH % 16 == 0 || DH % 16 == 8), "two whole heads per tile, a wave holds whole rows");
     constexpr int PITCH = BN + 8;                                       // bf16 elements per staging row
@@ -680,11 +721,11 @@ __device__ __forceinline__ void pp_store_qkv_reg(const GemmArgs& a, f32x4 (&acc)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         if constexpr (ZC) {   // LayerNorm algebra: the projection of LN(x) g + c is  r (acc - mu G') + C'
-            // G' / C' of the lane's four columns are re-read per fragment (LDS: parked behind the ring by z_finish; per-row timesteps: global, the slot differs
+            // G' / C' of the lane's four columns are re-read per fragment (LDS: parked behind the ring by z_late_load; per-row timesteps: global, the slot differs
             // between rows) instead of being held for the whole tile (2 x FN float4 = 72 registers)
             const int ncl = a.N - 4;
             const int rl = wm * TM + i * 16 + m_in;
-            const float2 mr = zrow[rl];
+            const float2 mr = zmr[i];
             const float r = mr.y, rm = mr.y * mr.x;
             if (!a.row_slot) {
 #pragma unroll
@@ -821,6 +862,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     asm("" : "+s"(M_), "+s"(zG_), "+s"(zC_));
     const float *rb_ = a.bias, *rg_ = a.gate, *rz_ = a.zg, *rz2_ = a.zg2;   // the same for the producer's per-column vectors (EPI_RESID)
     if constexpr (EPI == EPI_RESID) asm("" : "+s"(M_), "+s"(rb_), "+s"(rg_), "+s"(rz_), "+s"(rz2_));
+    const float *rc_ = a.hn.rope_cos, *rs_ = a.hn.rope_sin;                 // ... and for the RoPE tables the fused-QKV warm-up chooses between per thread
+    if constexpr (EPI == EPI_QKV) asm("" : "+s"(M_), "+s"(rc_), "+s"(rs_));
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -845,21 +888,24 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
 
     // VAR & 64 ("ZM"): EPI_GEGLU / EPI_QKV finish a LayerNorm in their epilogue (GemmArgs.z*, consumer side)
     constexpr bool ZM = (VAR & 64) != 0;
-    float2* zrow = reinterpret_cast<float2*>(smem + NS * STAGE);   // [BM] (mu, r) of this tile's rows, behind the ring
-    // LayerNorm algebra, consumer side: the partial statistics of the tile's rows (four threads per row, part-major table) and the G' / C'
-    // slices of the tile's columns (one float4 per thread) are requested right BEHIND the first K tile's LDS-DMA (z_late_load), waited for together
-    // with that tile (the counted wait that leaves only the YOUNGER tiles in flight) and turned into (mu, r) / parked in LDS behind the ring
-    // (z_finish) in front of the barrier that opens the K loop: the first tile's wait is needed anyway, the requests overlap it, no register
-    // rides through the loop and the epilogue needs no extra barrier (so the GEGLU math still overlaps the other group's last MFMA phase).  Ledger of the alternatives: profiles/r04_experiments.txt.
+    // LayerNorm algebra, consumer side: the G' / C' slices of the tile's columns go straight into the LDS table `zgc` by LDS-DMA right BEHIND the first K tile (z_late_load) and are not
+    // waited for in front of the loop; the partial statistics of the rows a lane finishes are requested by that lane when the loop enters its last PD tiles and merged behind the
+    // loop (z_lane_load / z_lane_finish above): nothing of the algebra sits between the prologue and the loop's first barrier any more, no register rides through the steady-state
+    // loop, and the epilogue needs no extra barrier.  Ledger of the alternatives: profiles/r04_experiments.txt, r06_experiments.txt (r06o, r06r - r06v).
     float* zgc = reinterpret_cast<float*>(smem + NS * STAGE + BM * 8);   // [2][BN]: G' | C' of this tile's columns (shared modulation slot only); EPI_RESID: [4][BN] bias | gate | LayerNorm gain | DUAL: the alternative gain
-    ZStatRegs zst;
-    f32x2 zs_b[Z_PT];   // the row statistics of this thread's row quarter, requested by blind loads (ld8_blind above)
+    constexpr bool ZMC = ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV);     // this instantiation finishes a LayerNorm in its epilogue
+    constexpr int FMR = SCHED == 1 ? FM : FM / 2;                        // 16-row fragments a lane finishes in the epilogue (SCHED 2: after the k-split exchange)
+    constexpr int NZT = ZMC ? FMR * Z_PT : 0;                            // blind statistics loads per lane (into AGPRs), issued by z_late_load
+    ZLaneRegs<FMR> zlr;
     const bool z_shared_slot = a.row_slot == nullptr;
     // threads that fetch one float4 of the epilogue's per-column vectors (LDS-DMA in z_late_load), and whether THIS wave is one of theirs: its counted wait in front of the
     // K loop then leaves that one DMA in flight (nt >= 2: the wait for K tile 1, which is younger, covers it)
     constexpr int ZNV = EPI == EPI_RESID ? ((VAR & 256) ? 4 : 3) * (BN / 4) : 2 * (BN / 4);
-    const bool zx = ((ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV) && z_shared_slot) || EPI == EPI_RESID) && wave * 64 < ZNV && nt >= 2;
-    constexpr bool ZP = (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) || EPI == EPI_RESID;   // this instantiation parks per-row / per-column vectors behind the ring
+    // zx = LDS-DMA instructions THIS wave issues in z_late_load on top of the NZT statistics loads every wave issues there (0 .. 2, wave-uniform): the per-column vectors'
+    // (the first waves only) and, fused QKV, the RoPE-table warm-up (every wave of a q / k tile).  The counted wait in front of the K loop leaves all of them in flight;
+    // they are older than every K tile but the first, so the wait for K tile 1 (nt >= 2) covers them
+    const bool z_warm = EPI == EPI_QKV && rc_ && col0 < 2 * a.hn.H * a.hn.dh;
+    const int zx = nt >= 2 ? ((((ZMC && z_shared_slot) || EPI == EPI_RESID) && wave * 64 < ZNV) ? 1 : 0) + (z_warm ? 1 : 0) : -1;   // (-1: a single K tile -- wait for everything)
     // G' / C' live in the table of the CURRENT modulation slot: their address needs the device step counter (slot0, a scalar load issued at
     // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
     // of the first tile (it did: +1 us per consumer launch)
@@ -871,13 +917,13 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             // at the same time, and no longer in the L2 by then (the kernels in between stream through it): each thread pulls one end of one row
             // of one table towards its L2 now -- a 4-byte LDS-DMA into a sink, nothing waits for it, no register is held
             const HeadNormArgs& hn = a.hn;
-            if (hn.rope_cos && col0 < 2 * hn.H * hn.dh) {
+            if (z_warm) {
                 const int r = tid >> 2, which = tid & 3;
                 int m = row0 + r;
                 m = m < a.M ? m : a.M - 1;
                 int b_, l_;
                 divmod_rows(m, hn.L, __builtin_amdgcn_rcpf((float)hn.L), b_, l_);
-                const char* src = reinterpret_cast<const char*>((which & 2) ? hn.rope_sin : hn.rope_cos) + ((long)l_ * (hn.dh / 2) + ((which & 1) ? hn.dh / 2 - 1 : 0)) * 4;
+                const char* src = reinterpret_cast<const char*>((which & 2) ? rs_ : rc_) + ((long)l_ * (hn.dh / 2) + ((which & 1) ? hn.dh / 2 - 1 : 0)) * 4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(smem + NS * STAGE + BM * 8 + 2 * BN * 4 + wave * 256), 4, 0, 0);
             }
@@ -903,32 +949,9 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((which ? zC_ : zG_) + (long)slot0 * a.zt_slot_stride + cp),
                                                  (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(zgc) + wave * 1024), 16, 0, 0);
             }
-        }
-    };
-    // the row statistics (no step counter in their address) go out in FRONT of the first K tile's LDS-DMA: they were written by the launch before this one and are as cold as the
-    // tile, so behind it they landed behind it -- and the merge below is what the K loop's first barrier waits for
-    auto z_early_load = [&]() {
-        if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            static_assert(4 * BM == NT, "four threads per row: EVERY thread loads, no branch (ld8_blind)");
-            int row = row0 + (tid >> 2);
-            row = row < a.M ? row : a.M - 1;
-            const float2* st = a.zstat_in + row;
-            const int pg = tid & 3;
-#pragma unroll
-            for (int k = 0; k < Z_PT; ++k) {   // (z_row_stats_load, common.h, as blind loads)
-                const int p = pg + 4 * k;
-                zs_b[k] = ld8_blind(st + (p < a.zparts ? p : a.zparts - 1) * a.zs_stride);
-            }
-        }
-    };
-    auto z_finish = [&]() {   // behind a wait for the loads of z_early_load; the caller puts a workgroup barrier between this and the first reader
-        if constexpr (ZM && (EPI == EPI_GEGLU || EPI == EPI_QKV)) {
-            // the blind loads' outputs are named HERE first, behind the caller's counted wait (volatile asm statements keep their order)
-#pragma unroll
-            for (int k = 0; k < Z_PT; ++k) { asm volatile("" : "+v"(zs_b[k])); zst.v[k] = make_float2(zs_b[k][0], zs_b[k][1]); }
-            const float2 mr = z_row_stats_finish(zst, a.zparts, tid & 3, a.zD, a.zeps);
-            if ((tid & 3) == 0) lds_st8_blind(lds_offset_of(zrow + (tid >> 2)), f32x2{mr.x, mr.y});
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stores have reached the LDS before the caller's barrier lets the readers go
+            // the partial statistics of the rows this lane finishes in the epilogue: blind loads into AGPRs (every lane, no branch), in flight through the first K tile
+            const int frow = SCHED == 1 ? row0 + wm * TM + (lane & 15) : row0 + (wm * 2 + grp) * (TM / 2) + (lane & 15);
+            z_lane_load<FMR>(a.zstat_in, a.zs_stride, a.zparts, frow, a.M - 1, lane >> 4, zlr);
         }
     };
     unsigned long long* ts = (a.ts && wave == 0) ? a.ts + 8 * (long)blockIdx.x : nullptr;
@@ -1065,14 +1088,12 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             using IB = std::integral_constant<int, PB>;
             using IE = std::integral_constant<int, PE>;
             // prologue: tiles 0 .. PD-1; tile 0 must be complete (every wave's share) before interval 0
-            z_early_load();
 #pragma unroll
             for (int t = 0; t < PD; ++t) {
                 if (t < nt) issue(t, IB{}, IE{});
-                if (t == 0) z_late_load();   // right behind tile 0: the wait for tile 0 below (everything but the YOUNGER tiles' pieces) covers these loads too
+                if (t == 0) z_late_load();   // right behind tile 0 (one LDS-DMA, left in flight by the wait below: zx)
             }
-            wait_younger_x<PG, PD - 1>((nt < PD ? nt : PD) - 1, zx);
-            z_finish();
+            if (zx < 0) wait_vmcnt<0>(); else wait_younger_x<PG, PD - 1, NZT>((nt < PD ? nt : PD) - 1, zx);
             barrier();
             if constexpr (G == 1) barrier();   // interval 0: group 1 has nothing to do yet
             auto step = [&](int t, auto RF_) {
@@ -1116,9 +1137,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         };
         auto run = [&](auto G_) {
             constexpr int G = decltype(G_)::value;
-            // the z loads go out right behind tile 0 in the group that owns it, in front of its first tile in the other group: in both, the
-            // counted wait for "everything but my younger tiles" covers them
-            z_early_load();
+            // z_late_load (the per-column vectors' LDS-DMA; fused QKV: the RoPE-table warm-up) goes out right behind tile 0 in the group that owns it, in front of its first
+            // tile in the other group; nothing in front of the loop waits for it in the other group
             if constexpr ((PD & 1) != G) z_late_load();
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
@@ -1127,10 +1147,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             }
             {
                 const int last = PD - 1 < nt - 1 ? PD - 1 : nt - 1;
-                if constexpr ((PD & 1) == G) wait_younger_x<NP, (PD - 1) / 2>(last >= 2 ? last / 2 : 0, zx);      // owner of tile 0: own younger tiles 2, 4, ...
-                else if constexpr (ZP) wait_younger_x<NP, PD / 2>((last + 1) / 2, zx);                            // the other group: own tiles 1, 3, ... stay in flight
+                if constexpr ((PD & 1) == G) { if (zx < 0) wait_vmcnt<0>(); else wait_younger_x<NP, (PD - 1) / 2, NZT>(last >= 2 ? last / 2 : 0, zx); }   // owner of tile 0: own younger tiles 2, 4, ...
             }
-            z_finish();
             barrier();
             // end of interval i: the owner of tile i + 1 -- group (i + 1 + PD) & 1 -- makes sure it has landed.  Group G's LOAD intervals are
             // i = G mod 2, so it owns tile i + 1 at the end of its LOAD intervals iff PD is odd, at the end of its MFMA (and idle) intervals
@@ -1183,6 +1201,12 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) asm volatile("" : "+a"(acc[i][j]));
+    // LayerNorm algebra: (mu, r) of the rows this lane finishes (the statistics were requested behind the first K tile and landed under the loop)
+    float2 zmr[FMR];
+    if constexpr (ZMC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        z_lane_finish<FMR>(zlr, a.zparts, lane >> 4, a.zD, a.zeps, zmr);
+    }
     if constexpr (SCHED == 2) {
         // exchange the two groups' partial sums through the (dead) ring: group g keeps the row fragments [g * FM/2, (g + 1) * FM/2) of its
         // wave tile and parks the others for its partner wave (same wg, other group); lane-linear 16-byte accesses
@@ -1263,14 +1287,14 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
             static_assert(BM * (BN + 4) * 4 + BM * BN * 2 <= NS * STAGE, "epilogue tile + staging must fit the ring");
             static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "bf16 staging tile must fit the ring");
-            if (a.hn.perm) pp_store_qkv_reg<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, lane, tid, zrow, zgc, reinterpret_cast<float*>(smem + NS * STAGE + BM * 8 + 2 * BN * 4 + 8 * 256), slot0, qop, ts);
-            else pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zrow, zgc, slot0);
+            if (a.hn.perm) pp_store_qkv_reg<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, lane, tid, zmr, zgc, reinterpret_cast<float*>(smem + NS * STAGE + BM * 8 + 2 * BN * 4 + 8 * 256), slot0, qop, ts);
+            else pp_store_qkv<BM, BN, BN / 2, HF, FN, TM / 2, TN, NT, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, zmr, zgc, slot0);
         }
         if constexpr (EPI == EPI_GEGLU || EPI == EPI_PARTIAL) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
-                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, zrow, zgc, slot0, ts);
+                    pp_store_lds<BM, BN, HF, FN, TM / 2, TN, NT, EPI, ZM>(a, half, smem, row0, col0, ewm, wn, lane, tid, z, zmr, zgc, slot0, ts);
                     if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
                     return;
                 }
@@ -1282,7 +1306,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
             constexpr bool lds_ok = BM * ((EPI == EPI_GEGLU ? BN / 2 : BN) + 8) * 2 <= NS * STAGE;
             if constexpr (lds_ok) {
                 if (EPI == EPI_GEGLU || a.part_bf16) {
-                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, zrow, zgc, slot0, ts);
+                    pp_store_lds<BM, BN, FM, FN, TM, TN, NT, EPI, ZM>(a, acc, smem, row0, col0, wm, wn, lane, tid, z, zmr, zgc, slot0, ts);
                     if (ts && lane == 0) { ts[3] = __builtin_readcyclecounter(); ts[7] = __builtin_amdgcn_s_memrealtime(); }
                     return;
                 }

@@ -599,12 +599,13 @@ def test_dual_form_constant_vector_registers_are_not_touched_before_their_wait()
     assert checked >= 1, checked
 
 
-def test_blind_loads_of_the_layernorm_algebra_consumers_are_not_touched_before_the_counted_wait():
-    """The LayerNorm-algebra consumers (k_gemm_pp, k_gemm_co) request the row statistics by inline-asm loads (gemm_pp.h ld8_blind) and park (mu, r) by an inline-asm LDS store, so
-    that hipcc does not drain vmcnt(0) in front of the K loop (G' / C' go straight into the LDS by LDS-DMA); the compiler believes an asm output defined at once.  On
-    the generated gfx950 code of every consumer instantiation: in front of the first MFMA hipcc itself neither waits on vmcnt nor loads a vector from global memory (everything of
-    that kind sits inside an inline-asm block); the `global_load_dwordx2 v[..]` there are not named by any instruction until a counted `s_waitcnt vmcnt(N)` follows them; and the
-    only LDS stores in front of the loop are the blind ds_write_b64 of (mu, r)."""
+def test_blind_statistics_loads_of_the_layernorm_algebra_consumers_are_not_touched_before_their_wait():
+    """The LayerNorm-algebra consumers (k_gemm_pp, k_gemm_co) fetch the row statistics a lane needs by inline-asm loads into AGPRs (gemm_pp.h ld8_blind) behind their first K
+    tile and merge them behind the loop; G' / C' go straight into the LDS by LDS-DMA.  hipcc neither counts nor waits for an asm load -- and believes its output defined at once
+    (ADVICE r05).  On the generated gfx950 code of every consumer instantiation: (1) in front of the first MFMA hipcc itself neither waits on vmcnt nor loads a vector from global
+    memory nor stores to the LDS (everything of that kind sits inside an inline-asm block): the loop starts behind the first K tile and nothing else; (2) from each inline-asm
+    `global_load_dwordx2 a[..]`, in program-text order, no instruction READS a destination register before an `s_waitcnt` with vmcnt(0) has been passed (a copy the
+    allocator inserts next to the accumulators would move data that has not arrived; an MFMA that accumulates into one of them would be worse)."""
     import re
     funcs = _gfx950_isa('gemm.hip')
     checked = 0
@@ -616,7 +617,6 @@ def test_blind_loads_of_the_layernorm_algebra_consumers_are_not_touched_before_t
         epi, var = (targs[5], targs[7]) if m.group(1) == 'pp' else (targs[2], targs[3])
         if not (var & 64) or epi not in (2, 3):   # EPI_GEGLU = 2, EPI_QKV = 3 with the LayerNorm algebra
             continue
-        # in front of the first MFMA, hipcc itself must neither wait on vmcnt nor load a vector from global memory: everything of that kind sits inside an inline-asm block
         raw = f.splitlines()
         first_mfma_raw = next(i for i, l in enumerate(raw) if l.strip().startswith('v_mfma'))
         inasm = False
@@ -629,37 +629,53 @@ def test_blind_loads_of_the_layernorm_algebra_consumers_are_not_touched_before_t
             elif not inasm:
                 assert not (t.startswith('s_waitcnt') and 'vmcnt' in t), (name, t)
                 assert not re.match(r'global_load_dword\w* v', t), (name, t)
-        lines = [l.strip().split(';')[0].strip() for l in f.splitlines()]
-        lines = [l for l in lines if l and not l.startswith('.') or re.match(r'\.LBB\d+_\d+:', l or '')]
-        first_mfma = next(i for i, l in enumerate(lines) if l.startswith('v_mfma'))
-        pro = lines[:first_mfma]
-        ld2 = [(i, int(mm.group(1)), int(mm.group(2))) for i, l in enumerate(pro) if (mm := re.match(r'global_load_dwordx2 v\[(\d+):(\d+)\]', l))]
-        assert len(ld2) >= 3, (name, len(ld2))   # Z_PT per row quarter (SCHED 2 emits the prologue once per wave group; k_gemm_co serves two rows per thread)
-        loads = sorted(ld2)
-        # every load: walk forward until the first ds_write (the parks of z_finish); a counted vmcnt wait must come first, and nothing may name the destination before it
-        for i, a, b in loads:
-            regs = set(range(a, b + 1))
-            waited = False
-            for j in range(i + 1, first_mfma):
-                ins = pro[j]
-                if ins.startswith('s_waitcnt') and 'vmcnt(' in ins:
-                    waited = True
-                if ins.startswith('ds_write'):
-                    assert waited, (name, pro[i], ins)
+                assert not t.startswith('ds_write'), (name, t)
+        lines, blind, inasm = [], set(), False   # blind = indices (into `lines`) of the vector loads that sit inside an inline-asm block (hipcc tracks the others itself)
+        for l in raw:
+            t = l.strip()
+            if t.startswith(';;#ASMSTART'):
+                inasm = True
+                continue
+            if t.startswith(';;#ASMEND'):
+                inasm = False
+                continue
+            t = t.split(';')[0].strip()
+            if t and (not t.startswith('.') or re.match(r'\.LBB\d+_\d+:', t)):
+                if inasm and t.startswith('global_load_dwordx2 a['):
+                    blind.add(len(lines))
+                lines.append(t)
+        loads = {i: set(range(int(mm.group(1)), int(mm.group(2)) + 1)) for i in blind if (mm := re.match(r'global_load_dwordx2 a\[(\d+):(\d+)\]', lines[i]))}
+        assert len(loads) >= 3, (name, len(loads))
+
+        def regs_of(text):
+            regs = {int(x) for x in re.findall(r'\ba(\d+)\b', text)}   # (the blind loads land in AGPRs)
+            for x, y in re.findall(r'\ba\[(\d+):(\d+)\]', text):
+                regs |= set(range(int(x), int(y) + 1))
+            return regs
+
+        # from each blind load, in program-text order: an instruction that READS a destination register must have an `s_waitcnt .. vmcnt(0)` between the load and itself; an
+        # instruction that only WRITES one ends that register's watch (a new value: the code of the other wave group, which the layout puts behind this one's)
+        for i, dest in loads.items():
+            pending, waited = set(dest), False
+            for ins in lines[i + 1:]:
+                if not pending or ins.startswith('s_endpgm'):
                     break
-                if waited:
+                if re.match(r'\.LBB\d+_\d+:', ins) or ' ' not in ins:
                     continue
-                ops = ins.split(None, 1)[1] if ' ' in ins else ''
-                named = {int(x) for x in re.findall(r'\bv(\d+)\b', ops)}
-                for x, y in re.findall(r'\bv\[(\d+):(\d+)\]', ops):
-                    named |= set(range(int(x), int(y) + 1))
-                if re.match(r'\.LBB|s_cbranch|s_branch', ins):
+                op, ops = ins.split(None, 1)
+                if op == 's_waitcnt':
+                    waited = waited or 'vmcnt(0)' in ops
                     continue
-                assert not (named & regs), (name, pro[i], ins)
-        stores = [l for l in pro if l.startswith('ds_write')]
-        assert stores and all(l.startswith('ds_write_b64') for l in stores), (name, stores)
+                is_store = op.startswith(('global_store', 'ds_write', 'buffer_store', 'scratch_store'))
+                first, _, rest = ops.partition(',')
+                read = regs_of(ops if is_store else rest) & pending
+                if op.startswith(('global_load', 'buffer_load', 'ds_read')):   # (address operands)
+                    read = regs_of(rest) & pending
+                assert not read or waited, f'{name}: {ins!r} reads a blind load\'s destination before any vmcnt(0)'
+                if not is_store:
+                    pending -= regs_of(first)
         checked += 1
-    assert checked >= 3, checked
+    assert checked >= 4, checked
 
 
 def test_inline_asm_mfma_results_are_read_behind_their_wait_states():
