@@ -56,6 +56,7 @@ struct WsPtrs {  // workspace regions used on the per-step path, resolved once a
     uint8_t* kmask; bf16_t *kc, *vc; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
     float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
+    float2* zstat_skip; float* zt_skip;                // ... of the out-blocks' LN_2D([x | skip]) -> skip_linear: the skips' statistics (kept from the in-block to its out-block), static tables
     float* zd;   // [nblk][B][D] constant cross-attention-out vectors of the single-key batch elements (opt_xkey1)
 };
 
@@ -119,6 +120,13 @@ struct ezdit_handle {
     // of the 102 row-kernel launches of an XL step less (239 launches instead of 325), the same algebra as the reference (goldens pass at the
     // same gates).  Needs gemm_pp bits 0 and 1 and a LayerNorm-algebra q projection; otherwise the step falls back to split-K slabs + the row kernel.
     int opt_zfuse = 1;
+    // ... and the out-blocks' LN_2D([x | skip]) -> skip_linear (blocks.py:124-128) the same way (round 6, k_gemm_ks forms COPY2 / ZIN, gemm_ks.h): the statistics of the concatenation
+    // are the sums of the halves'; the in-block that produces `skip` keeps them and writes bf16(skip g[D:]) into the right half of ITS out-block's operand (one operand buffer per
+    // out-block), the MLP-out projection in front of the out-block runs un-split and writes bf16(x g[:D]) + statistics, skip_linear finishes the LayerNorm in its epilogue:
+    // 14 split-K GEMMs + 14 row-kernel launches of an XL step become 14 un-split launches (225 launches instead of 239).  k_gemm_ks shapes only (M <= kZBigM rows);
+    // ControlNet residuals change the skips (skip + scale * residual) and take the row-kernel path.
+    int opt_skip_z = 1;
+    bool skip_z_usable() const { return opt_skip_z && !is_cn && nhalf > 0 && ztile() == kZTile && (D + zwidth() - 1) / zwidth() <= 16; }
     // GEGLU GEMM on the co-resident kernel (k_gemm_co, gemm_co.h: 4-wave workgroups with a 128 x 144 tile, TWO per CU, so that a workgroup's prologue and
     // epilogue run under its neighbour's K loop): 0 = never, 1 = above kCoM rows (batched prompts: the ping-pong kernel runs 4 rounds of workgroups there), 2 = always
     int opt_geglu_co = 0;
@@ -378,8 +386,9 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("h", Mp * D * 4);
     add("skips", (size_t)h->nhalf * Mp * D * 4);
     add("u", Mp * h->ldD * 2);
-    add("ucat", Mp * h->ld2D * 2);                        // LN_2D([x | skip]) of the out-blocks: its own buffer, because the skip GEMM that reads it
-                                                          // writes `u` from inside the same launch (fused row operator)
+    // LN_2D([x | skip]) of the out-blocks: its own buffer, because the skip GEMM that reads it writes `u` from inside the same launch (fused row operator).
+    // One per out-block where the LayerNorm algebra covers skip_linear (opt_skip_z): the in-block fills the right half long before the out-block runs
+    add("ucat", (size_t)((M <= ezdit_handle::kZBigM && !h->is_cn && h->nhalf > 0) ? h->nhalf : 1) * Mp * h->ld2D * 2);
     add("qkv", Mp * 3 * D * 4);
     add("q", (size_t)B * H * Lp * h->DQK * 2);
     add("k", (size_t)B * H * Lp * h->DQK * 2);
@@ -413,10 +422,12 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     // LayerNorm algebra: partial row statistics (chunks of 64 columns, up to the 2D-wide concat), G' / C' tables per modulation slot
     {
         const long I2 = 2L * h->I, N3 = 3L * D, nmax = I2 > N3 ? I2 : N3;
-        add("zstat", (size_t)Mp * ((2 * D + 63) / 64) * 8);
+        add("zstat", (size_t)Mp * (((2 * D + 63) / 64) > 2 * Z_MAXP ? ((2 * D + 63) / 64) : 2 * Z_MAXP) * 8);   // two part ranges of Z_MAXP: the second one holds the statistics of the x half in front of an out-block (skip_z)
         add("zt_qkv", (size_t)ns * nblk * 2 * N3 * 4);
         add("zt_geglu", (size_t)ns * nblk * 2 * I2 * 4);
         add("zt_q2", (size_t)nblk * 2 * D * 4);
+        add("zstat_skip", (size_t)(h->nhalf > 0 ? h->nhalf : 1) * Z_MAXP * Mp * 8);
+        add("zt_skip", (size_t)(h->nhalf > 0 ? h->nhalf : 1) * 2 * D * 4);
         add("zd", (size_t)nblk * B * D * 4);
         add("zA", (size_t)rup(4 * ns, 128) * h->ldD * 2);
         add("ztmp", (size_t)rup(4 * ns, 128) * nmax * 4);
@@ -437,6 +448,7 @@ struct Ctx {
     const HeadNormArgs* hn = nullptr;   // one-shot: EPI_QKV epilogue arguments
     bool panel = false;                 // one-shot: panel placement of a split-K GEMM (GemmArgs.xcd_panel)
     const float* zG = nullptr; const float* zC = nullptr; long zt_stride = 0;   // one-shot: LayerNorm algebra in the consumer's epilogue
+    const float2* zstat = nullptr;      // one-shot: ... its partial statistics when they are not in the shared buffer (null = WsPtrs.zstat)
     int zrow0 = 0, zb0 = 0;   // one-shot: the launch covers a row sub-range that starts at row zrow0 = batch element zb0 (statistics table / per-row slot offsets)
     const int* cur = nullptr; const int* row_slot = nullptr;   // modulation slot of this forward (a ControlNet attached to the fused sampler reads the BACKBONE's step counter)
     // first launch failure of this call (hipGetLastError after EVERY launch: a rejected launch -- LDS limit, bad grid,
@@ -495,10 +507,10 @@ void gemm(Ctx& c, const bf16_t* A, int lda, const WRef& w, const float* bias, vo
     }
 #endif
     if (c.zG) {
-        g.zw = h->zwidth(); g.zstat_in = h->p.zstat + c.zrow0; g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
+        g.zw = h->zwidth(); g.zstat_in = (c.zstat ? c.zstat : h->p.zstat) + c.zrow0; g.zs_stride = h->Mp; g.zparts = (h->D + g.zw - 1) / g.zw; g.zD = h->D; g.zG = c.zG; g.zC = c.zC; g.zt_slot_stride = c.zt_stride; g.zeps = 1e-5f;
         g.cur_step = c.cur ? c.cur : h->p.ints; g.row_slot = c.cur ? c.row_slot : (h->per_row ? h->p.ints + 16 : nullptr); g.rows_per_b = h->L;
         if (g.row_slot) g.row_slot += c.zb0;
-        c.zG = nullptr;
+        c.zG = nullptr; c.zstat = nullptr;
     }
     c.zrow0 = 0; c.zb0 = 0;
     g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
@@ -568,6 +580,7 @@ void resolve_workspace(ezdit_handle* h) {
     p.mod = h->buf<float>("mod"); p.modf = h->buf<float>("modf");
     p.zd = h->buf<float>("zd");
     p.zstat = h->buf<float2>("zstat"); p.zt_qkv = h->buf<float>("zt_qkv"); p.zt_geglu = h->buf<float>("zt_geglu"); p.zt_q2 = h->buf<float>("zt_q2");
+    p.zstat_skip = h->buf<float2>("zstat_skip"); p.zt_skip = h->buf<float>("zt_skip");
     if (h->is_cn) { p.cembed = h->buf<float>("cembed"); p.cnres = h->buf<float>("cnres"); p.skipbf = h->buf<bf16_t>("skipbf"); }
 }
 
@@ -871,6 +884,12 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
             launch_z_hilo(w.n2w, w.n2b, 0, zA, h->ldD, 1, D, st);
             gemm(c, zA, h->ldD, w.wq2, nullptr, ztmp, D, 4, D, EPI_F32, 25);
             launch_z_combine(ztmp, D, nullptr, h->p.zt_q2 + (long)b * 2 * D, h->p.zt_q2 + (long)b * 2 * D + D, 0, 1, D, st);
+            if (b > h->nhalf && h->skip_z_usable()) {   // skip_norm (static, over the 2 D columns of [x | skip]) in front of skip_linear; C' carries skip_linear.bias
+                const int j = b - h->nhalf - 1;
+                launch_z_hilo(w.snw, w.snb, 0, zA, h->ld2D, 1, 2 * D, st);
+                gemm(c, zA, h->ld2D, w.wskip, nullptr, ztmp, D, 4, D, EPI_F32, 25);
+                launch_z_combine(ztmp, D, w.bskip, h->p.zt_skip + (long)j * 2 * D, h->p.zt_skip + (long)j * 2 * D + D, 0, 1, D, st);
+            }
         }
         const hipError_t e = hipGetLastError();
         if (c.bad() || e != hipSuccess) return fail(EZDIT_E_HIP, "LayerNorm-algebra table launch failed: %s", hipGetErrorString(e));
@@ -976,17 +995,24 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     const int qkv_mode = h->qkv_mode();   // 2: fused QKV GEMM (ping-pong kernel), 0: fp32 projection + k_headnorm
     const bool zf = h->z_tables_ready && h->zfuse_usable();
     // eb0 / enb: the launch covers the batch elements [eb0, eb0 + enb) only (enb < 0: all); dual_blk >= 0: DUAL form for block dual_blk (GemmArgs.zd)
+    struct ZExtra {   // the skip path's forms of the un-split residual projection (GemmArgs: COPY2 / ZIN); whole-batch launches only
+        bf16_t* zu = nullptr; int ld_zu = 0;          // operand buffer instead of `u`
+        float2* zstat_out = nullptr;                  // statistics instead of the shared buffer
+        bf16_t* zu2 = nullptr; int ld_zu2 = 0; const float* zg2 = nullptr;   // COPY2
+        const float2 *zin = nullptr, *zin2 = nullptr; const float* zG = nullptr; int zparts = 0, zD = 0;   // ZIN
+    };
+    const float2* zstat_next = nullptr;   // where the last producer put its statistics when not in the shared buffer (handed to the next consumer: Ctx.zstat)
     auto resid_z = [&](const bf16_t* A, int lda, const WRef& w, const float* h_in, float* h_out, const float* bias, const float* gate, long gate_stride,
-                       const float* zg, long zg_stride, const char* what, int eb0 = 0, int enb = -1, int dual_blk = -1) {
+                       const float* zg, long zg_stride, const char* what, int eb0 = 0, int enb = -1, int dual_blk = -1, const ZExtra* zx = nullptr) {
         const long r0 = (long)eb0 * h->L;
         const int Ms = enb < 0 ? M : enb * h->L;
         GemmArgs g;
         memset(&g, 0, sizeof g);
         g.A = A + r0 * lda; g.lda = lda; g.W = w.W; g.ldw = w.ld; g.wrows = w.rows; g.bias = bias;
-        g.out = h_out + r0 * D; g.ldo = D; g.M = Ms; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->ztile();
+        g.out = h_out ? h_out + r0 * D : nullptr; g.ldo = D; g.M = Ms; g.N = D; g.K = w.ld; g.splitk = 1; g.epi = EPI_RESID; g.tile = h->ztile();
         // few rows (the cross-attention-out projection over one prompt's conditional rows, M = 500): 48-row tiles leave 11 x 12 = 132 workgroups for 256 CUs;
         // 32 x 96 tiles (id 72) give 16 x 12 = 192 with 11 % fewer operand bytes each: 3.968 -> 3.951 ms per step, bit-identical (profiles/r05_experiments.txt)
-        if (g.tile == ezdit_handle::kZTile && dual_blk < 0 && Ms <= 672 && g.K <= 2 * D) g.tile = 72;
+        if (g.tile == ezdit_handle::kZTile && dual_blk < 0 && !(zx && (zx->zu2 || zx->zin2)) && Ms <= 672 && g.K <= 2 * D) g.tile = 72;
         g.xcd_map = 1; g.wt = h->wt();
         g.resid = h_in ? h_in + r0 * D : nullptr; g.ldr = D; g.gate = gate; g.gate_slot_stride = gate_stride;
         g.cur_step = cur; g.row_slot = row_slot ? row_slot + eb0 : nullptr; g.rows_per_b = h->L;
@@ -996,10 +1022,23 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             g.zg2 = modv(dual_blk, 3); g.zg2_slot_stride = mod_slot;
             g.act_row0 = h->act_b0 * h->L; g.act_row1 = h->act_b1 * h->L;
         }
+        zstat_next = nullptr;
+        if (zx) {
+            if (zx->zu) { g.zu = zx->zu; g.ld_zu = zx->ld_zu; }
+            if (zx->zstat_out) { g.zstat_out = zx->zstat_out; zstat_next = zx->zstat_out; }
+            g.zu2 = zx->zu2; g.ld_zu2 = zx->ld_zu2;
+            if (zx->zu2) { g.zg2 = zx->zg2; g.zg2_slot_stride = 0; }
+            if (zx->zin2) { g.zstat_in = zx->zin; g.zstat_in2 = zx->zin2; g.zG = zx->zG; g.zparts = zx->zparts; g.zD = zx->zD; g.zeps = 1e-5f; }
+        }
         g.ts = c.stamps(); g.ts_cap = g_gemm_ts_cap;
         c.launched(what, launch_gemm(g, st));
         u_is_z = true;
     };
+    // LN_2D([x | skip]) -> skip_linear by the LayerNorm algebra (opt_skip_z): not with ControlNet residuals (they change the skips)
+    const bool skipz = zf && h->skip_z_usable() && !(cn && n_cn > 0);
+    const int zsp = (D + h->zwidth() - 1) / h->zwidth();                      // statistics parts of a D-wide producer
+    auto ucat_of = [&](int j) { return p.ucat + (size_t)j * Mp * h->ld2D; };     // operand [x | skip] of out-block j
+    auto zskip_of = [&](int i) { return p.zstat_skip + (size_t)i * Z_MAXP * Mp; };   // statistics of skip i
     // single-key shortcut (opt_xkey1): cross-attention + its out-projection cover the batch elements [xb0, xb0 + xnb) only
     const bool x1 = zf && h->opt_xkey1 && h->xkey1;
     const int xb0 = x1 ? h->act_b0 : 0, xnb = x1 ? h->act_b1 - h->act_b0 : h->B;
@@ -1021,7 +1060,12 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         if (is_out) {
             // u holds LN_2D([x | skip]) -> skip_linear (blocks.py:124-128)
             STOPCHK();
-            if (zf) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot, "k_gemm (un-split residual: skip_linear)");
+            if (skipz) {
+                const int j = b - nhalf - 1;
+                ZExtra zx;
+                zx.zin = p.zstat + (size_t)Z_MAXP * Mp; zx.zin2 = zskip_of(nhalf - 1 - j); zx.zG = p.zt_skip + (long)j * 2 * D; zx.zparts = zsp; zx.zD = 2 * D;
+                resid_z(ucat_of(j), h->ld2D, w.wskip, nullptr, hA, zx.zG + D, nullptr, 0, modv(b, 0), mod_slot, "k_gemm (un-split residual: skip_linear ZIN)", 0, -1, -1, &zx);
+            } else if (zf) resid_z(p.ucat, h->ld2D, w.wskip, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), mod_slot, "k_gemm (un-split residual: skip_linear)");
             else resid(p.ucat, h->ld2D, w.wskip, 2, nullptr, hA, w.bskip, nullptr, 0, modv(b, 0), modv(b, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = hA;
         }
@@ -1040,7 +1084,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             // head-norm + RoPE + the attention layouts inside the projection GEMM (128 x two-head tiles): no fp32 q|k|v round trip, one launch less
             hn.perm = 1;   // (qkv_mode == 2 <=> the weights were packed with EZDIT_T_QKROPE)
             c.hn = &hn;
-            if (u_is_z) { c.zG = p.zt_qkv + (long)b * 2 * 3 * D; c.zC = c.zG + 3 * D; c.zt_stride = (long)nblk * 2 * 3 * D; }
+            if (u_is_z) { c.zG = p.zt_qkv + (long)b * 2 * 3 * D; c.zC = c.zG + 3 * D; c.zt_stride = (long)nblk * 2 * 3 * D; c.zstat = zstat_next; }
             gemm(c, u, h->ldD, w.wqkv, nullptr, nullptr, 0, M, 3 * D, EPI_QKV, h->qkv_tile());
         } else {
             gemm(c, u, h->ldD, w.wqkv, nullptr, p.qkv, 3 * D, M, 3 * D, EPI_F32, tile_for(h, M, false));
@@ -1141,10 +1185,20 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
             const float* skip = skips + (size_t)(nhalf - 1 - j) * Mp * D;
             const float* cnp = (cn && n_cn > 0) ? cn[n_cn - 1 - j] : nullptr;
             if (cnp && cn_ready) { (void)hipStreamWaitEvent(st, cn_ready, 0); cn_ready = nullptr; }   // join the ControlNet stream
+            if (skipz) {   // un-split: x_new only lives on as bf16(x_new g[:D]) in the left half of the out-block's operand, statistics in the second part range of the shared buffer
+                ZExtra zx;
+                zx.zu = ucat_of(j); zx.ld_zu = h->ld2D; zx.zstat_out = p.zstat + (size_t)Z_MAXP * Mp;
+                resid_z(p.act, h->ldI, w.w2, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, 0, "k_gemm (un-split residual: MLP-out -> [x | skip])", 0, -1, -1, &zx);
+            } else
             resid(p.act, h->ldI, w.w2, 1, hA, nullptr, b2, modv(b, 5), mod_slot, h->blk[b + 1].snw, h->blk[b + 1].snb, 0, skip, cnp, h->ld2D);
         } else {
             float* dst = is_in ? skips + (size_t)b * Mp * D : hA;
-            if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot, "k_gemm (un-split residual: MLP-out)");
+            if (zf && skipz && is_in) {   // COPY2: + the skip half of the matching out-block's operand, statistics kept until that out-block
+                const int j = nhalf - 1 - b;
+                ZExtra zx;
+                zx.zstat_out = zskip_of(b); zx.zu2 = ucat_of(j) + D; zx.ld_zu2 = h->ld2D; zx.zg2 = h->blk[nhalf + 1 + j].snw + D;
+                resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot, "k_gemm (un-split residual: MLP-out COPY2)", 0, -1, -1, &zx);
+            } else if (zf) resid_z(p.act, h->ldI, w.w2, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), mod_slot, "k_gemm (un-split residual: MLP-out)");
             else resid(p.act, h->ldI, w.w2, 1, hA, dst, b2, modv(b, 5), mod_slot, modv(b + 1, 0), modv(b + 1, 1), mod_slot, nullptr, nullptr, h->ldD);
             hcur = dst;
         }
@@ -1489,6 +1543,7 @@ int ezdit_set_option(ezdit_handle* h, const char* name, int value) {
     if (!h || !name) return fail(EZDIT_E_INVALID, "null argument");
     if (!strcmp(name, "zfuse")) h->opt_zfuse = value;
     else if (!strcmp(name, "xkey1")) h->opt_xkey1 = value;
+    else if (!strcmp(name, "skip_z")) h->opt_skip_z = value;
     else if (!strcmp(name, "geglu_co")) h->opt_geglu_co = value;
     else if (!strcmp(name, "qkv_co")) h->opt_qkv_co = value;
     else if (!strcmp(name, "wt")) h->opt_wt = value;

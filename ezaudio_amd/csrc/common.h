@@ -246,6 +246,13 @@ struct GemmArgs {
     // batch elements -- the rows OUTSIDE [act_row0, act_row1) -- the attention-out projection adds that vector (zd [B][zd_stride], per batch element)
     // on top of its own gated residual and emits the operand of the GEGLU GEMM (gain zg2) instead of the cross-attention q projection's
     const float* zd; long zd_stride; const float* zg2; long zg2_slot_stride; int act_row0, act_row1;
+    // producer, COPY2 form (k_gemm_ks; null zu2 = off): a second operand  bf16(h_new * zg2) -> zu2 [M][ld_zu2]  (zg2 static: no slot) -- the in-blocks' MLP-out
+    // projection writes the `skip` half of the matching out-block's [x | skip] operand while it has the values in registers
+    bf16_t* zu2; int ld_zu2;
+    // consumer + producer, ZIN form (k_gemm_ks, EPI_RESID without gate and residual; null zstat_in2 = off): the operand is A' = bf16([x | skip] * g) with partial statistics
+    // in TWO sets of zparts parts (zstat_in: the x half, zstat_in2: the skip half; the row's statistics over zD = 2 D columns are their sums);
+    // acc := r (acc - mu G'[col]) + C'[col] with G' = zG and C' = `bias` (static tables), then the producer's epilogue as usual
+    const float2* zstat_in2;
     // consumer (EPI_QKV, EPI_GEGLU; null zstat_in = plain GEMM):
     const float2* zstat_in; int zparts; int zD; int zw; // [zparts][zs_stride] partial statistics of the operand's rows: zparts = ceil(zD / zw) <= Z_MAXP parts of zw columns (the last one ragged; zw = the producer's tile width)
     const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]

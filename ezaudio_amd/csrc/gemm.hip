@@ -424,7 +424,7 @@ int launch_co(const GemmArgs& a0, hipStream_t st) {
 }
 
 // K-split-inside-the-workgroup kernel (gemm_ks.h): 8 waves, each with private LDS slots for its own K chunks, no barrier in the K loop
-template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, bool DUAL = false>
+template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, int X = KS_PLAIN>
 int launch_ks(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
     a.xcd_panel = 0; a.splitk = 1;
@@ -440,12 +440,12 @@ int launch_ks(const GemmArgs& a0, hipStream_t st) {
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 32) return 1;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES, CK, DUAL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_ks<FM, FN, EPI, GATE, RES, CK, X>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess) return 1;
         attr_set[dev].store(true, std::memory_order_release);
     }
     if (a.ts && (long)grid.x > a.ts_cap) a.ts = nullptr;   // the stamp buffer has no room for this grid
-    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES, CK, DUAL>), grid, dim3(512), SMEM, st, a);
+    hipLaunchKernelGGL((k_gemm_ks<FM, FN, EPI, GATE, RES, CK, X>), grid, dim3(512), SMEM, st, a);
     return 0;
 }
 // tile ids of the K-split kernel: 70 = 48 x 96 (21 x 12 = 252 workgroups at M = 1000, N = 1152), 72 = 32 x 96, 73 = 48 x 64 (the final Linear, N = 128), one 64-wide K chunk
@@ -560,10 +560,18 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     }
     if (a.epi == EPI_QKV) return 1;   // (the lockstep kernel's 64 x four-head form was deleted in round 6: nothing but gemm_pp = 0 reached it)
     if (a.epi == EPI_RESID && a.tile >= 70) {   // K-split-inside-the-workgroup kernel: residual (optional) + gate (optional) + statistics + next operand
-        if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.out || !a.bias || a.splitk != 1 || (a.gate && !a.resid)) return 1;
+        if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.bias || a.splitk != 1 || (a.gate && !a.resid)) return 1;   // (null out: the fp32 stream is not stored)
         if (a.zd) {   // DUAL form: 48 x 96 tiles only
             if (!a.gate || !a.zg2 || a.tile != 70 || a.rows_per_b <= 0) return 1;
-            return launch_ks<3, 6, EPI_RESID, true, true, 64, true>(a, st);
+            return launch_ks<3, 6, EPI_RESID, true, true, 64, KS_DUAL>(a, st);
+        }
+        if (a.zu2) {   // COPY2 form: the in-blocks' MLP-out (gate + residual, 48 x 96 tiles)
+            if (!a.gate || !a.zg2 || a.tile != 70 || a.ld_zu2 <= 0) return 1;
+            return launch_ks<3, 6, EPI_RESID, true, true, 64, KS_COPY2>(a, st);
+        }
+        if (a.zstat_in2) {   // ZIN form: skip_linear (no gate, no residual, 48 x 96 tiles)
+            if (a.gate || a.resid || a.tile != 70 || !a.zstat_in || !a.zG || a.zparts <= 0 || a.zparts > 16 || a.zD <= 0) return 1;
+            return launch_ks<3, 6, EPI_RESID, false, false, 64, KS_ZIN>(a, st);
         }
         if (a.gate) return launch_ks_tile<EPI_RESID, true, true>(a, st);
         if (a.resid) return launch_ks_tile<EPI_RESID, false, true>(a, st);

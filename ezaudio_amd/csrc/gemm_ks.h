@@ -32,19 +32,32 @@ namespace {
 template <int SL>
 struct KsOperands {
     f32x4 b[SL], r[SL], g[SL], z[SL];
+    f32x2 st[4];   // KS_ZIN: four partial statistics (sum, sum of squares) of this thread's row
 };
+// forms of the EPI_RESID epilogue (template parameter X)
+constexpr int KS_PLAIN = 0;
+constexpr int KS_DUAL = 1;    // constant cross-attention-out vector for the rows outside the active range (GemmArgs.zd)
+constexpr int KS_COPY2 = 2;   // a SECOND operand bf16(h_new * zg2) -> zu2: the in-blocks' MLP-out also writes its half of the out-block's [x | skip] operand
+constexpr int KS_ZIN = 3;     // the launch also is a LayerNorm-algebra CONSUMER: acc := r (acc - mu G') + C' with (mu, r) from two sets of partial statistics (skip_linear)
 __device__ __forceinline__ f32x4 ks_ld16_agpr(const float* p) {
     f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(v) : "v"(p) : "memory");
     return v;
 }
+__device__ __forceinline__ f32x2 ks_ld8_agpr(const float2* p) {
+    f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=a"(v) : "v"(p) : "memory");
+    return v;
+}
 // all loads of this wave have landed; ties the operand registers to the wait so that no read of them can be scheduled above it
-template <int SL, int EPI, bool GATE, bool RES>
+template <int SL, int EPI, bool GATE, bool RES, int X>
 __device__ __forceinline__ void ks_operands_wait(KsOperands<SL>& op) {
+    if constexpr (X == KS_ZIN) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.st[0]), "+a"(op.st[1]), "+a"(op.st[2]), "+a"(op.st[3]));
 #pragma unroll
     for (int q = 0; q < SL; ++q) {
         if constexpr (EPI == EPI_RESID) {
-            if constexpr (GATE && RES) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.r[q]), "+a"(op.g[q]), "+a"(op.z[q]));
+            if constexpr (X == KS_ZIN) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.g[q]), "+a"(op.z[q]));
+            else if constexpr (GATE && RES) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.r[q]), "+a"(op.g[q]), "+a"(op.z[q]));
             else if constexpr (RES) asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.r[q]), "+a"(op.z[q]));
             else asm volatile("s_waitcnt vmcnt(0)" : "+a"(op.b[q]), "+a"(op.z[q]));
         } else {
@@ -85,10 +98,16 @@ __device__ __forceinline__ bool ks_tile_of_block(const GemmArgs& a, int tilesM, 
 // DUAL (EPI_RESID with gate and residual; the attention-out projection when cross-attention is skipped for single-key batch elements, GemmArgs.zd):
 // rows OUTSIDE [a.act_row0, a.act_row1) get  h_new = resid + gate (acc + bias) + zd[batch element][col]  and  A' = bf16(h_new * zg2): for them this
 // launch also is the cross-attention-out projection (whose output is the constant vector zd) and the producer of the GEGLU GEMM's operand
-template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, bool DUAL = false>
+// KS_COPY2 / KS_ZIN (round 6): the out-blocks' LN_2D([x | skip]) -> skip_linear (blocks.py:124-128) by the LayerNorm algebra.  The statistics of the concatenation are the sums of
+// the halves' statistics: the in-block that produced `skip` stored them (and bf16(skip * g[D:]) into the right half of the out-block's operand, COPY2), the MLP-out projection in front
+// of the out-block stores bf16(x * g[:D]) + its statistics, and skip_linear (ZIN) finishes the LayerNorm in its epilogue: no split-K slabs, no row kernel
+template <int FM, int FN, int EPI, bool GATE, bool RES, int CK, int X = KS_PLAIN>
 __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
+    constexpr bool DUAL = X == KS_DUAL;
     static_assert(EPI == EPI_F32 || EPI == EPI_RESID, "epilogues");
     static_assert(!DUAL || (EPI == EPI_RESID && GATE && RES), "DUAL: the gated residual projection only");
+    static_assert(X == KS_PLAIN || EPI == EPI_RESID, "forms of the residual epilogue");
+    static_assert(X != KS_ZIN || (!GATE && !RES), "ZIN: the gate's register slot carries G'");
     static_assert(FN % 2 == 0 && FM >= 1 && FM <= 4, "tile geometry: 8 lanes per output row, FN / 2 column slots each");
     static_assert(CK == 64 || CK == 32, "chunk width");
     constexpr int BM = 16 * FM, BN = 16 * FN;
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     // KsOperands) and carried through the K loop.  EVERY thread issues them (rows / columns clamped; the threads beyond the 8 BM epilogue threads
     // never use theirs) so that each wave has exactly NOPL loads behind its prologue chunks: the counted waits below rely on it, the
     // sched_barriers pin the order, and tests/test_host.py counts the loads in the generated code
-    constexpr int NOPL = SL * (1 + (EPI == EPI_RESID ? 1 + (RES ? 1 : 0) + (GATE ? 1 : 0) : 0));
+    constexpr int NOPL = SL * (1 + (EPI == EPI_RESID ? 1 + (RES ? 1 : 0) + (GATE || X == KS_ZIN ? 1 : 0) : 0)) + (X == KS_ZIN ? 4 : 0);
     KsOperands<SL> op;
     bool alt = false;          // DUAL: this thread's row belongs to a batch element whose cross-attention is the constant zd
     int brow = 0;              // ... its batch element
@@ -221,8 +240,16 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
                 if constexpr (EPI == EPI_RESID) {
                     if constexpr (RES) op.r[q] = ks_ld16_agpr(a.resid + (long)erow * a.ldr + col);
                     if constexpr (GATE) op.g[q] = ks_ld16_agpr(gsrc + col);
+                    if constexpr (X == KS_ZIN) op.g[q] = ks_ld16_agpr(a.zG + col);   // (static table: no slot)
                     op.z[q] = ks_ld16_agpr(zsrc + col);
                 }
+            }
+            if constexpr (X == KS_ZIN) {   // the 8 lanes of a row share its 2 x zparts partial statistics: lane j takes parts j and j + 8 of both sets (weight 0 beyond zparts: ks_zin_mu_r)
+                const int p1 = ej + 8 < a.zparts ? ej + 8 : a.zparts - 1;
+                op.st[0] = ks_ld8_agpr(a.zstat_in + (long)ej * a.zs_stride + erow);
+                op.st[1] = ks_ld8_agpr(a.zstat_in + (long)p1 * a.zs_stride + erow);
+                op.st[2] = ks_ld8_agpr(a.zstat_in2 + (long)ej * a.zs_stride + erow);
+                op.st[3] = ks_ld8_agpr(a.zstat_in2 + (long)p1 * a.zs_stride + erow);
             }
         };
         // per-row timesteps (ezdit_forward with one t per batch element, never the sampler): the row's slot offset is a dependent vector load.
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     if (ts && lane == 0) ts[2] = __builtin_readcyclecounter();
     // (the wait states between the last MFMA and the first read of an accumulator are inside the loop: see the last MFMA of a chunk)
 
-    ks_operands_wait<SL, EPI, GATE, RES>(op);   // (landed long ago whenever the wave had a second chunk: its vmcnt(0) covered them; here, in front of the DUAL requests below)
+    ks_operands_wait<SL, EPI, GATE, RES, X>(op);   // (landed long ago whenever the wave had a second chunk: its vmcnt(0) covered them; here, in front of the DUAL requests below)
     // ---- park this wave's partial tile in its OWN slot (dead: its last chunk was read above and nothing is in flight): [BM][S4] 16-byte
     // slots, slot s of row r at s ^ (r & 7) -- the 8 lanes of a store group hold 8 different rows of one column slot
     {
@@ -303,8 +330,8 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     // own, first touched here) and lands under the barrier and the partial sums; as plain C++ loads behind the barrier their miss sat in the epilogue
     // (in-situ stamps r05e: DUAL epilogue 9.3K cycles against 6.3 ... 7.8K of the plain form)
     f32x4 dv[SL];
-    if constexpr (DUAL) {
-        const float* dsrc = a.zd + (long)brow * a.zd_stride;
+    if constexpr (DUAL || X == KS_COPY2) {   // (COPY2: the gain of the second operand, a static vector)
+        const float* dsrc = DUAL ? a.zd + (long)brow * a.zd_stride : a.zg2;
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             int col = col0 + 4 * ks_slot_of<SL>(q, ej);
@@ -335,7 +362,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         t_sum = __builtin_readcyclecounter();
     }
     float* out = reinterpret_cast<float*>(a.out);
-    if constexpr (DUAL) {   // the asm loads of dv have landed; ties the registers to the wait
+    if constexpr (DUAL || X == KS_COPY2) {   // the asm loads of dv have landed; ties the registers to the wait
 #pragma unroll
         for (int q = 0; q < SL; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dv[q]));
     }
@@ -351,11 +378,26 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             }
         }
     } else {
+        float zmu = 0.f, zr = 1.f;
+        if constexpr (X == KS_ZIN) {   // (mu, r) of the row over the zD columns of BOTH statistics sets: fixed order, bit-reproducible
+            const bool two = ej + 8 < a.zparts;
+            float zs = (op.st[0][0] + (two ? op.st[1][0] : 0.f)) + (op.st[2][0] + (two ? op.st[3][0] : 0.f));
+            float zq = (op.st[0][1] + (two ? op.st[1][1] : 0.f)) + (op.st[2][1] + (two ? op.st[3][1] : 0.f));
+            zs = oct_sum(zs);
+            zq = oct_sum(zq);
+            const float inv_d = __builtin_amdgcn_rcpf((float)a.zD);
+            zmu = zs * inv_d;
+            zr = rsqrtf(fmaxf(fmaf(zq, inv_d, -zmu * zmu), 0.f) + a.zeps);
+        }
         float s1 = 0.f;
 #pragma unroll
         for (int q = 0; q < SL; ++q) {
             const int col = col0 + 4 * ks_slot_of<SL>(q, ej);
             const bool ok = col < a.N;
+            if constexpr (X == KS_ZIN) {   // finish the LayerNorm of the operand: r (acc - mu G') (+ C' = the `bias` operand, below)
+                v[q].x = zr * fmaf(-zmu, op.g[q][0], v[q].x); v[q].y = zr * fmaf(-zmu, op.g[q][1], v[q].y);
+                v[q].z = zr * fmaf(-zmu, op.g[q][2], v[q].z); v[q].w = zr * fmaf(-zmu, op.g[q][3], v[q].w);
+            }
             // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
             float4 x = make_float4(v[q].x + op.b[q][0], v[q].y + op.b[q][1], v[q].z + op.b[q][2], v[q].w + op.b[q][3]);
             if constexpr (GATE) { x.x *= op.g[q][0]; x.y *= op.g[q][1]; x.z *= op.g[q][2]; x.w *= op.g[q][3]; }
@@ -365,7 +407,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             }
             v[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
             s1 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
-            if (row_ok && ok) {
+            if (row_ok && ok && out) {   // (null out: nothing reads the fp32 stream behind this launch -- the MLP-out in front of an out-block)
                 float* dst = out + (long)erow * a.ldo + col;
                 if (a.wt) st16_wt(dst, v[q]); else *reinterpret_cast<float4*>(dst) = v[q];
             }
@@ -385,9 +427,9 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
             pk[q].y = pack_bf2(v[q].z * op.z[q][2], v[q].w * op.z[q][3]);
         }
         bf16_t* zrow = a.zu + (long)erow * a.ld_zu;
-        auto store8 = [&](int col, uint2 lo, uint2 hi) {   // columns [col, col + 8) of this row
+        auto store8 = [&](int col, uint2 lo, uint2 hi, bf16_t* rowp) {   // columns [col, col + 8) of this row
             if (!row_ok || col >= a.N) return;
-            bf16_t* dst = zrow + col;
+            bf16_t* dst = rowp + col;
             if (col + 8 <= a.N) {
                 const float4 f = make_float4(__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y));
                 if (a.wt) st16_wt(dst, f); else *reinterpret_cast<float4*>(dst) = f;
@@ -395,15 +437,26 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
                 *reinterpret_cast<uint2*>(dst) = lo;
             }
         };
+        auto store_row = [&](bf16_t* rowp) {
 #pragma unroll
-        for (int q = 0; q + 1 < 2 * (SL / 2); q += 2) store8(col0 + 4 * ks_slot_of<SL>(q, ej), pk[q], pk[q + 1]);
-        if constexpr (SL & 1) {
-            // the single slot: lanes (2 i, 2 i + 1) hold the two halves of one 8-column chunk; the even lane stores it
-            const uint2 mine = pk[SL - 1];
-            uint2 other;
-            other.x = quad_xor1_u32(mine.x);
-            other.y = quad_xor1_u32(mine.y);
-            if ((ej & 1) == 0) store8(col0 + 4 * ks_slot_of<SL>(SL - 1, ej), mine, other);
+            for (int q = 0; q + 1 < 2 * (SL / 2); q += 2) store8(col0 + 4 * ks_slot_of<SL>(q, ej), pk[q], pk[q + 1], rowp);
+            if constexpr (SL & 1) {
+                // the single slot: lanes (2 i, 2 i + 1) hold the two halves of one 8-column chunk; the even lane stores it
+                const uint2 mine = pk[SL - 1];
+                uint2 other;
+                other.x = quad_xor1_u32(mine.x);
+                other.y = quad_xor1_u32(mine.y);
+                if ((ej & 1) == 0) store8(col0 + 4 * ks_slot_of<SL>(SL - 1, ej), mine, other, rowp);
+            }
+        };
+        store_row(zrow);
+        if constexpr (X == KS_COPY2) {   // A'' = bf16(h_new * zg2) -> zu2 (the out-block's [x | skip] operand, right half)
+#pragma unroll
+            for (int q = 0; q < SL; ++q) {
+                pk[q].x = pack_bf2(v[q].x * dv[q][0], v[q].y * dv[q][1]);
+                pk[q].y = pack_bf2(v[q].z * dv[q][2], v[q].w * dv[q][3]);
+            }
+            store_row(a.zu2 + (long)erow * a.ld_zu2);
         }
     }
     if (ts && lane == 0) {

@@ -237,6 +237,9 @@ int ezdit_debug_stop_after(ezdit_handle* h, int n_launches);
  *   xkey1 0/1, default 1 (single-key cross-attention shortcut, needs zfuse: a batch element whose context mask has ONE valid key -- every unconditional
  *     row of classifier-free guidance -- gets the constant W_o v_key + b_o from the attention-out projection instead of a cross-attention launch;
  *     cross-attention and its out-projection then run over the other batch elements only.  Exact (softmax over one key is 1); 0 = every row through k_attn)
+ *   skip_z 0/1, default 1 (needs zfuse; M <= 2048 token rows, no ControlNet residuals: the out-blocks' LayerNorm over [x | skip] in front of skip_linear by the same algebra --
+ *     the in-block that produces a skip keeps its statistics and writes its half of the out-block's operand, the MLP-out projection in front of the out-block runs un-split,
+ *     skip_linear finishes the LayerNorm in its epilogue: one launch less per out-block; 0 = split-K slabs + the row kernel on that edge)
  *   geglu_co / qkv_co 0/1/2 (GEGLU GEMM / fused QKV GEMM on the co-resident kernel k_gemm_co (csrc/gemm_co.h): 4-wave workgroups, 128 x 144 tiles, TWO per CU, so that one
  *     workgroup's prologue / epilogue runs under the other's K loop; 1 = above 2048 token rows (batched prompts), 2 = always, 0 = the ping-pong kernel's 128 x 288 tile.
  *     Defaults: geglu_co 0, qkv_co 1 -- four prompts per GPU -1.5 % per step, one prompt untouched)

@@ -318,11 +318,44 @@ def test_layernorm_algebra_and_split_k_paths_match_reference_golden(lib, dev, na
     finally:
         assert lib.ezdit_set_option(m._h, b'zfuse', 1) == 0
     nblk = cfg['depth'] + 1
-    assert n_z == n_base - (2 * nblk + cfg['depth'])      # attention-out and cross-out of every block, MLP-out in front of in / mid blocks, skip_linear of the out-blocks
+    x_shape = np.asarray(inp['x']).shape     # [B, C, L]
+    skip_z = x_shape[0] * x_shape[-1] <= 2048   # (option skip_z: LN_2D([x | skip]) -> skip_linear by the algebra as well, k_gemm_ks shapes only: one launch less per out-block)
+    # attention-out and cross-out of every block, MLP-out in front of in / mid blocks, skip_linear of the out-blocks (+ the MLP-out in front of every out-block with skip_z)
+    assert n_z == n_base - (2 * nblk + cfg['depth'] + (cfg['depth'] // 2 if skip_z else 0))
     for what, p in (('zfuse', pred), ('split-K', base)):
         r, a = rel_l2(p, ref), float(np.abs(p - ref).max())
         record(f'{name} t={t} {what}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {n_base} -> {n_z}')
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48)
+
+
+@pytest.mark.parametrize('name', ['xs', 'xs64', 'xs_edit', 'xs_cn', 's', 'l', 'xl'])
+def test_skip_connection_layernorm_by_the_algebra_matches_reference_golden(lib, dev, name):
+    """Option skip_z (default ON; blocks.py:124-128): the out-blocks' LayerNorm over [x | skip] in front of skip_linear by the LayerNorm algebra -- the in-block that produces a skip
+    keeps its partial statistics and writes bf16(skip g[D:]) into the right half of its out-block's operand (k_gemm_ks COPY2), the MLP-out projection in front of the out-block runs
+    un-split, skip_linear finishes the LayerNorm in its epilogue (ZIN) -- against skip_z = 0 (split-K slabs + the row kernel on that edge): both inside the gates of the reference's
+    own outputs, one launch less per out-block.  With ControlNet residuals (xs_cn: skip + residual changes the statistics) the row-kernel path must run: same launch count, same bits."""
+    cfg, sd, inp, kw, g, meta = golden_case(name)
+    m = get_model(meta['size'], meta['seed_w'])
+    t = meta['timesteps'][0]
+    ref = g[f'pred_t{t}']
+    outs, launches = {}, {}
+    try:
+        for v in (1, 0):
+            assert lib.ezdit_set_option(m._h, b'skip_z', v) == 0
+            outs[v] = _forward(m, inp, t, kw).cpu().numpy()
+            launches[v] = m.last_launch_count
+    finally:
+        assert lib.ezdit_set_option(m._h, b'skip_z', 1) == 0
+    if 'controlnet_skips' in kw:
+        assert launches[1] == launches[0]
+        np.testing.assert_array_equal(outs[1], outs[0])
+    else:
+        assert launches[1] == launches[0] - cfg['depth'] // 2, launches
+        assert rel_l2(outs[1], outs[0]) < 1e-2
+    for v in (1, 0):
+        r, a = rel_l2(outs[v], ref), float(np.abs(outs[v] - ref).max())
+        record(f'{name} t={t} skip_z={v}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {launches[v]}')
+        assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, v, r, a)
 
 
 @pytest.mark.parametrize('size,n_valid,act,L', [('s', (9, 1), (0, 1), 100), ('s', (1, 9), (1, 2), 100), ('s64', (1, 1), (0, 0), 100), ('s', (9, 1, 5), None, 100), ('s', (9, 4, 1, 1), (0, 2), 100),
@@ -618,12 +651,12 @@ def test_editing_with_one_reference_clip_shared_by_several_prompts(lib, dev):
         smp.prepare(text, tm, un, um, t_(init).repeat(P, 1, 1), None, 3.5, 0.0, steps, 0.0, gt=gt1.repeat(2, 1, 1), gt_mask=gm1.repeat(2, 1, 1))
 
 
-DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=1, attn_qtile=0)
+DEFAULT_OPTS = dict(attn_xcd=1, row_variant=1, gemm_panel=3, row_affine=1, epi_lds=1, attn_xk2=1, gemm_pp=3, tile_partial=9, zfuse=1, wt=2, fuse_q2=1, q2_pp=1, xkey1=1, geglu_co=0, qkv_co=1, attn_qtile=0, skip_z=1)
 
 
 @pytest.mark.parametrize('opt,values', [('attn_qtile', (64, 32)), ('attn_xcd', (0, 1)), ('row_variant', (0, 1)), ('gemm_panel', (0, 7)), ('row_affine', (0, 1)),
                                         ('epi_lds', (0, 1)), ('attn_xk2', (0, 1)), ('gemm_pp', (0, 3)), ('geglu_co', (0, 2)), ('qkv_co', (0, 2)), ('tile_partial', (9, 62)), ('zfuse', (1, 0)), ('wt', (0, 1)),
-                                        ('fuse_q2', (1, 0)), ('q2_pp', (1, 0)), ('xkey1', (1, 0))])
+                                        ('fuse_q2', (1, 0)), ('q2_pp', (1, 0)), ('xkey1', (1, 0)), ('skip_z', (1, 0))])
 def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
     """attn_xcd only moves workgroups between XCDs (bitwise identical); row_variant changes the summation tree of the
     LayerNorm statistics: fp32 rounding only, but a last-bit change of a statistic flips bf16 roundings of the GEMM operands
@@ -644,7 +677,7 @@ def test_placement_and_row_kernel_variants_agree(lib, dev, opt, values):
             outs.append(_forward(m, inp, 499, kw).cpu().numpy())
         assert lib.ezdit_set_option(m._h, opt.encode(), DEFAULT_OPTS[opt]) == 0
         assert lib.ezdit_set_option(m._h, b'fuse_q2', 1) == 0
-    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1', 'geglu_co', 'qkv_co', 'attn_qtile'):   # placement / issue order / launch structure only: bitwise identical
+    if opt not in ('row_variant', 'gemm_pp', 'tile_partial', 'zfuse', 'fuse_q2', 'q2_pp', 'xkey1', 'geglu_co', 'qkv_co', 'attn_qtile', 'skip_z'):   # placement / issue order / launch structure only: bitwise identical
         for o in outs[1:]:
             np.testing.assert_array_equal(outs[0], o)
     else:   # row_variant: same math, different rounding points; gemm_pp / tile_partial: another kernel (other MFMA shape, other fp32 summation order over K)

@@ -198,7 +198,7 @@ def test_product_scheduler_agrees_with_oracle_restatement():
         DDIMScheduler(**dict(DIFF, prediction_type='epsilon'))
 
 
-OPTION_NAMES = ['zfuse', 'xkey1', 'geglu_co', 'qkv_co', 'wt', 'gemm_pp', 'tile_partial', 'attn_xcd', 'row_variant', 'gemm_panel', 'row_affine', 'epi_lds', 'attn_xk2',
+OPTION_NAMES = ['zfuse', 'xkey1', 'skip_z', 'geglu_co', 'qkv_co', 'wt', 'gemm_pp', 'tile_partial', 'attn_xcd', 'row_variant', 'gemm_panel', 'row_affine', 'epi_lds', 'attn_xk2',
                 'attn_nkh', 'attn_qtile', 'cn_overlap', 'fuse_q2', 'q2_pp', 'stamp_launch', 'trace_launches']
 
 
@@ -485,8 +485,10 @@ def test_k_split_kernel_counts_exactly_its_operand_loads_behind_the_prologue_dma
         m = re.search(r'k_gemm_ksI((?:L[ib]\d+E)+)', name)
         if not m:
             continue
-        fm, fn, epi, gate, res, ck, dual = [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(1))]
-        nopl = (fn // 2) * (1 + ((1 + res + gate) if epi == 4 else 0))
+        fm, fn, epi, gate, res, ck, form = [int(x) for x in re.findall(r'L[ib](\d+)E', m.group(1))]   # form 3 = KS_ZIN: G' rides in the gate's slot, + 4 partial statistics (dwordx2)
+        nopl4 = (fn // 2) * (1 + ((1 + res + (gate or form == 3)) if epi == 4 else 0))
+        nopl2 = 4 if form == 3 else 0
+        nopl = nopl4 + nopl2
         lines = [l.strip() for l in f.splitlines()]
         first_dma = next(i for i, l in enumerate(lines) if l.startswith('global_load_lds'))
         shared = next(i for i, l in enumerate(lines) if l == '; shared slot')
@@ -494,8 +496,9 @@ def test_k_split_kernel_counts_exactly_its_operand_loads_behind_the_prologue_dma
         while not re.match(r'\.LBB\d+_\d+:', lines[blk]):
             blk -= 1
         body = lines[blk:shared]
-        assert sum(l.startswith('global_load_dwordx4 a[') for l in body) == nopl, (name, nopl)
-        assert not any(l.startswith(('global_load_lds', 'buffer_load', 's_waitcnt vmcnt')) or (l.startswith('global_load') and not l.startswith('global_load_dwordx4 a[')) for l in body), name
+        assert sum(l.startswith('global_load_dwordx4 a[') for l in body) == nopl4, (name, nopl4)
+        assert sum(l.startswith('global_load_dwordx2 a[') for l in body) == nopl2, (name, nopl2)
+        assert not any(l.startswith(('global_load_lds', 'buffer_load', 's_waitcnt vmcnt')) or (l.startswith('global_load') and not l.startswith(('global_load_dwordx4 a[', 'global_load_dwordx2 a['))) for l in body), name
         per_row = [i for i, l in enumerate(lines) if l == '; per-row slot']
         for i in range(first_dma, shared):
             if lines[i].startswith('s_waitcnt vmcnt'):
@@ -504,11 +507,12 @@ def test_k_split_kernel_counts_exactly_its_operand_loads_behind_the_prologue_dma
         assert lines[nxt] == 's_waitcnt vmcnt(%d)' % nopl, (name, lines[nxt])
         assert not any(l.startswith('global_load') for l in lines[shared:nxt]), name
         acc = [(int(a), int(b)) for a, b in re.findall(r'v_mfma_f32_16x16x32_bf16 a\[(\d+):(\d+)\]', f)]
-        ops = [(int(a), int(b)) for a, b in re.findall(r'global_load_dwordx4 a\[(\d+):(\d+)\]', f)]
-        assert max(b for _, b in ops) < min(a for a, _ in acc) or min(a for a, _ in ops) > max(b for _, b in acc), name
-        lo, hi = min(a for a, _ in ops), max(b for _, b in ops)
+        ops = [(int(a), int(b)) for a, b in re.findall(r'global_load_dwordx[24] a\[(\d+):(\d+)\]', f)]
+        acc_regs = {r for a, b in acc for r in range(a, b + 1)}
+        op_regs = {r for a, b in ops for r in range(a, b + 1)}
+        assert not (acc_regs & op_regs), name
         last_mfma = max(i for i, l in enumerate(lines) if l.startswith('v_mfma'))
-        first_read = next(i for i, l in enumerate(lines) if (mm := re.match(r'v_accvgpr_read_b32 v\d+, a(\d+)', l)) and lo <= int(mm.group(1)) <= hi)
+        first_read = next(i for i, l in enumerate(lines) if (mm := re.match(r'v_accvgpr_read_b32 v\d+, a(\d+)', l)) and int(mm.group(1)) in op_regs)
         assert first_read > last_mfma and any(l == 's_waitcnt vmcnt(0)' for l in lines[last_mfma:first_read]), name
         assert 'scratch_' not in f, name
         checked += 1

@@ -391,5 +391,13 @@ def test_public_api_controlnet_text_plus_energy_to_audio(tmp_path, monkeypatch):
     plain = A.EzAudio.__new__(A.EzAudio)
     plain.__dict__.update(autoencoder=ez.autoencoder, unet=ez.unet, tokenizer=ez.tokenizer, text_encoder=ez.text_encoder,
                           noise_scheduler=ez.noise_scheduler, params=ez.params, device=ez.device)
-    sr, base_audio = plain.generate_audio('a dog barking', length=10, guidance_scale=3.5, guidance_rescale=0, ddim_steps=20, random_seed=3)
+    # (ControlNet residuals change the skips, so the backbone takes the row-kernel path for LN([x | skip]) whatever their scale; the plain sampler's default is the
+    # LayerNorm-algebra form of that edge, option skip_z -- the same math with other bf16 rounding points.  Same path: equal to fp32 rounding; default path: inside the loop gate)
+    sr, default_audio = plain.generate_audio('a dog barking', length=10, guidance_scale=3.5, guidance_rescale=0, ddim_steps=20, random_seed=3)
+    assert ez.unet.lib.ezdit_set_option(ez.unet._h, b'skip_z', 0) == 0
+    try:
+        sr, base_audio = plain.generate_audio('a dog barking', length=10, guidance_scale=3.5, guidance_rescale=0, ddim_steps=20, random_seed=3)
+    finally:
+        assert ez.unet.lib.ezdit_set_option(ez.unet._h, b'skip_z', 1) == 0
     assert rel_l2(off, base_audio) < 1e-5
+    assert rel_l2(off, default_audio) < 5e-2

@@ -72,7 +72,7 @@ def measure(combo):
 
 # defaults of the options this script may touch (csrc/api.hip)
 DEFAULTS = dict(zfuse=1, gemm_pp=3, tile_partial=9, wt=2, fuse_q2=1, attn_xk2=1, gemm_panel=3, row_affine=1, attn_nkh=0, q2_pp=1, attn_xcd=1, row_variant=1,
-                epi_lds=1, cn_overlap=1, zfake=0, xkey1=1, geglu_co=0, qkv_co=1, attn_qtile=0)
+                epi_lds=1, cn_overlap=1, zfake=0, xkey1=1, geglu_co=0, qkv_co=1, attn_qtile=0, skip_z=1)
 for r in range(rounds):
     for combo in combos:
         try:
