@@ -123,10 +123,10 @@ struct ezdit_handle {
     // ... and the out-blocks' LN_2D([x | skip]) -> skip_linear (blocks.py:124-128) the same way (round 6, k_gemm_ks forms COPY2 / ZIN, gemm_ks.h): the statistics of the concatenation
     // are the sums of the halves'; the in-block that produces `skip` keeps them and writes bf16(skip g[D:]) into the right half of ITS out-block's operand (one operand buffer per
     // out-block), the MLP-out projection in front of the out-block runs un-split and writes bf16(x g[:D]) + statistics, skip_linear finishes the LayerNorm in its epilogue:
-    // 14 split-K GEMMs + 14 row-kernel launches of an XL step become 14 un-split launches (225 launches instead of 239).  k_gemm_ks shapes only (M <= kZBigM rows);
+    // 14 split-K GEMMs + 14 row-kernel launches of an XL step become 14 un-split launches (225 launches instead of 239).  The ping-pong producer (M > kZBigM rows) has the same forms.
     // ControlNet residuals change the skips (skip + scale * residual) and take the row-kernel path.
     int opt_skip_z = 1;
-    bool skip_z_usable() const { return opt_skip_z && !is_cn && nhalf > 0 && ztile() == kZTile && (D + zwidth() - 1) / zwidth() <= 16; }
+    bool skip_z_usable() const { return opt_skip_z && !is_cn && nhalf > 0 && (D + zwidth() - 1) / zwidth() <= (ztile() == kZTile ? 16 : 8); }   // (statistics parts a lane group of the consumer covers)
     // GEGLU GEMM on the co-resident kernel (k_gemm_co, gemm_co.h: 4-wave workgroups with a 128 x 144 tile, TWO per CU, so that a workgroup's prologue and
     // epilogue run under its neighbour's K loop): 0 = never, 1 = above kCoM rows (batched prompts: the ping-pong kernel runs 4 rounds of workgroups there), 2 = always
     int opt_geglu_co = 0;
@@ -388,7 +388,7 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("u", Mp * h->ldD * 2);
     // LN_2D([x | skip]) of the out-blocks: its own buffer, because the skip GEMM that reads it writes `u` from inside the same launch (fused row operator).
     // One per out-block where the LayerNorm algebra covers skip_linear (opt_skip_z): the in-block fills the right half long before the out-block runs
-    add("ucat", (size_t)((M <= ezdit_handle::kZBigM && !h->is_cn && h->nhalf > 0) ? h->nhalf : 1) * Mp * h->ld2D * 2);
+    add("ucat", (size_t)((!h->is_cn && h->nhalf > 0) ? h->nhalf : 1) * Mp * h->ld2D * 2);
     add("qkv", Mp * 3 * D * 4);
     add("q", (size_t)B * H * Lp * h->DQK * 2);
     add("k", (size_t)B * H * Lp * h->DQK * 2);

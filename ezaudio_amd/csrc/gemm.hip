@@ -582,10 +582,18 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
         return launch_ks_tile<EPI_F32, false, false>(a, st);
     }
     if (a.epi == EPI_RESID && a.tile == 61) {   // batched prompts: un-split residual projection on the ping-pong kernel, 128 x 144 tiles (k-split schedule, ring 4)
-        if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.out || !a.bias || a.splitk != 1 || (a.gate && !a.resid) || a.row_slot) return 1;
+        if (!a.zu || !a.zg || !a.zstat_out || a.zs_stride <= 0 || !a.bias || a.splitk != 1 || (a.gate && !a.resid) || a.row_slot) return 1;   // (null out: the fp32 stream is not stored)
         if (a.zd) {   // DUAL form (GemmArgs.zd)
             if (!a.gate || !a.zg2 || a.rows_per_b <= 0) return 1;
             return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 64 + 128 + 256>(a, st);
+        }
+        if (a.zu2) {   // COPY2 form: the in-blocks' MLP-out
+            if (!a.gate || !a.zg2 || a.ld_zu2 <= 0) return 1;
+            return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 64 + 128 + 512>(a, st);
+        }
+        if (a.zstat_in2) {   // ZIN form: skip_linear
+            if (a.gate || a.resid || !a.zstat_in || !a.zG || a.zparts <= 0 || a.zparts > 8 || a.zD <= 0) return 1;
+            return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 1024>(a, st);
         }
         if (a.gate) return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 64 + 128>(a, st);
         if (a.resid) return launch_pp<128, 144, 4, 1, 4, EPI_RESID, 2, 128>(a, st);

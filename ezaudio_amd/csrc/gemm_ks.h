@@ -341,6 +341,13 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     }
     __syncthreads();
     if (ts && lane == 0) ts[4] = __builtin_readcyclecounter();
+    if constexpr (X == KS_COPY2) {
+        // COPY2 waits for its vector HERE, right behind the barrier it landed under -- not behind the partial sums like DUAL: with 12 more live registers through the sums hipcc
+        // parked one of the (to its knowledge defined) destination registers in an AGPR in front of the wait, i.e. copied data that had not arrived: results differed from run to
+        // run (tools/diag_determinism.py; tests/test_host.py reads the generated code for exactly this)
+#pragma unroll
+        for (int q = 0; q < SL; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dv[q]));
+    }
     if (!epi_thread) return;
 
     // ---- sum the eight partials in wave order (fixed: bit-reproducible) and finish the row segment
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
         t_sum = __builtin_readcyclecounter();
     }
     float* out = reinterpret_cast<float*>(a.out);
-    if constexpr (DUAL || X == KS_COPY2) {   // the asm loads of dv have landed; ties the registers to the wait
+    if constexpr (DUAL) {   // the asm loads of dv have landed; ties the registers to the wait
 #pragma unroll
         for (int q = 0; q < SL; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(dv[q]));
     }

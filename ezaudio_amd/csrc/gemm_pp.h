@@ -345,9 +345,13 @@ __device__ __forceinline__ void pp_store_lds(const GemmArgs& a, f32x4 (&acc)[FM]
 // LayerNorm gain) were parked in LDS behind the ring (`vec`: [3][BN]); the residual rows `r4` were requested right after the K loop.
 // DUAL (GemmArgs.zd, see k_gemm_ks): the rows outside [act_row0, act_row1) also get the constant cross-attention-out vector of their batch element
 // (`d4`, requested with the residual rows) and the gain of the GEGLU GEMM's LayerNorm (`vec` row 3) instead of the q projection's.
-template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, bool GATE, bool RES, bool DUAL>
+// COPY2 / ZIN (round 6; the forms of k_gemm_ks, gemm_ks.h): COPY2 -- a second operand bf16(h_new * zg2) -> zu2 (`vec` row 3 holds zg2): the in-blocks' MLP-out writes the skip half of the
+// out-block's [x | skip] operand; ZIN -- the launch is skip_linear and finishes LN_2D([x | skip]) first: acc := r (acc - mu G') + C' with G' in `vec` row 1 (the gate's), C' in row 0
+// (the bias's) and (mu, r) from `zst`: parts cg and cg + 4 of the two statistics sets for each of this lane's rows, requested with the residual rows
+template <int BM, int BN, int FM, int FN, int TM, int TN, int NT, bool GATE, bool RES, bool DUAL, bool COPY2 = false, bool ZIN = false>
 __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[FM][FN], char* smem, int row0, int col0, int wm, int lane, int tid,
-                                               const float* vec, const float4 (&r4)[FM][FN], const float4 (&d4)[FM][FN]) {
+                                               const float* vec, const float4 (&r4)[FM][FN], const float4 (&d4)[FM][FN], const float2 (&zst)[FM][4]) {
+    static_assert(!ZIN || (!GATE && !RES && !DUAL), "ZIN: the gate's row of `vec` carries G'");
     static_assert(TN == BN, "one wave holds whole tile rows");
     constexpr int PITCH = BN + 8;
     static_assert(BN % 8 == 0, "16-byte row chunks");
@@ -355,11 +359,23 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
     const int m_in = lane & 15, cg = lane >> 4;
     const int tn = col0 / BN;
     float* out = reinterpret_cast<float*>(a.out);
-    uint2 pk[FM][FN];
+    uint2 pk[FM][FN], pk2[COPY2 ? FM : 1][COPY2 ? FN : 1];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int row = row0 + wm * TM + i * 16 + m_in;
         const bool alt = DUAL && (row < a.act_row0 || row >= a.act_row1);
+        float zr = 1.f, zrm = 0.f;
+        if constexpr (ZIN) {   // the row's statistics over the zD columns of both sets: the 4 lanes (cg) of a row sit 16 lanes apart; fixed order, bit-reproducible
+            const bool two = cg + 4 < a.zparts;
+            float zs = (zst[i][0].x + (two ? zst[i][1].x : 0.f)) + (zst[i][2].x + (two ? zst[i][3].x : 0.f));
+            float zq = (zst[i][0].y + (two ? zst[i][1].y : 0.f)) + (zst[i][2].y + (two ? zst[i][3].y : 0.f));
+            zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
+            zq += __shfl_xor(zq, 16, 64); zq += __shfl_xor(zq, 32, 64);
+            const float inv_d = __builtin_amdgcn_rcpf((float)a.zD);
+            const float mu = zs * inv_d;
+            zr = rsqrtf(fmaxf(fmaf(zq, inv_d, -mu * mu), 0.f) + a.zeps);
+            zrm = zr * mu;
+        }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -368,6 +384,11 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
             const float4 b4 = *reinterpret_cast<const float4*>(vec + cl);
             // h_new = resid + gate * (acc + bias): the same two roundings per element as the row kernel (rowbody.h)
             float4 x = make_float4(acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w);
+            if constexpr (ZIN) {   // r (acc - mu G') + C'
+                const float4 g4 = *reinterpret_cast<const float4*>(vec + BN + cl);
+                x = make_float4(fmaf(zr, acc[i][j][0], fmaf(-zrm, g4.x, b4.x)), fmaf(zr, acc[i][j][1], fmaf(-zrm, g4.y, b4.y)),
+                                fmaf(zr, acc[i][j][2], fmaf(-zrm, g4.z, b4.z)), fmaf(zr, acc[i][j][3], fmaf(-zrm, g4.w, b4.w)));
+            }
             if constexpr (GATE) {
                 const float4 g4 = *reinterpret_cast<const float4*>(vec + BN + cl);
                 x.x *= g4.x; x.y *= g4.y; x.z *= g4.z; x.w *= g4.w;
@@ -377,13 +398,18 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
             if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
             s1 += (x.x + x.y) + (x.z + x.w);
             s2 = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, s2))));
-            if (ok && row < a.M) {
+            if (ok && row < a.M && out) {   // (null out: nothing reads the fp32 stream behind this launch -- the MLP-out in front of an out-block)
                 float* dst = out + (long)row * a.ldo + col;
                 if (a.wt) st16_wt(dst, x); else *reinterpret_cast<float4*>(dst) = x;
             }
             const float4 z4 = *reinterpret_cast<const float4*>(vec + (alt ? 3 : 2) * BN + cl);
             pk[i][j].x = pack_bf2(x.x * z4.x, x.y * z4.y);
             pk[i][j].y = pack_bf2(x.z * z4.z, x.w * z4.w);
+            if constexpr (COPY2) {
+                const float4 y4 = *reinterpret_cast<const float4*>(vec + 3 * BN + cl);
+                pk2[i][j].x = pack_bf2(x.x * y4.x, x.y * y4.y);
+                pk2[i][j].y = pack_bf2(x.z * y4.z, x.w * y4.w);
+            }
         }
         // the 4 lanes (cg) of a row sit 16 lanes apart
         s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
@@ -398,6 +424,16 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
             *reinterpret_cast<uint2*>(tile + (wm * TM + i * 16 + m_in) * PITCH + j * 16 + 4 * cg) = pk[i][j];
     __syncthreads();
     copy_out_bf16<NT>(tile, PITCH, BM, BN, a.zu, a.ld_zu, row0, col0, a.M, a.N, a.wt, tid);
+    if constexpr (COPY2) {   // the second operand through the same staging tile
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<uint2*>(tile + (wm * TM + i * 16 + m_in) * PITCH + j * 16 + 4 * cg) = pk2[i][j];
+        __syncthreads();
+        copy_out_bf16<NT>(tile, PITCH, BM, BN, a.zu2, a.ld_zu2, row0, col0, a.M, a.N, a.wt, tid);
+    }
 }
 
 // q / k epilogue through an fp32 park (what k_headnorm does on the fp32 projection; attention.py:137-142, rotary.py:6-18): the tile holds NH = BN / head_dim
@@ -900,7 +936,7 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     const bool z_shared_slot = a.row_slot == nullptr;
     // threads that fetch one float4 of the epilogue's per-column vectors (LDS-DMA in z_late_load), and whether THIS wave is one of theirs: its counted wait in front of the
     // K loop then leaves that one DMA in flight (nt >= 2: the wait for K tile 1, which is younger, covers it)
-    constexpr int ZNV = EPI == EPI_RESID ? ((VAR & 256) ? 4 : 3) * (BN / 4) : 2 * (BN / 4);
+    constexpr int ZNV = EPI == EPI_RESID ? ((VAR & (256 | 512)) ? 4 : 3) * (BN / 4) : 2 * (BN / 4);
     // zx = LDS-DMA instructions THIS wave issues in z_late_load on top of the NZT statistics loads every wave issues there (0 .. 2, wave-uniform): the per-column vectors'
     // (the first waves only) and, fused QKV, the RoPE-table warm-up (every wave of a q / k tile).  The counted wait in front of the K loop leaves all of them in flight;
     // they are older than every K tile but the first, so the wait for K tile 1 (nt >= 2) covers them
@@ -910,7 +946,9 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
     // the top of the kernel).  Requested right AFTER the prologue's LDS-DMA went out, so that the counter's round trip does not sit in front
     // of the first tile (it did: +1 us per consumer launch)
     constexpr bool RGATE = EPI == EPI_RESID && (VAR & 64) != 0, RRES = EPI == EPI_RESID && (VAR & 128) != 0, RDUAL = EPI == EPI_RESID && (VAR & 256) != 0;
+    constexpr bool RCOPY2 = EPI == EPI_RESID && (VAR & 512) != 0, RZIN = EPI == EPI_RESID && (VAR & 1024) != 0;   // pp_store_resid: second operand / LayerNorm-finishing skip_linear
     static_assert(!RDUAL || (RGATE && RRES), "DUAL: the gated residual projection only");
+    static_assert(!(RDUAL && RCOPY2) && !(RZIN && (RGATE || RRES || RDUAL || RCOPY2)), "forms of the residual epilogue");
     auto z_late_load = [&]() {
         if constexpr (EPI == EPI_QKV) {
             // q / k tiles: the RoPE rows of the tile's 128 tokens (2 x 18 KB of the cos / sin tables) are read in the epilogue, by every workgroup
@@ -934,8 +972,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
                 const int which = tid / (BN / 4), t4 = tid - which * (BN / 4);
                 int cp = col0 + 4 * t4;
                 cp = cp < a.N - 4 ? cp : a.N - 4;
-                const float* src = which == 0 ? rb_ : which == 1 ? (RGATE ? rg_ + (long)slot0 * a.gate_slot_stride : rb_) : which == 2 ? rz_ + (long)slot0 * a.zg_slot_stride
-                                   : (RDUAL ? rz2_ + (long)slot0 * a.zg2_slot_stride : rb_);
+                const float* src = which == 0 ? rb_ : which == 1 ? (RGATE ? rg_ + (long)slot0 * a.gate_slot_stride : RZIN ? zG_ : rb_) : which == 2 ? rz_ + (long)slot0 * a.zg_slot_stride
+                                   : ((RDUAL || RCOPY2) ? rz2_ + (long)slot0 * a.zg2_slot_stride : rb_);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + cp),
                                                  (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(zgc) + wave * 1024), 16, 0, 0);
             }
@@ -1237,6 +1275,20 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         // EPI_RESID: the residual rows this wave finishes after the exchange (16 rows x the tile's columns)
         constexpr int RF = EPI == EPI_RESID ? FM / 2 : 1, RN = EPI == EPI_RESID ? FN : 1;
         float4 rres[RF][RN], dres[RDUAL ? RF : 1][RDUAL ? RN : 1];
+        float2 zst[RF][4];
+        if constexpr (RZIN) {   // partial statistics of the rows this wave finishes: parts cg, cg + 4 of both sets (zparts <= 8; clamped, weight 0 beyond: pp_store_resid)
+            const int m_in = lane & 15, cg = lane >> 4;
+            const int p1 = cg + 4 < a.zparts ? cg + 4 : a.zparts - 1;
+#pragma unroll
+            for (int i = 0; i < RF; ++i) {
+                int row = row0 + (wm * 2 + grp) * (TM / 2) + i * 16 + m_in;
+                row = row < a.M ? row : a.M - 1;
+                zst[i][0] = a.zstat_in[(long)cg * a.zs_stride + row];
+                zst[i][1] = a.zstat_in[(long)p1 * a.zs_stride + row];
+                zst[i][2] = a.zstat_in2[(long)cg * a.zs_stride + row];
+                zst[i][3] = a.zstat_in2[(long)p1 * a.zs_stride + row];
+            }
+        }
         if constexpr (RRES) {
             const int m_in = lane & 15, cg = lane >> 4;
 #pragma unroll
@@ -1280,8 +1332,8 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         if constexpr (EPI == EPI_RESID) {
             static_assert(WN == 1, "EPI_RESID: a wave holds whole tile rows after the exchange");
             static_assert(BM * (BN + 8) * 2 <= NS * STAGE, "A' tile must fit the ring");
-            if constexpr (RDUAL) pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES, true>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres, dres);
-            else pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES, false>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres, rres);
+            if constexpr (RDUAL) pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES, true>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres, dres, zst);
+            else pp_store_resid<BM, BN, HF, FN, TM / 2, TN, NT, RGATE, RRES, false, RCOPY2, RZIN>(a, half, smem, row0, col0, ewm, lane, tid, zgc, rres, rres, zst);
         }
         if constexpr (EPI == EPI_QKV) {
             static_assert(BN == 144 || BN == 128, "EPI_QKV tiles hold two whole heads (head_dim 72 / 64)");
