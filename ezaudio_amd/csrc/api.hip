@@ -56,7 +56,7 @@ struct WsPtrs {  // workspace regions used on the per-step path, resolved once a
     uint8_t* kmask; bf16_t *kc, *vc; float *mod, *modf;
     float *cembed, *cnres; bf16_t* skipbf;   // ControlNet only
     float2* zstat; float *zt_qkv, *zt_geglu, *zt_q2;   // LayerNorm algebra: partial row statistics, G' / C' tables
-    float2* zstat_skip; float* zt_skip;                // ... of the out-blocks' LN_2D([x | skip]) -> skip_linear: the skips' statistics (kept from the in-block to its out-block), static tables
+    float2* zstat_skip; float* zt_skip; bf16_t* ucat_z;              // ... of the out-blocks' LN_2D([x | skip]) -> skip_linear: the skips' statistics (kept from the in-block to its out-block), static tables
     float* zd;   // [nblk][B][D] constant cross-attention-out vectors of the single-key batch elements (opt_xkey1)
 };
 
@@ -386,9 +386,8 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
     add("h", Mp * D * 4);
     add("skips", (size_t)h->nhalf * Mp * D * 4);
     add("u", Mp * h->ldD * 2);
-    // LN_2D([x | skip]) of the out-blocks: its own buffer, because the skip GEMM that reads it writes `u` from inside the same launch (fused row operator).
-    // One per out-block where the LayerNorm algebra covers skip_linear (opt_skip_z): the in-block fills the right half long before the out-block runs
-    add("ucat", (size_t)((!h->is_cn && h->nhalf > 0) ? h->nhalf : 1) * Mp * h->ld2D * 2);
+    add("ucat", Mp * h->ld2D * 2);                        // LN_2D([x | skip]) of the out-blocks: its own buffer, because the skip GEMM that reads it
+                                                          // writes `u` from inside the same launch (fused row operator)
     add("qkv", Mp * 3 * D * 4);
     add("q", (size_t)B * H * Lp * h->DQK * 2);
     add("k", (size_t)B * H * Lp * h->DQK * 2);
@@ -426,8 +425,6 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         add("zt_qkv", (size_t)ns * nblk * 2 * N3 * 4);
         add("zt_geglu", (size_t)ns * nblk * 2 * I2 * 4);
         add("zt_q2", (size_t)nblk * 2 * D * 4);
-        add("zstat_skip", (size_t)(h->nhalf > 0 ? h->nhalf : 1) * Z_MAXP * Mp * 8);
-        add("zt_skip", (size_t)(h->nhalf > 0 ? h->nhalf : 1) * 2 * D * 4);
         add("zd", (size_t)nblk * B * D * 4);
         add("zA", (size_t)rup(4 * ns, 128) * h->ldD * 2);
         add("ztmp", (size_t)rup(4 * ns, 128) * nmax * 4);
@@ -435,6 +432,11 @@ size_t carve(const ezdit_handle* h, int B, int L, int Lc, int n_slots, std::map<
         add("zneutral", (size_t)Z_MAXP * Mp * 8);
         add("zzeros", (size_t)nmax * 4);
 #endif
+        // skip path by the LayerNorm algebra (opt_skip_z), BEHIND everything else: the buffers above keep the offsets -- the relative placement in the HBM channels -- the
+        // round's measurements were made with.  One [x | skip] operand per out-block (the in-block fills the right half long before the out-block runs), the skips' statistics, static tables
+        add("ucat_z", (size_t)((!h->is_cn && h->nhalf > 0) ? h->nhalf : 1) * Mp * h->ld2D * 2);
+        add("zstat_skip", (size_t)(h->nhalf > 0 ? h->nhalf : 1) * Z_MAXP * Mp * 8);
+        add("zt_skip", (size_t)(h->nhalf > 0 ? h->nhalf : 1) * 2 * D * 4);
     }
     return off;
 }
@@ -580,7 +582,7 @@ void resolve_workspace(ezdit_handle* h) {
     p.mod = h->buf<float>("mod"); p.modf = h->buf<float>("modf");
     p.zd = h->buf<float>("zd");
     p.zstat = h->buf<float2>("zstat"); p.zt_qkv = h->buf<float>("zt_qkv"); p.zt_geglu = h->buf<float>("zt_geglu"); p.zt_q2 = h->buf<float>("zt_q2");
-    p.zstat_skip = h->buf<float2>("zstat_skip"); p.zt_skip = h->buf<float>("zt_skip");
+    p.zstat_skip = h->buf<float2>("zstat_skip"); p.zt_skip = h->buf<float>("zt_skip"); p.ucat_z = h->buf<bf16_t>("ucat_z");
     if (h->is_cn) { p.cembed = h->buf<float>("cembed"); p.cnres = h->buf<float>("cnres"); p.skipbf = h->buf<bf16_t>("skipbf"); }
 }
 
@@ -948,9 +950,6 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     STOPCHK();
     launch_assemble(as, st);
     c.launched("k_assemble");
-    STOPCHK();
-    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, M <= 2048 ? ezdit_handle::kTilePE : tile_for(h, M, false));
-
     const float* part_src = part;
     bool u_is_z = false;   // `u` holds A' = bf16(h g) + partial statistics (LayerNorm algebra) instead of a finished LayerNorm
     bool* u_is_z_ptr = &u_is_z;
@@ -1037,7 +1036,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
     // LN_2D([x | skip]) -> skip_linear by the LayerNorm algebra (opt_skip_z): not with ControlNet residuals (they change the skips)
     const bool skipz = zf && h->skip_z_usable() && !(cn && n_cn > 0);
     const int zsp = (D + h->zwidth() - 1) / h->zwidth();                      // statistics parts of a D-wide producer
-    auto ucat_of = [&](int j) { return p.ucat + (size_t)j * Mp * h->ld2D; };     // operand [x | skip] of out-block j
+    auto ucat_of = [&](int j) { return p.ucat_z + (size_t)j * Mp * h->ld2D; };   // operand [x | skip] of out-block j
     auto zskip_of = [&](int i) { return p.zstat_skip + (size_t)i * Z_MAXP * Mp; };   // statistics of skip i
     // single-key shortcut (opt_xkey1): cross-attention + its out-projection cover the batch elements [xb0, xb0 + xnb) only
     const bool x1 = zf && h->opt_xkey1 && h->xkey1;
@@ -1045,12 +1044,19 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
 
     // LN1 of block 0 on the patch embedding (ControlNet: x = patch_embed(x) + controlnet_pre(condition) first, :263-266)
     STOPCHK();
+    if (zf && !cn_mode) {
+        // LayerNorm algebra: the patch embed itself is the producer for block 0's norm1 (no gate, no residual: h = acc + bias, statistics, bf16(h g)) -- no row-kernel launch
+        resid_z(p.ape, h->ldPE, h->w_pe, nullptr, hA, h->b_pe, nullptr, 0, modv(0, 0), mod_slot, "k_gemm (un-split residual: patch embed)");
+    } else {
+    gemm(c, p.ape, h->ldPE, h->w_pe, h->b_pe, hA, D, M, D, EPI_F32, M <= 2048 ? ezdit_handle::kTilePE : tile_for(h, M, false));
+    STOPCHK();
     if (cn_mode) {
         part_src = p.cembed;
         row(1, hA, hA, 1, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
         part_src = part;
     } else {
         row(0, hA, nullptr, 0, nullptr, nullptr, 0, modv(0, 0), modv(0, 1), mod_slot, nullptr, nullptr, h->ldD);
+    }
     }
     const float* hcur = hA;
 

@@ -246,13 +246,6 @@ struct GemmArgs {
     // batch elements -- the rows OUTSIDE [act_row0, act_row1) -- the attention-out projection adds that vector (zd [B][zd_stride], per batch element)
     // on top of its own gated residual and emits the operand of the GEGLU GEMM (gain zg2) instead of the cross-attention q projection's
     const float* zd; long zd_stride; const float* zg2; long zg2_slot_stride; int act_row0, act_row1;
-    // producer, COPY2 form (k_gemm_ks; null zu2 = off): a second operand  bf16(h_new * zg2) -> zu2 [M][ld_zu2]  (zg2 static: no slot) -- the in-blocks' MLP-out
-    // projection writes the `skip` half of the matching out-block's [x | skip] operand while it has the values in registers
-    bf16_t* zu2; int ld_zu2;
-    // consumer + producer, ZIN form (k_gemm_ks, EPI_RESID without gate and residual; null zstat_in2 = off): the operand is A' = bf16([x | skip] * g) with partial statistics
-    // in TWO sets of zparts parts (zstat_in: the x half, zstat_in2: the skip half; the row's statistics over zD = 2 D columns are their sums);
-    // acc := r (acc - mu G'[col]) + C'[col] with G' = zG and C' = `bias` (static tables), then the producer's epilogue as usual
-    const float2* zstat_in2;
     // consumer (EPI_QKV, EPI_GEGLU; null zstat_in = plain GEMM):
     const float2* zstat_in; int zparts; int zD; int zw; // [zparts][zs_stride] partial statistics of the operand's rows: zparts = ceil(zD / zw) <= Z_MAXP parts of zw columns (the last one ragged; zw = the producer's tile width)
     const float* zG; const float* zC; long zt_slot_stride;   // G', C' [slots][N]
@@ -260,6 +253,15 @@ struct GemmArgs {
     unsigned long long* ts;   // test hook (k_gemm_pp, k_gemm_ks): [workgroup][8] shader-clock stamps (kernel start, loop start, loop end, kernel end, 4 epilogue marks), nullable
     long ts_cap;              // workgroups `ts` has room for: the launcher drops `ts` for a larger grid
     int epi_lds;   // k_gemm bf16 epilogues (GEGLU output, bf16 slabs): park the tile in the dead ring and write whole rows, 16 bytes per lane
+    // ---- round 6, the skip path's forms of the producers (k_gemm_ks, k_gemm_pp EPI_RESID).  At the END of the struct: the offsets of everything above -- and with them how hipcc groups
+    // the kernel-argument loads of every GEMM prologue -- stay what they were (in the middle of the struct the same three fields cost the whole step 0.5 %, r06ah)
+    // producer, COPY2 form (null zu2 = off): a second operand  bf16(h_new * zg2) -> zu2 [M][ld_zu2]  (zg2 static: no slot) -- the in-blocks' MLP-out
+    // projection writes the `skip` half of the matching out-block's [x | skip] operand while it has the values in registers
+    bf16_t* zu2; int ld_zu2;
+    // consumer + producer, ZIN form (EPI_RESID without gate and residual; null zstat_in2 = off): the operand is A' = bf16([x | skip] * g) with partial statistics
+    // in TWO sets of zparts parts (zstat_in: the x half, zstat_in2: the skip half; the row's statistics over zD = 2 D columns are their sums);
+    // acc := r (acc - mu G'[col]) + C'[col] with G' = zG and C' = `bias` (static tables), then the producer's epilogue as usual
+    const float2* zstat_in2;
 };
 int launch_gemm(const GemmArgs& a, hipStream_t st);   // 0 = launched, nonzero = configuration not supported (nothing launched)
 

@@ -319,8 +319,8 @@ def test_layernorm_algebra_and_split_k_paths_match_reference_golden(lib, dev, na
         assert lib.ezdit_set_option(m._h, b'zfuse', 1) == 0
     nblk = cfg['depth'] + 1
     # attention-out and cross-out of every block, MLP-out in front of in / mid blocks, skip_linear of the out-blocks; + the MLP-out in front of every out-block
-    # (option skip_z: LN_2D([x | skip]) -> skip_linear by the algebra as well)
-    assert n_z == n_base - (2 * nblk + cfg['depth'] + cfg['depth'] // 2)
+    # (option skip_z: LN_2D([x | skip]) -> skip_linear by the algebra as well); + block 0's norm1 (the patch embed is its producer)
+    assert n_z == n_base - (2 * nblk + cfg['depth'] + cfg['depth'] // 2 + 1)
     for what, p in (('zfuse', pred), ('split-K', base)):
         r, a = rel_l2(p, ref), float(np.abs(p - ref).max())
         record(f'{name} t={t} {what}: rel-L2 {r:.3e} max-abs {a:.3e}; launches {n_base} -> {n_z}')

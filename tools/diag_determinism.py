@@ -59,7 +59,7 @@ if len(seen) == 1:
     sys.exit(0)
 
 HIP = C.CDLL('libamdhip64.so')
-NAMES = ['h', 'u', 'ucat', 'skips', 'zstat', 'zstat_skip', 'ao', 'act', 'q', 'k', 'v']
+NAMES = ["h", "u", "ucat", "ucat_z", 'skips', 'zstat', 'zstat_skip', 'ao', 'act', 'q', 'k', 'v']
 
 
 def state_after(n):
