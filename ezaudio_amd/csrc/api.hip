@@ -1513,6 +1513,29 @@ int ezdit_test_resid(int tile, const void* A, int lda, const void* W, int ldw, c
     return EZDIT_OK;
 }
 
+// the skip path's forms of the same launch (GemmArgs COPY2 / ZIN), stand-alone:
+//   zu2 != NULL (COPY2; gate and h_in required): additionally zu2 = bf16(h_out * zg2)
+//   zstat_in2 != NULL (ZIN; no gate, no h_in): the operand A is bf16(x * g) of rows whose (sum, sum of squares) over zD columns come in two part-major sets of zparts parts
+//   (zstat_in, zstat_in2: [zparts][M] float pairs); acc := r (acc - mu zG[col]) + bias[col] (bias = C'), then the epilogue as above.  h_out NULL = the fp32 stream is not stored
+int ezdit_test_resid_skip(int tile, const void* A, int lda, const void* W, int ldw, const float* bias, const float* h_in, const float* gate, const float* zg,
+                          float* h_out, void* zu, int ld_zu, void* zstat, int M, int N, int K,
+                          const float* zg2, void* zu2, int ld_zu2, const void* zstat_in, const void* zstat_in2, int zparts, int zD, const float* zG, ezdit_stream stream) {
+    if (K % 64) return fail(EZDIT_E_INVALID, "K=%d must be a multiple of 64", K);
+    GemmArgs g;
+    memset(&g, 0, sizeof g);
+    g.A = (const bf16_t*)A; g.lda = lda; g.W = (const bf16_t*)W; g.ldw = ldw; g.wrows = (int)rup(N, 128); g.bias = bias;
+    g.out = h_out; g.ldo = N; g.M = M; g.N = N; g.K = K; g.splitk = 1; g.epi = EPI_RESID; g.tile = tile; g.xcd_map = 1;
+    g.resid = h_in; g.ldr = N; g.gate = gate; g.rows_per_b = 1;
+    g.zu = (bf16_t*)zu; g.ld_zu = ld_zu; g.zg = zg; g.zstat_out = (float2*)zstat; g.zs_stride = M;
+    g.zu2 = (bf16_t*)zu2; g.ld_zu2 = ld_zu2; g.zg2 = zg2;
+    g.zstat_in = (const float2*)zstat_in; g.zstat_in2 = (const float2*)zstat_in2; g.zparts = zparts; g.zD = zD; g.zG = zG; g.zeps = 1e-5f;
+    (void)hipGetLastError();
+    if (launch_gemm(g, (hipStream_t)stream)) return fail(EZDIT_E_UNSUPPORTED, "residual GEMM configuration not supported");
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(EZDIT_E_HIP, "launch of the residual GEMM failed: %s", hipGetErrorString(e));
+    return EZDIT_OK;
+}
+
 int ezdit_test_attention(ezdit_handle* h, const void* q, const void* k, const void* v, const uint8_t* kmask, void* out, int B,
                          int Lq, int Lk, int Lqp, int Lkp, ezdit_stream stream) {
     if (!h) return fail(EZDIT_E_INVALID, "null handle");

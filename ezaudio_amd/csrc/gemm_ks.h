@@ -245,10 +245,11 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
                 }
             }
             if constexpr (X == KS_ZIN) {   // the 8 lanes of a row share its 2 x zparts partial statistics: lane j takes parts j and j + 8 of both sets (weight 0 beyond zparts: ks_zin_mu_r)
+                const int p0 = ej < a.zparts ? ej : a.zparts - 1;
                 const int p1 = ej + 8 < a.zparts ? ej + 8 : a.zparts - 1;
-                op.st[0] = ks_ld8_agpr(a.zstat_in + (long)ej * a.zs_stride + erow);
+                op.st[0] = ks_ld8_agpr(a.zstat_in + (long)p0 * a.zs_stride + erow);
                 op.st[1] = ks_ld8_agpr(a.zstat_in + (long)p1 * a.zs_stride + erow);
-                op.st[2] = ks_ld8_agpr(a.zstat_in2 + (long)ej * a.zs_stride + erow);
+                op.st[2] = ks_ld8_agpr(a.zstat_in2 + (long)p0 * a.zs_stride + erow);
                 op.st[3] = ks_ld8_agpr(a.zstat_in2 + (long)p1 * a.zs_stride + erow);
             }
         };
@@ -387,9 +388,9 @@ __global__ __launch_bounds__(512) void k_gemm_ks(GemmArgs a) {
     } else {
         float zmu = 0.f, zr = 1.f;
         if constexpr (X == KS_ZIN) {   // (mu, r) of the row over the zD columns of BOTH statistics sets: fixed order, bit-reproducible
-            const bool two = ej + 8 < a.zparts;
-            float zs = (op.st[0][0] + (two ? op.st[1][0] : 0.f)) + (op.st[2][0] + (two ? op.st[3][0] : 0.f));
-            float zq = (op.st[0][1] + (two ? op.st[1][1] : 0.f)) + (op.st[2][1] + (two ? op.st[3][1] : 0.f));
+            const bool one = ej < a.zparts, two = ej + 8 < a.zparts;   // (fewer than 8 parts: the lanes beyond them contribute nothing)
+            float zs = ((one ? op.st[0][0] : 0.f) + (two ? op.st[1][0] : 0.f)) + ((one ? op.st[2][0] : 0.f) + (two ? op.st[3][0] : 0.f));
+            float zq = ((one ? op.st[0][1] : 0.f) + (two ? op.st[1][1] : 0.f)) + ((one ? op.st[2][1] : 0.f) + (two ? op.st[3][1] : 0.f));
             zs = oct_sum(zs);
             zq = oct_sum(zq);
             const float inv_d = __builtin_amdgcn_rcpf((float)a.zD);

@@ -366,9 +366,9 @@ __device__ __forceinline__ void pp_store_resid(const GemmArgs& a, f32x4 (&acc)[F
         const bool alt = DUAL && (row < a.act_row0 || row >= a.act_row1);
         float zr = 1.f, zrm = 0.f;
         if constexpr (ZIN) {   // the row's statistics over the zD columns of both sets: the 4 lanes (cg) of a row sit 16 lanes apart; fixed order, bit-reproducible
-            const bool two = cg + 4 < a.zparts;
-            float zs = (zst[i][0].x + (two ? zst[i][1].x : 0.f)) + (zst[i][2].x + (two ? zst[i][3].x : 0.f));
-            float zq = (zst[i][0].y + (two ? zst[i][1].y : 0.f)) + (zst[i][2].y + (two ? zst[i][3].y : 0.f));
+            const bool one = cg < a.zparts, two = cg + 4 < a.zparts;   // (fewer than 4 parts: the lanes beyond them contribute nothing)
+            float zs = ((one ? zst[i][0].x : 0.f) + (two ? zst[i][1].x : 0.f)) + ((one ? zst[i][2].x : 0.f) + (two ? zst[i][3].x : 0.f));
+            float zq = ((one ? zst[i][0].y : 0.f) + (two ? zst[i][1].y : 0.f)) + ((one ? zst[i][2].y : 0.f) + (two ? zst[i][3].y : 0.f));
             zs += __shfl_xor(zs, 16, 64); zs += __shfl_xor(zs, 32, 64);
             zq += __shfl_xor(zq, 16, 64); zq += __shfl_xor(zq, 32, 64);
             const float inv_d = __builtin_amdgcn_rcpf((float)a.zD);
@@ -1278,14 +1278,15 @@ __global__ __launch_bounds__(512) void k_gemm_pp(GemmArgs a) {
         float2 zst[RF][4];
         if constexpr (RZIN) {   // partial statistics of the rows this wave finishes: parts cg, cg + 4 of both sets (zparts <= 8; clamped, weight 0 beyond: pp_store_resid)
             const int m_in = lane & 15, cg = lane >> 4;
+            const int p0 = cg < a.zparts ? cg : a.zparts - 1;
             const int p1 = cg + 4 < a.zparts ? cg + 4 : a.zparts - 1;
 #pragma unroll
             for (int i = 0; i < RF; ++i) {
                 int row = row0 + (wm * 2 + grp) * (TM / 2) + i * 16 + m_in;
                 row = row < a.M ? row : a.M - 1;
-                zst[i][0] = a.zstat_in[(long)cg * a.zs_stride + row];
+                zst[i][0] = a.zstat_in[(long)p0 * a.zs_stride + row];
                 zst[i][1] = a.zstat_in[(long)p1 * a.zs_stride + row];
-                zst[i][2] = a.zstat_in2[(long)cg * a.zs_stride + row];
+                zst[i][2] = a.zstat_in2[(long)p0 * a.zs_stride + row];
                 zst[i][3] = a.zstat_in2[(long)p1 * a.zs_stride + row];
             }
         }

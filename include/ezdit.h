@@ -211,6 +211,13 @@ int ezdit_test_gemm(ezdit_handle* h, int variant, const void* dev_a_bf16, int ld
 int ezdit_test_resid(int tile, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw, const float* dev_bias, const float* dev_h_in,
                      const float* dev_gate, const float* dev_zg, float* dev_h_out, void* dev_zu_bf16, int ld_zu, void* dev_zstat,
                      int M, int N, int K, ezdit_stream stream);
+/* ... and of its two skip-path forms (csrc/common.h GemmArgs COPY2 / ZIN; DESIGN.md "The skip path"): dev_zu2 != NULL -- additionally zu2 = bf16(h_out * zg2) ([M][ld_zu2]; gate and
+ * h_in required); dev_zstat_in2 != NULL -- the launch first finishes a LayerNorm over zD columns whose partial statistics come in two part-major sets of zparts parts
+ * (dev_zstat_in, dev_zstat_in2: [zparts][M] float pairs): acc := r (acc - mu zG[col]) + bias[col], no gate, no h_in.  dev_h_out NULL = the fp32 stream is not stored. */
+int ezdit_test_resid_skip(int tile, const void* dev_a_bf16, int lda, const void* dev_w_bf16, int ldw, const float* dev_bias, const float* dev_h_in,
+                          const float* dev_gate, const float* dev_zg, float* dev_h_out, void* dev_zu_bf16, int ld_zu, void* dev_zstat,
+                          int M, int N, int K, const float* dev_zg2, void* dev_zu2_bf16, int ld_zu2, const void* dev_zstat_in, const void* dev_zstat_in2,
+                          int zparts, int zD, const float* dev_zG, ezdit_stream stream);
 /* test hook: launches of k_gemm_pp / k_gemm_ks / k_attn record, per workgroup, eight 64-bit shader-clock stamps (kernel start, K-loop
  * start, K-loop end, kernel end, then epilogue internals) into dev_buf ([capacity_workgroups][8] uint64; NULL switches it off).  A launch
  * whose grid exceeds capacity_workgroups writes no stamps.  Un-register (NULL) before freeing the buffer. */

@@ -201,6 +201,86 @@ def _resid_case(lib, dev, M, N, K, tile, mode, hmean=0.7, var_rtol=2e-5, mean_at
     assert (zu.float().cpu()[:, N:] == 0).all()
 
 
+@pytest.mark.parametrize('tile', [70, 61])   # k_gemm_ks (one prompt) and the ping-pong producer (batched prompts)
+@pytest.mark.parametrize('M,D', [(1000, 1152), (300, 576), (77, 160)])   # 12 | 8, 6 | 4 and 2 statistics parts per half (fewer parts than lanes that fetch them)
+def test_skip_path_forms_of_the_residual_gemm(lib, dev, tile, M, D):
+    """The two forms the skip path adds to the un-split residual projection (GemmArgs COPY2 / ZIN), stand-alone against fp64.
+    COPY2 (the in-blocks' MLP-out, K = 4 D): everything _resid_case checks + the second operand bf16(h_new * g2).
+    ZIN (skip_linear, K = 2 D): the operand is bf16([x | skip] * g) with the halves' partial statistics in two part-major sets; the launch must produce
+    LN_2D([x | skip]) g-folded through W -- r (acc - mu G') + C' -- and then its own statistics and next operand like any producer.  Reference: the LayerNorm of the
+    UNROUNDED rows through fp64 (the operand's bf16 rounding is the only difference: 3e-3)."""
+    cw = ZW[tile]
+    parts = (D + cw - 1) // cw
+    g = torch.Generator().manual_seed(tile + M + D)
+    ld = (D + 63) // 64 * 64
+    Np = (D + 127) // 128 * 128
+    # ---- COPY2 ----
+    K = 4 * D
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = torch.zeros(Np, K, dtype=torch.bfloat16)
+    W[:D] = (torch.randn(D, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias, gate = torch.randn(D, generator=g), torch.rand(D, generator=g)
+    zg, zg2 = 1 + 0.3 * torch.randn(D, generator=g), 1 + 0.3 * torch.randn(D, generator=g)
+    h_in = torch.randn(M, D, generator=g) + 0.7
+    ref = h_in.double() + gate.double() * (A.float().double() @ W[:D].float().double().T + bias.double())
+    dv = [t.to(dev) for t in (A, W, bias, h_in, gate, zg, zg2)]
+    h_out = torch.full((M, D), float('nan'), device=dev)
+    zu = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    zu2 = torch.zeros(M, 2 * ld, dtype=torch.bfloat16, device=dev)     # the right half of an [M][2 ld] operand, as in the step
+    zs = torch.zeros(parts, M, 2, device=dev)
+    rc = lib.ezdit_test_resid_skip(tile, dv[0].data_ptr(), K, dv[1].data_ptr(), K, dv[2].data_ptr(), dv[3].data_ptr(), dv[4].data_ptr(), dv[5].data_ptr(),
+                                   h_out.data_ptr(), zu.data_ptr(), ld, zs.data_ptr(), M, D, K, dv[6].data_ptr(), zu2.data_ptr() + 2 * ld, 2 * ld, None, None, 0, 0, None, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = h_out.cpu().double()
+    assert rel_l2(got.numpy(), ref.numpy()) < 1e-5
+    assert rel_l2(zu.float().cpu().numpy()[:, :D], (got * zg.double()).float().numpy()) < 3e-3
+    z2 = zu2.float().cpu()
+    assert rel_l2(z2.numpy()[:, ld:ld + D], (got * zg2.double()).float().numpy()) < 3e-3
+    assert (z2[:, :ld] == 0).all() and (z2[:, ld + D:] == 0).all()          # nothing outside the half it owns
+    st = zs.cpu().double().permute(1, 0, 2)
+    np.testing.assert_allclose((st[:, :, 0].sum(1) / D).numpy(), ref.mean(1).numpy(), rtol=0, atol=2e-5)
+    # ---- ZIN ----
+    K = 2 * D
+    x = torch.randn(M, K, generator=g) * (1 + torch.rand(M, 1, generator=g)) + 0.5 * torch.randn(M, 1, generator=g)    # rows [x | skip] with their own mean and spread
+    gam, bet = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    Wf = torch.randn(D, K, generator=g) / K ** 0.5
+    W = torch.zeros(Np, K, dtype=torch.bfloat16)
+    W[:D] = Wf.to(torch.bfloat16)
+    Wd = W[:D].float().double()
+    b = torch.randn(D, generator=g)
+    A = (x * gam).to(torch.bfloat16)
+    mu, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+    ref = ((x.double() - mu) / torch.sqrt(var + 1e-5) * gam.double() + bet.double()) @ Wd.T + b.double()
+    Gp, Cp = (gam.double() @ Wd.T).float(), (bet.double() @ Wd.T + b.double()).float()
+    xs = x.double()
+
+    def part_stats(half):      # [parts][M][2]: (sum, sum of squares) over each cw-column tile of a half
+        out = torch.zeros(parts, M, 2, dtype=torch.float64)
+        for p_ in range(parts):
+            c = half[:, p_ * cw:min((p_ + 1) * cw, D)]
+            out[p_, :, 0], out[p_, :, 1] = c.sum(1), (c * c).sum(1)
+        return out.float()
+    s1, s2 = part_stats(xs[:, :D]), part_stats(xs[:, D:])
+    zg = 1 + 0.3 * torch.randn(D, generator=g)
+    dv = [t.to(dev) for t in (A, W, Cp, zg, s1, s2, Gp)]
+    h_out = torch.full((M, D), float('nan'), device=dev)
+    zu = torch.zeros(M, ld, dtype=torch.bfloat16, device=dev)
+    zs = torch.zeros(parts, M, 2, device=dev)
+    rc = lib.ezdit_test_resid_skip(tile, dv[0].data_ptr(), K, dv[1].data_ptr(), K, dv[2].data_ptr(), None, None, dv[3].data_ptr(),
+                                   h_out.data_ptr(), zu.data_ptr(), ld, zs.data_ptr(), M, D, K, None, None, 0, dv[4].data_ptr(), dv[5].data_ptr(), parts, K, dv[6].data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = h_out.cpu().double()
+    r = rel_l2(got.numpy(), ref.numpy())
+    record(f'ZIN tile {tile} M={M} D={D}: rel-L2 {r:.3e}')
+    assert r < 5e-3                                                     # the bf16 rounding of the operand
+    assert rel_l2(zu.float().cpu().numpy()[:, :D], (got * zg.double()).float().numpy()) < 3e-3
+    st = zs.cpu().double().permute(1, 0, 2)
+    np.testing.assert_allclose((st[:, :, 0].sum(1) / D).numpy(), got.mean(1).numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose((st[:, :, 1].sum(1) / D - (st[:, :, 0].sum(1) / D) ** 2).numpy(), got.var(1, unbiased=False).numpy(), rtol=1e-4)
+
+
 @pytest.mark.parametrize('tile', [6, 13, 2013, 2060, 2061, 2062, 2066])   # + 2000: LDS-staged epilogue; 60+: ping-pong kernel; 66: co-resident kernel
 def test_gemm_geglu_epilogue(lib, dev, tile):
     M, D, inner = 300, 128, 576
