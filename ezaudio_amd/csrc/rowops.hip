@@ -279,38 +279,95 @@ __global__ __launch_bounds__(256) void k_assemble(AssembleArgs a) {
 // weight row [C][3] is read with 16-byte loads (12 floats = 4 input channels x 3 taps per step), activations are LDS
 // broadcasts (every lane of a wave reads the same word).
 __global__ __launch_bounds__(256) void k_final_conv(FinalConvArgs a) {
+    // One workgroup = 4 output positions x all C output channels of one batch element.  A thread owns ONE output channel and HALF of the input channels (threads 0 - 127 the lower
+    // half, 128 - 255 the upper) for all four positions: its weight row segment (C / 2 x 3 floats, its own 16-byte loads -- 64 rows per load instruction, nothing to coalesce) is the
+    // kernel's critical path, a chain of dependent load batches; with four accumulators per thread and half a row each the chain is a quarter as long as in the round-1 form
+    // (one channel, two positions, the whole row: 24 batches of 12 loads, 19.4 us), the two halves meet in the LDS.
     constexpr int TL = 4;
-    extern __shared__ float sy[];  // [(TL+2)][C]
+    extern __shared__ float sy[];  // [(TL+2)][C] input rows, then [C][TL] partial sums of the upper half
     const int C = a.C;
+    float* red = sy + (TL + 2) * C;
     const int ltiles = (a.L + TL - 1) / TL;
     const int b = blockIdx.x / ltiles;
     const int l0 = (blockIdx.x % ltiles) * TL;
-    for (int i = threadIdx.x; i < (TL + 2) * C; i += 256) {
-        const int r = i / C, ci = i % C;
-        const int l = l0 + r - 1;
-        sy[r * C + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
-    }
-    __syncthreads();
-    const int ll = (threadIdx.x >> 7) * 2;
-    for (int co = threadIdx.x & 127; co < C; co += 128) {
-    float acc0 = a.b[co], acc1 = acc0;
-    const float* wr = a.w + (long)co * C * 3;
-    const float* s0 = sy + ll * C;
-    // 4 steps of the weight row in flight at once (same accumulation order: the loop was one L2 round trip per 4 input channels, 32 in a row)
-#pragma unroll 4
-    for (int ci = 0; ci < C; ci += 4) {
-        const float4 w0 = ld4(wr + ci * 3), w1 = ld4(wr + ci * 3 + 4), w2 = ld4(wr + ci * 3 + 8);
-        const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float y0 = s0[ci + e], y1 = s0[C + ci + e], y2 = s0[2 * C + ci + e], y3 = s0[3 * C + ci + e];
-            acc0 = fmaf(w[3 * e], y0, acc0); acc0 = fmaf(w[3 * e + 1], y1, acc0); acc0 = fmaf(w[3 * e + 2], y2, acc0);
-            acc1 = fmaf(w[3 * e], y1, acc1); acc1 = fmaf(w[3 * e + 1], y2, acc1); acc1 = fmaf(w[3 * e + 2], y3, acc1);
+    bool staged = false;
+    auto stage = [&]() {   // the TL + 2 input rows of this tile -> LDS.  Called BEHIND the first weight block's requests: one round trip instead of two in front of the first FMA
+        if (staged) return;
+        for (int i = threadIdx.x; i < (TL + 2) * C; i += 256) {
+            const int r = i / C, ci = i % C;
+            const int l = l0 + r - 1;
+            sy[r * C + ci] = (l >= 0 && l < a.L) ? a.y[((long)b * a.L + l) * a.ldy + ci] : 0.f;
         }
-    }
-    const int l = l0 + ll;
-    if (l < a.L) a.out[((long)b * C + co) * a.L + l] = acc0;
-    if (l + 1 < a.L) a.out[((long)b * C + co) * a.L + l + 1] = acc1;
+        __syncthreads();
+        staged = true;
+    };
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);   // wave-uniform
+    const bool split = (C & 7) == 0;             // (otherwise the lower half walks the whole row; C % 4 == 0 as ever)
+    const int ci_begin = split ? half * (C >> 1) : 0, ci_end = split ? (half + 1) * (C >> 1) : (half == 0 ? C : 0);
+    for (int co0 = 0; co0 < C; co0 += 128) {
+        const int co = co0 + (threadIdx.x & 127);
+        const bool co_ok = co < C;
+        float acc[TL] = {0.f, 0.f, 0.f, 0.f};
+        const float* wr = a.w + (long)(co_ok ? co : 0) * C * 3;
+        auto fma4 = [&](int ci, const float4& w0, const float4& w1, const float4& w2) {   // 4 input channels x 3 taps x TL positions
+            const float w[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y[TL + 2];
+#pragma unroll
+                for (int r = 0; r < TL + 2; ++r) y[r] = sy[r * C + ci + e];   // (broadcast reads: the address does not depend on the lane)
+#pragma unroll
+                for (int t = 0; t < TL; ++t) {
+                    acc[t] = fmaf(w[3 * e], y[t], acc[t]); acc[t] = fmaf(w[3 * e + 1], y[t + 1], acc[t]); acc[t] = fmaf(w[3 * e + 2], y[t + 2], acc[t]);
+                }
+            }
+        };
+        if (((ci_end - ci_begin) & 15) == 0) {
+            // blocks of 16 input channels = 12 16-byte loads; the NEXT block's loads are all issued before the current block's arithmetic (pinned: left to itself hipcc
+            // interleaves them three at a time with the FMAs, i.e. one L2 round trip per 4 channels again)
+            // Every workgroup reads the SAME 196 KB of weights; the workgroups of one position tile start at a block of their own (rotation by the tile index, the same for every
+            // batch element: a sample's bits do not depend on its place in the batch) so that 250 workgroups do not walk the same L2 lines in the same order at the same time
+            const int nblk = (ci_end - ci_begin) >> 4;
+            const int rot = (blockIdx.x % ltiles) % nblk;
+            float4 wc[12], wn[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) wc[q] = ld4(wr + (ci_begin + 16 * rot) * 3 + 4 * q);
+            __builtin_amdgcn_sched_barrier(0);
+            stage();
+            for (int ib = 0; ib < nblk; ++ib) {
+                int kb = ib + rot; kb = kb >= nblk ? kb - nblk : kb;
+                int kn = kb + 1; kn = kn >= nblk ? kn - nblk : kn;   // (behind the last block: a harmless re-load instead of a branch around the loads)
+                const int ci = ci_begin + 16 * kb, cn = ci_begin + 16 * kn;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) wn[q] = ld4(wr + cn * 3 + 4 * q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fma4(ci + 4 * q, wc[3 * q], wc[3 * q + 1], wc[3 * q + 2]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 12; ++q) wc[q] = wn[q];
+            }
+        } else {
+            stage();
+            for (int ci = ci_begin; ci < ci_end; ci += 4) fma4(ci, ld4(wr + ci * 3), ld4(wr + ci * 3 + 4), ld4(wr + ci * 3 + 8));
+        }
+        if (half == 1 && co_ok) *reinterpret_cast<float4*>(red + co * TL) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        if (half == 0 && co_ok) {
+            const float4 o = *reinterpret_cast<const float4*>(red + co * TL);
+            const float bb = a.b[co];
+            const float4 v = make_float4((acc[0] + o.x) + bb, (acc[1] + o.y) + bb, (acc[2] + o.z) + bb, (acc[3] + o.w) + bb);
+            float* dst = a.out + ((long)b * C + co) * a.L + l0;
+            if (l0 + TL <= a.L && (a.L & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = v;
+            } else {
+                if (l0 < a.L) dst[0] = v.x;
+                if (l0 + 1 < a.L) dst[1] = v.y;
+                if (l0 + 2 < a.L) dst[2] = v.z;
+                if (l0 + 3 < a.L) dst[3] = v.w;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -552,7 +609,7 @@ void launch_assemble(const AssembleArgs& a, hipStream_t st) {
 
 void launch_final_conv(const FinalConvArgs& a, hipStream_t st) {
     const int ltiles = (a.L + 3) / 4;
-    const size_t sh = (size_t)6 * a.C * sizeof(float);
+    const size_t sh = (size_t)(6 + 4) * a.C * sizeof(float);   // input rows + the upper half's partial sums
     hipLaunchKernelGGL(k_final_conv, dim3(a.B * ltiles), dim3(256), sh, st, a);
 }
 
