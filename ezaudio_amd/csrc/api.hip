@@ -82,6 +82,7 @@ struct ezdit_handle {
     std::map<std::string, Buf> bufs;
     bool ctx_ready = false, ts_ready = false, cond_ready = false;
     bool z_tables_ready = false;   // the LayerNorm-algebra tables of the prepared timesteps exist (opt_zfuse was on at ezdit_prepare_timesteps)
+    bool skip_tables_ready = false;   // ... and the static tables of the skip path (opt_skip_z was on as well): a forward never reads tables that were not built
     int n_ts = 0, per_row = 0;
 
     // sampler
@@ -899,6 +900,7 @@ int ezdit_prepare_timesteps(ezdit_handle* h, const int32_t* ts, int n, int per_r
     h->steps_done = 0;
     h->ts_ready = true;
     h->z_tables_ready = h->zfuse_usable();
+    h->skip_tables_ready = h->z_tables_ready && h->skip_z_usable();
     h->n_ts = n;
     h->per_row = per_row;
     return EZDIT_OK;
@@ -1034,7 +1036,7 @@ static int forward_impl(ezdit_handle* h, const float* x, int in_ch, int x_rows, 
         u_is_z = true;
     };
     // LN_2D([x | skip]) -> skip_linear by the LayerNorm algebra (opt_skip_z): not with ControlNet residuals (they change the skips)
-    const bool skipz = zf && h->skip_z_usable() && !(cn && n_cn > 0);
+    const bool skipz = zf && h->skip_tables_ready && h->skip_z_usable() && !(cn && n_cn > 0);
     const int zsp = (D + h->zwidth() - 1) / h->zwidth();                      // statistics parts of a D-wide producer
     auto ucat_of = [&](int j) { return p.ucat_z + (size_t)j * Mp * h->ld2D; };   // operand [x | skip] of out-block j
     auto zskip_of = [&](int i) { return p.zstat_skip + (size_t)i * Z_MAXP * Mp; };   // statistics of skip i

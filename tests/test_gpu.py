@@ -437,6 +437,30 @@ def test_skip_connection_layernorm_by_the_algebra_matches_reference_golden(lib, 
         assert r < REL_TOL and a < ABS_TOL * max(1.0, float(ref.std()) / 1.48), (name, v, r, a)
 
 
+def test_skip_path_is_not_taken_on_tables_that_were_not_built(lib, dev):
+    """The static G' / C' tables of the skip path are built by ezdit_prepare_timesteps when skip_z is on.  A C-ABI caller that prepares with skip_z = 0, switches the option on and
+    calls ezdit_forward WITHOUT preparing again must get the row-kernel path (same bits, same launch count), not a LayerNorm finished on tables that do not exist."""
+    cfg, sd, inp, kw, g, meta = golden_case('s')
+    m = get_model('s', meta['seed_w'])
+    t = meta['timesteps'][0]
+    try:
+        assert lib.ezdit_set_option(m._h, b'skip_z', 0) == 0
+        want = _forward(m, inp, t, kw)                       # binds, prepares context and timesteps with skip_z off
+        n_off = m.last_launch_count
+        x = m._keep[0]
+        assert lib.ezdit_set_option(m._h, b'skip_z', 1) == 0
+        got = torch.empty_like(want)
+        assert lib.ezdit_forward(m._h, x.data_ptr(), x.shape[1], x.shape[0], None, None, None, 0, got.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert m.last_launch_count == n_off
+        assert torch.equal(got, want)
+        again = _forward(m, inp, t, kw)                      # prepared again with the option on: the skip path runs
+        assert m.last_launch_count == n_off - cfg['depth'] // 2
+        assert rel_l2(again.cpu().numpy(), want.cpu().numpy()) < 1e-2
+    finally:
+        assert lib.ezdit_set_option(m._h, b'skip_z', 1) == 0
+
+
 @pytest.mark.parametrize('size,n_valid,act,L', [('s', (9, 1), (0, 1), 100), ('s', (1, 9), (1, 2), 100), ('s64', (1, 1), (0, 0), 100), ('s', (9, 1, 5), None, 100), ('s', (9, 4, 1, 1), (0, 2), 100),
                                                 ('xs', (1, 6, 20, 1), (1, 3), 100),
                                                 # > 2048 token rows: the ping-pong kernel's 128 x 144 producer in its DUAL form (BASELINE config #4's layout: P cond rows, then P uncond rows)
