@@ -140,3 +140,32 @@ def test_single_key_cross_attention_is_the_constant_the_shortcut_adds():
         d = (ctx[b, key] @ wv.T) @ wo.T + bo           # W_o v_key + b_o
         np.testing.assert_allclose(out[b], np.broadcast_to(d, (L, D)), rtol=0, atol=1e-12)
     assert np.abs(out[2] - out[2][0:1]).max() > 1e-3   # six valid keys: the rows differ
+
+
+def test_skip_connection_layernorm_is_the_algebra_the_skip_path_runs():
+    """The identity the product's `skip_z` path rests on (csrc/gemm_ks.h forms COPY2 / ZIN, DESIGN.md "The skip path"), checked on the oracle that is pinned to the reference
+    (blocks.py:124-128: x = skip_linear(skip_norm(cat[x, skip]))): with the per-tile partial (sum, sum of squares) of the two HALVES -- the skip's produced many blocks earlier --
+    the row statistics of the concatenation are plain sums, and  r (([x | skip] * g) W^T - mu G') + C'  with G' = g W^T, C' = c W^T + b  is the reference's result."""
+    cfg = model_config('xs')
+    from oracle.dit import layer_norm, linear, LN_EPS
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(cfg, 4)
+    o = DiTOracle(cfg, sd, np.float64)
+    D, M, cw = cfg['embed_dim'], 37, 96
+    pfx = 'model.out_blocks.0'
+    g, c = o.p(f'{pfx}.skip_norm.weight'), o.p(f'{pfx}.skip_norm.bias')
+    W, b = o.p(f'{pfx}.skip_linear.weight'), o.p(f'{pfx}.skip_linear.bias')
+    x = uniform_pm1('skipz.x', M * D, 11).reshape(M, D).astype(np.float64) * 1.3 + 0.4
+    skip = uniform_pm1('skipz.s', M * D, 12).reshape(M, D).astype(np.float64) * 0.6 - 0.2
+    want = linear(layer_norm(np.concatenate([x, skip], -1), g, c), W, b)
+
+    def parts(h):       # what a producer stores: (sum, sum of squares) over each cw-column tile of its D columns
+        return [(h[:, i:i + cw].sum(1), (h[:, i:i + cw] ** 2).sum(1)) for i in range(0, D, cw)]
+    s1 = sum(p[0] for p in parts(x)) + sum(p[0] for p in parts(skip))
+    s2 = sum(p[1] for p in parts(x)) + sum(p[1] for p in parts(skip))
+    mu = s1 / (2 * D)
+    r = 1.0 / np.sqrt(s2 / (2 * D) - mu * mu + LN_EPS)
+    A = np.concatenate([x * g[:D], skip * g[D:]], -1)            # the two halves of the operand, each written by its own producer
+    Gp, Cp = g @ W.T, c @ W.T + b
+    got = r[:, None] * (A @ W.T - mu[:, None] * Gp) + Cp
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
